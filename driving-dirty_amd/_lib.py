@@ -1,0 +1,72 @@
+"""ctypes binding of ``csrc/libdd_hotpath.so`` (C ABI: ``include/dd_hotpath.h``).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+from .build import LIB
+
+_i32, _i64, _f32, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct dd_conv_desc"""
+    _fields_ = [(n, _i32) for n in ("batch", "height", "width", "cin_real", "cin_store", "cout",
+                                    "ksize", "stride", "pad", "rows_per_task")]
+
+
+_DP = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/dd_hotpath.h one to one
+SIGNATURES = {
+    "dd_abi_version": (_i32, []),
+    "dd_last_error": (C.c_char_p, []),
+    "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_nhwc_to_nchw": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_conv_packed_floats": (_i64, [_DP, _i32]),
+    "dd_conv_pack": (_i32, [_p, _p, _DP, _i32, _p]),
+    "dd_conv_fwd": (_i32, [_p, _p, _p, _p, _p, _DP, _i32, _p]),
+    "dd_conv_dgrad": (_i32, [_p, _p, _p, _p, _DP, _p]),
+    "dd_conv_wgrad_workspace_bytes": (_i64, [_DP]),
+    "dd_conv_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _DP, _p]),
+    "dd_relu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
+    "dd_pool4_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_pool4_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_bn_relu_drop_fwd": (_i32, [_p] * 9 + [_i32, _i32, _f32, _f32, _f32, _i32, _p]),
+    "dd_bn_relu_drop_bwd": (_i32, [_p] * 12 + [_i32, _i32, _f32, _f32, _i32, _p]),
+    "dd_loss_workspace_bytes": (_i64, [_i64]),
+    "dd_bce_logits": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
+    "dd_mse": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
+    "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
+}
+
+_lib = None
+
+
+class HotpathError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise HotpathError(
+                f"{LIB} is missing: build the HIP extension first (python -m driving_dirty_amd.build "
+                "or __graft_entry__.build()). There is no CPU / eager fallback for the hot path.")
+        handle = C.CDLL(LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.dd_abi_version() != 1:
+            raise HotpathError("libdd_hotpath.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HotpathError(f"{what} failed (code {rc}): {lib().dd_last_error().decode()}")

@@ -1,0 +1,86 @@
+"""Encoder / Decoder / DenseBlock with the reference's constructor signatures, attribute names and
+``state_dict`` keys (reference src/autoencoder/components.py), computed by the HIP hot path.
+
+Drop-in contract kept from the reference:
+  * ``Encoder(hidden_dim, latent_dim, in_channels, input_height, input_width)``, attribute ``c3_only``
+    (components.py:11,31,44-45); ``forward(x[B,3,H,W]) -> z[B,latent]`` or the conv feature
+    ``[B,32,H/2,W/2]`` (returned as an NCHW-shaped channels_last tensor: same values, NHWC memory);
+  * ``DenseBlock(in_dim, out_dim, drop_p=0.2)``: Linear -> BatchNorm1d -> ReLU -> dropout that is
+    ALWAYS active (components.py:108 omits ``training=``) with ``drop_p`` read at call time;
+  * parameters are ordinary ``nn.Parameter``s in PyTorch layouts, created in the reference's order with
+    the same RNG consumption, so the same seed gives the same initial weights and checkpoints load.
+There is no CPU path: the forward raises if its input is not on a GPU or the HIP library is missing.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+
+POOL = 4
+
+
+def _require_gpu(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: the hot path runs on MI355X only (got a {t.device} tensor); "
+                           "the CPU restatement lives in oracle/ and is test infrastructure")
+
+
+class DenseBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, drop_p=0.2):
+        super().__init__()
+        self.drop_p = drop_p
+        self.fc1 = nn.Linear(in_dim, out_dim)
+        self.fc_bn = nn.BatchNorm1d(out_dim)
+        self.in_dim = in_dim
+
+    def forward(self, x, keep=None):
+        """``keep`` (optional 0/1 tensor) injects the dropout mask; otherwise one is drawn on the device."""
+        _require_gpu(x, "DenseBlock")
+        lin = F.linear(x, self.fc1.weight, self.fc1.bias)
+        bn = self.fc_bn
+        p = float(self.drop_p)
+        if keep is None and p > 0.0:
+            keep = torch.bernoulli(torch.full_like(lin, 1.0 - p))
+        training = bn.training or bn.running_mean is None
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        scale = 1.0 / (1.0 - p) if p < 1.0 else 0.0
+        return ops.BnReluDrop.apply(lin.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, keep,
+                                    training, bn.eps, momentum, scale)
+
+
+class Encoder(nn.Module):
+    def __init__(self, hidden_dim, latent_dim, in_channels, input_height, input_width):
+        super().__init__()
+        if in_channels != 3:
+            raise ValueError("the MI355X conv stack is built for 3-channel camera images")
+        self.hidden_dim, self.latent_dim = hidden_dim, latent_dim
+        self.input_height, self.input_width, self.in_channels = input_height, input_width, in_channels
+        # nn.Conv2d modules only hold the parameters (names + default init); the arithmetic is ops.EncoderConvStack
+        self.c1 = nn.Conv2d(in_channels, 32, kernel_size=3, padding=1)
+        self.c2 = nn.Conv2d(32, 32, kernel_size=3, padding=1)
+        self.c3 = nn.Conv2d(32, 32, kernel_size=3, stride=2, padding=1)
+        self.pooling_size = POOL
+        torch.rand(1, in_channels, input_height, input_width)   # RNG parity with the reference's sizing dry run (:34)
+        ho, wo = ops.conv_out(input_height, 2), ops.conv_out(input_width, 2)
+        self.fc1 = DenseBlock((32 * ho * wo) // POOL, hidden_dim)
+        self.fc2 = DenseBlock(hidden_dim, hidden_dim)
+        self.fc_z_out = nn.Linear(hidden_dim, latent_dim)
+        self.c3_only = False
+        self.rows_per_task = 0     # kernel tuning knob (never changes results)
+
+    def forward_nhwc4(self, x4, keeps=(None, None)):
+        """x4: [B,H,W,4] NHWC image (channel 3 zero), e.g. straight from ``ops.stitch6``."""
+        if self.c3_only:
+            feat = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, False, self.rows_per_task)
+            return feat.permute(0, 3, 1, 2)         # NCHW-shaped view of the NHWC buffer
+        pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, True, self.rows_per_task)
+        h = self.fc1(pooled, keeps[0])
+        h = self.fc2(h, keeps[1])
+        return F.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
+
+    def forward(self, x, keeps=(None, None)):
+        _require_gpu(x, "Encoder")
+        return self.forward_nhwc4(ops.nchw_to_nhwc(x.contiguous(), 4), keeps)

@@ -1,0 +1,667 @@
+// 3x3 convolution family for the encoder conv stack (reference src/autoencoder/components.py:19-21,41-43)
+// as implicit GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32), NHWC activations.
+//
+// Decomposition ("strip marching"): one WAVE owns a strip of 32 output pixels of one image row band
+// and marches down the rows.  It keeps the three input rows a 3x3 window needs in its own LDS ring
+// (3 slots), prefetches the next row(s) into registers while the matrix cores work on the current
+// row, and never synchronises with another wave: no barrier in the main loop.  The GEMM view is
+// M = 32 pixels, N = 32 output channels, K = 9 taps x Cin; fp32 MFMA issues once per 64 cycles per
+// SIMD, so LDS (2 x ds_read_b128 per 4 MFMAs) and HBM (one 4.3 KB row per 9216 MFMA cycles) are far
+// from binding: the kernels are MFMA-issue bound by construction.
+//
+//   conv_strip_fwd <CIN,S,EPI>  forward (bias+ReLU epilogue) and stride-1 data gradient (ReLU-mask epilogue)
+//   conv_s2_dgrad               data gradient of the stride-2 conv, by output parity class (no zero insertion)
+//   conv_wgrad <CIN,S>          weight + bias gradient, persistent waves, register accumulators,
+//                               deterministic two-stage reduction
+#include "dd_common.h"
+
+namespace {
+
+template <int CIN, int S>
+struct StripCfg {
+  static constexpr int PXB = CIN * 4;        // bytes per pixel
+  static constexpr int CHUNKS = CIN / 4;     // 16-byte chunks per pixel
+  static constexpr int NPX = 32 * S + 2;     // input pixels a 32-wide output strip touches (+1 spare for S=2)
+  static constexpr int SLOTB = NPX * PXB;    // one ring slot = one input row of the strip
+  static constexpr int NCH = NPX * CHUNKS;
+  static constexpr int NLOAD = (NCH + 63) / 64;
+  static constexpr int KGROUPS = (CIN == 32) ? 36 : 5;   // groups of 4 MFMA k-steps
+  static constexpr int WFLOATS = KGROUPS * 64 * 4;
+};
+
+// XOR swizzle of the 16-byte chunk index inside a 128-byte pixel so that the ds_read_b128 of 16
+// consecutive pixels (one lane group) covers all 64 banks: pixels q and q+1 differ in address bit 7,
+// (q>>1)&7 spreads the other 8 pixel pairs over the 8 chunk positions.
+template <int CIN>
+__device__ __forceinline__ int swz(int q) {
+  return CIN == 32 ? ((q >> 1) & 7) : 0;
+}
+
+// Load one row of a strip (NPX pixels starting at gx0, row iy of image `img`) into registers.
+// Out-of-image pixels read a clamped (valid) address and are zeroed afterwards: no branches around loads.
+template <int CIN, int S>
+__device__ __forceinline__ void load_row(const float* __restrict__ img, int H, int W, int iy, int gx0, int lane,
+                                         f32x4 (&r)[StripCfg<CIN, S>::NLOAD]) {
+  using C = StripCfg<CIN, S>;
+  const bool rowok = (iy >= 0) && (iy < H);
+  const int iyc = min(max(iy, 0), H - 1);
+  const float* rp = img + (long)iyc * W * CIN;
+#pragma unroll
+  for (int i = 0; i < C::NLOAD; ++i) {
+    const int c = lane + 64 * i;
+    const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
+    const int gx = gx0 + q;
+    const bool ok = rowok && (c < C::NCH) && (gx >= 0) && (gx < W);
+    const int gxc = min(max(gx, 0), W - 1);
+    f32x4 v = *(const f32x4*)(rp + (long)gxc * CIN + ch * 4);
+    r[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int CIN, int S, bool SWZ>
+__device__ __forceinline__ void store_row(char* slot, int lane, const f32x4 (&r)[StripCfg<CIN, S>::NLOAD]) {
+  using C = StripCfg<CIN, S>;
+#pragma unroll
+  for (int i = 0; i < C::NLOAD; ++i) {
+    const int c = lane + 64 * i;
+    const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
+    if (c < C::NCH) *(f32x4*)(slot + q * C::PXB + ((ch ^ (SWZ ? swz<CIN>(q) : 0)) << 4)) = r[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / stride-1 dgrad
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int S, int EPI, int WPB>
+__global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ msk, float* __restrict__ y,
+                                                           int B, int H, int W, int Ho, int Wo, int nstrips,
+                                                           int nbands, int RB) {
+  using C = StripCfg<CIN, S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    f32x4* wl4 = (f32x4*)smem;
+    const f32x4* wg4 = (const f32x4*)wp;
+    for (int i = tid; i < C::WFLOATS / 4; i += WPB * 64) wl4[i] = wg4[i];
+  }
+  __syncthreads();
+  const long total = (long)B * nbands * nstrips;
+  const long task = (long)blockIdx.x * WPB + wave;
+  if (task >= total) return;
+  const int strip = (int)(task % nstrips);
+  const int band = (int)((task / nstrips) % nbands);
+  const int b = (int)(task / ((long)nstrips * nbands));
+  const int x0 = strip * 32, y0 = band * RB;
+  const int y1 = min(y0 + RB, Ho);
+  char* ring = smem + C::WFLOATS * 4 + wave * 3 * C::SLOTB;
+  const char* wl = smem;
+  const int h = lane >> 5, n = lane & 31;
+  const float* xb = x + (long)b * H * W * CIN;
+  const float bv = (EPI == DD_EPI_BIAS || EPI == DD_EPI_BIAS_RELU) ? bias[n] : 0.f;
+  const int gx0 = S * x0 - 1;
+
+  {  // prologue: the three rows output row y0 needs
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      f32x4 t[C::NLOAD];
+      const int iy = S * y0 - 1 + d;
+      load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
+      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, lane, t);
+    }
+  }
+
+  for (int yy = y0; yy < y1; ++yy) {
+    // prefetch the S new input rows output row yy+1 needs (overlaps the MFMAs below)
+    f32x4 pre[S][C::NLOAD];
+#pragma unroll
+    for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
+
+    float mreg[16];
+    if (EPI == DD_EPI_RELU_MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int xo = min(x0 + dd_acc_row(r, lane), Wo - 1);
+        mreg[r] = msk[((long)(b * Ho + yy) * Wo + xo) * 32 + n];
+      }
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (CIN == 32) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;   // slot of input row S*yy-1+dy
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int q = S * n + dx;
+          const char* pa = rowb + q * 128;
+          const int sw = swz<32>(q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 a = *(const f32x4*)(pa + (((2 * j + h) ^ sw) << 4));
+            const f32x4 w = *(const f32x4*)(wl + (((dy * 3 + dx) * 4 + j) * 64 + lane) * 16);
+            acc = DD_MFMA(a.x, w.x, acc);
+            acc = DD_MFMA(a.y, w.y, acc);
+            acc = DD_MFMA(a.z, w.z, acc);
+            acc = DD_MFMA(a.w, w.w, acc);
+          }
+        }
+      }
+    } else {  // CIN == 4 (3 real channels): k-step = one channel of a PAIR of taps (lower / upper half-wave)
+#pragma unroll
+      for (int jp = 0; jp < 5; ++jp) {
+        const int tap = min(2 * jp + h, 8);   // tap 9 does not exist: its packed weights are zero
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;
+        const f32x4 a = *(const f32x4*)(rowb + (S * n + dx) * 16);
+        const f32x4 w = *(const f32x4*)(wl + (jp * 64 + lane) * 16);
+        acc = DD_MFMA(a.x, w.x, acc);
+        acc = DD_MFMA(a.y, w.y, acc);
+        acc = DD_MFMA(a.z, w.z, acc);
+      }
+    }
+
+    // epilogue: lane = output channel, register = pixel -> 128-byte contiguous stores per pixel
+    float* yrow = y + ((long)(b * Ho + yy) * Wo) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int xo = x0 + dd_acc_row(r, lane);
+      float v = acc[r];
+      if (EPI == DD_EPI_BIAS) v += bv;
+      if (EPI == DD_EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
+      if (EPI == DD_EPI_RELU_MASK) v = (mreg[r] > 0.f) ? v : 0.f;
+      if (xo < Wo) yrow[(long)xo * 32 + n] = v;
+    }
+
+    // retire the prefetched rows into the slots of the rows no longer needed
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int iy = S * yy + 2 + s;
+      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, lane, pre[s]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stride-2 data gradient.  dx[yi][xi] collects, per parity class (yi&1, xi&1), 1/2/2/4 taps:
+//   yi = 2r   : ky = 1 from dy row r            yi = 2r+1 : ky = 0 from row r+1, ky = 2 from row r
+// (same along x), so a pair of output rows x 64 output pixels costs the same 144 MFMAs the forward
+// spends on 32 output pixels -- no multiplies by inserted zeros.
+// ------------------------------------------------------------------------------------------------
+template <int WPB, bool MASK>
+__global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restrict__ dy, const float* __restrict__ wp,
+                                                          const float* __restrict__ msk, float* __restrict__ dx,
+                                                          int B, int H, int W, int Ho, int Wo, int nstrips,
+                                                          int nbands, int RB) {
+  using C = StripCfg<32, 1>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    f32x4* wl4 = (f32x4*)smem;
+    const f32x4* wg4 = (const f32x4*)wp;
+    for (int i = tid; i < C::WFLOATS / 4; i += WPB * 64) wl4[i] = wg4[i];
+  }
+  __syncthreads();
+  const int nr = (H + 1) / 2;   // output row pairs
+  const long total = (long)B * nbands * nstrips;
+  const long task = (long)blockIdx.x * WPB + wave;
+  if (task >= total) return;
+  const int strip = (int)(task % nstrips);
+  const int band = (int)((task / nstrips) % nbands);
+  const int b = (int)(task / ((long)nstrips * nbands));
+  const int s0 = strip * 32, r0 = band * RB;
+  const int r1 = min(r0 + RB, nr);
+  char* ring = smem + C::WFLOATS * 4 + wave * 3 * C::SLOTB;
+  const char* wl = smem;
+  const int h = lane >> 5, n = lane & 31;
+  const float* dyb = dy + (long)b * Ho * Wo * 32;
+
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    f32x4 t[C::NLOAD];
+    load_row<32, 1>(dyb, Ho, Wo, r0 + d, s0, lane, t);
+    store_row<32, 1, true>(ring + ((r0 + d) % 3) * C::SLOTB, lane, t);
+  }
+
+  for (int r = r0; r < r1; ++r) {
+    f32x4 pre[C::NLOAD];
+    load_row<32, 1>(dyb, Ho, Wo, r + 2, s0, lane, pre);
+
+    f32x16 a00, a01, a10, a11;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
+
+    const char* row_r = ring + (r % 3) * C::SLOTB;
+    const char* row_r1 = ring + ((r + 1) % 3) * C::SLOTB;
+    const int q0 = n, q1 = n + 1;
+    const int sw0 = swz<32>(q0), sw1 = swz<32>(q1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = 2 * j + h;
+      const f32x4 A_r_s = *(const f32x4*)(row_r + q0 * 128 + ((ch ^ sw0) << 4));
+      const f32x4 A_r_s1 = *(const f32x4*)(row_r + q1 * 128 + ((ch ^ sw1) << 4));
+      const f32x4 A_r1_s = *(const f32x4*)(row_r1 + q0 * 128 + ((ch ^ sw0) << 4));
+      const f32x4 A_r1_s1 = *(const f32x4*)(row_r1 + q1 * 128 + ((ch ^ sw1) << 4));
+#define DD_TAP(ACC, A, T)                                                        \
+  {                                                                              \
+    const f32x4 w = *(const f32x4*)(wl + ((((T)) * 4 + j) * 64 + lane) * 16);    \
+    ACC = DD_MFMA(A.x, w.x, ACC);                                                \
+    ACC = DD_MFMA(A.y, w.y, ACC);                                                \
+    ACC = DD_MFMA(A.z, w.z, ACC);                                                \
+    ACC = DD_MFMA(A.w, w.w, ACC);                                                \
+  }
+      DD_TAP(a00, A_r_s, 4)      // (ky,kx) = (1,1)
+      DD_TAP(a01, A_r_s1, 3)     // (1,0)
+      DD_TAP(a01, A_r_s, 5)      // (1,2)
+      DD_TAP(a10, A_r1_s, 1)     // (0,1)
+      DD_TAP(a10, A_r_s, 7)      // (2,1)
+      DD_TAP(a11, A_r1_s1, 0)    // (0,0)
+      DD_TAP(a11, A_r1_s, 2)     // (0,2)
+      DD_TAP(a11, A_r_s1, 6)     // (2,0)
+      DD_TAP(a11, A_r_s, 8)      // (2,2)
+#undef DD_TAP
+    }
+
+#define DD_EMIT(ACC, PY, PX)                                                      \
+  {                                                                               \
+    const int yi = 2 * r + (PY);                                                  \
+    if (yi < H) {                                                                 \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                         \
+        const int xi = 2 * (s0 + dd_acc_row(rr, lane)) + (PX);                    \
+        if (xi < W) {                                                             \
+          const long o = ((long)(b * H + yi) * W + xi) * 32 + n;                  \
+          float v = ACC[rr];                                                      \
+          if (MASK) v = (msk[o] > 0.f) ? v : 0.f;                                 \
+          dx[o] = v;                                                              \
+        }                                                                         \
+      }                                                                           \
+    }                                                                             \
+  }
+    DD_EMIT(a00, 0, 0)
+    DD_EMIT(a01, 0, 1)
+    DD_EMIT(a10, 1, 0)
+    DD_EMIT(a11, 1, 1)
+#undef DD_EMIT
+
+    store_row<32, 1, true>(ring + ((r + 2) % 3) * C::SLOTB, lane, pre);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight / bias gradient.  GEMM view: M = 32 output channels, N = 32 input channels (one 32x32 tile per
+// tap, 9 register accumulators), K = pixels.  A = dy (straight from HBM, 256 contiguous bytes per
+// wave-load), B = x rows from the LDS ring (ds_read_b32, 32 consecutive dwords per half-wave).
+// Persistent waves accumulate over all their tasks and write ONE partial each.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int S, int WPB>
+__global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ part, float* __restrict__ bpart, int B,
+                                                       int H, int W, int Ho, int Wo, int nstrips, int nbands,
+                                                       int RB) {
+  using C = StripCfg<CIN, S>;
+  constexpr int NT = (CIN == 32) ? 9 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ring = smem + wave * 3 * C::SLOTB;
+  const int h = lane >> 5, n = lane & 31;
+  const long total = (long)B * nbands * nstrips;
+  const int gw = blockIdx.x * WPB + wave;
+  const int nw = gridDim.x * WPB;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  // CIN == 4: output column j = lane&31 stands for (tap, channel) = (j/3, j%3); columns >= 27 are ignored.
+  const int tap4 = min(n / 3, 8), c4 = n % 3;
+  const int dy4 = tap4 / 3, dx4 = tap4 - 3 * dy4;
+
+  for (long task = gw; task < total; task += nw) {
+    const int strip = (int)(task % nstrips);
+    const int band = (int)((task / nstrips) % nbands);
+    const int b = (int)(task / ((long)nstrips * nbands));
+    const int x0 = strip * 32, y0 = band * RB;
+    const int y1 = min(y0 + RB, Ho);
+    const float* xb = x + (long)b * H * W * CIN;
+    const float* dyb = dy + (long)b * Ho * Wo * 32;
+    const int gx0 = S * x0 - 1;
+
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      f32x4 t[C::NLOAD];
+      const int iy = S * y0 - 1 + d;
+      load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
+      store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, lane, t);
+    }
+    float areg[16];
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp) {
+      const int xo = x0 + 2 * pp + h;
+      const float v = dyb[((long)y0 * Wo + min(xo, Wo - 1)) * 32 + n];
+      areg[pp] = (xo < Wo) ? v : 0.f;
+    }
+
+    for (int yy = y0; yy < y1; ++yy) {
+      f32x4 pre[S][C::NLOAD];
+#pragma unroll
+      for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
+      float anext[16];
+      {
+        const int yn = min(yy + 1, Ho - 1);
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+          const int xo = x0 + 2 * pp + h;
+          const float v = dyb[((long)yn * Wo + min(xo, Wo - 1)) * 32 + n];
+          anext[pp] = (xo < Wo) ? v : 0.f;
+        }
+      }
+
+      if (CIN == 32) {
+        const char* rb0 = ring + ((S * yy + 0) % 3) * C::SLOTB;
+        const char* rb1 = ring + ((S * yy + 1) % 3) * C::SLOTB;
+        const char* rb2 = ring + ((S * yy + 2) % 3) * C::SLOTB;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+          const float a = areg[pp];
+          bsum += a;
+          const int off = (S * (2 * pp + h)) * 128 + n * 4;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            acc[0 + dx] = DD_MFMA(a, *(const float*)(rb0 + off + dx * 128), acc[0 + dx]);
+            acc[3 + dx] = DD_MFMA(a, *(const float*)(rb1 + off + dx * 128), acc[3 + dx]);
+            acc[6 + dx] = DD_MFMA(a, *(const float*)(rb2 + off + dx * 128), acc[6 + dx]);
+          }
+        }
+      } else {
+        const char* rb = ring + ((S * yy + dy4) % 3) * C::SLOTB + dx4 * 16 + c4 * 4;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+          const float a = areg[pp];
+          bsum += a;
+          acc[0] = DD_MFMA(a, *(const float*)(rb + (S * (2 * pp + h)) * 16), acc[0]);
+        }
+      }
+
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int iy = S * yy + 2 + s;
+        store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, lane, pre[s]);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 16; ++pp) areg[pp] = anext[pp];
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(((long)gw * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+  bpart[(long)gw * 64 + lane] = bsum;
+}
+
+// Second stage: sum the per-wave partials in a fixed order and scatter to OIHW.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ part,
+                                                         const float* __restrict__ bpart, float* __restrict__ dw,
+                                                         float* __restrict__ db, int nw) {
+  constexpr int NT = (CIN == 32) ? 9 : 1;
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int row = blockIdx.x;   // (t*16 + r), or NT*16 for the bias
+  float s = 0.f;
+  if (row < NT * 16) {
+    for (int w = g; w < nw; w += 4) s += part[((long)w * NT * 16 + row) * 64 + l];
+  } else {
+    for (int w = g; w < nw; w += 4) s += bpart[(long)w * 64 + l];
+  }
+  red[g][l] = s;
+  __syncthreads();
+  if (g != 0) return;
+  s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  if (row < NT * 16) {
+    const int t = row >> 4, r = row & 15;
+    const int o = dd_acc_row(r, l), j = l & 31;
+    if (CIN == 32) {
+      dw[((long)o * 32 + j) * 9 + t] = s;
+    } else if (j < 27) {
+      dw[((long)o * 3 + (j % 3)) * 9 + (j / 3)] = s;
+    }
+  } else {
+    const float other = __shfl_xor(s, 32);   // lanes l and l+32 hold the two pixel parities of channel l&31
+    if (l < 32) db[l] = s + other;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: PyTorch OIHW -> the per-lane B-operand image the kernels read with ds_read_b128.
+//   CIN=32: packed[((t*4 + j)*64 + lane)*4 + i] = Weff[n = lane&31][c = 8j + 4(lane>>5) + i][t]
+//   CIN=4 : packed[(jp*64 + lane)*4 + i]        = W[n][i][tap = 2jp + (lane>>5)]  (0 for tap 9 / i == 3)
+// kind 0: Weff = W;  kind 1: Weff[n][c][t] = W[c][n][8-t] (stride-1 dgrad);  kind 2: Weff[n][c][t] = W[c][n][t].
+// ------------------------------------------------------------------------------------------------
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int cin_real, int kind) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cin_real == 32) {
+    if (idx >= 36 * 64 * 4) return;
+    const int i = idx & 3, lane = (idx >> 2) & 63, g = idx >> 8;
+    const int j = g & 3, t = g >> 2;
+    const int n = lane & 31, c = 8 * j + 4 * (lane >> 5) + i;
+    float v;
+    if (kind == 0) v = w[((long)n * 32 + c) * 9 + t];
+    else if (kind == 1) v = w[((long)c * 32 + n) * 9 + (8 - t)];
+    else v = w[((long)c * 32 + n) * 9 + t];
+    p[idx] = v;
+  } else {
+    if (idx >= 5 * 64 * 4) return;
+    const int i = idx & 3, lane = (idx >> 2) & 63, jp = idx >> 8;
+    const int n = lane & 31, tap = 2 * jp + (lane >> 5);
+    p[idx] = (tap < 9 && i < 3) ? w[((long)n * 3 + i) * 9 + tap] : 0.f;
+  }
+}
+
+__global__ void relu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ y, f32x4* __restrict__ out,
+                                long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g = dy[i], v = y[i];
+    f32x4 o;
+    o.x = v.x > 0.f ? g.x : 0.f;
+    o.y = v.y > 0.f ? g.y : 0.f;
+    o.z = v.z > 0.f ? g.z : 0.f;
+    o.w = v.w > 0.f ? g.w : 0.f;
+    out[i] = o;
+  }
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+  static thread_local const void* done[16];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kernel) return 0;
+  if (ndone < 16) done[ndone++] = (const void*)kernel;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? 0 : dd_fail(DD_ERR_LAUNCH, "hipFuncSetAttribute(%zu bytes LDS): %s", bytes, hipGetErrorString(e));
+}
+
+int check_desc(const dd_conv_desc* d) {
+  DD_REQUIRE(d != nullptr, DD_ERR_BAD_ARG, "conv: NULL descriptor");
+  DD_REQUIRE(d->batch > 0 && d->height > 0 && d->width > 0, DD_ERR_BAD_ARG, "conv: non-positive size");
+  DD_REQUIRE(d->ksize == 3 && d->pad == 1, DD_ERR_UNSUPPORTED, "conv: only k3 p1 is implemented (got k%d p%d)", d->ksize, d->pad);
+  DD_REQUIRE(d->stride == 1 || d->stride == 2, DD_ERR_UNSUPPORTED, "conv: stride %d", d->stride);
+  DD_REQUIRE(d->cout == 32, DD_ERR_UNSUPPORTED, "conv: Cout %d (only 32)", d->cout);
+  DD_REQUIRE((d->cin_real == 32 && d->cin_store == 32) || (d->cin_real == 3 && d->cin_store == 4), DD_ERR_UNSUPPORTED,
+             "conv: Cin %d stored as %d (supported: 32/32, 3/4)", d->cin_real, d->cin_store);
+  DD_REQUIRE(!(d->cin_real == 3 && d->stride == 2), DD_ERR_UNSUPPORTED, "conv: Cin 3 with stride 2");
+  DD_REQUIRE((long)d->height * d->width * 32 < (1L << 31), DD_ERR_UNSUPPORTED, "conv: image too large for 32-bit pixel offsets");
+  return 0;
+}
+
+int pick_rows(const dd_conv_desc* d, int rows) {
+  int rb = d->rows_per_task > 0 ? d->rows_per_task : 16;
+  return max(1, min(rb, rows));
+}
+
+template <int CIN, int S, int EPI, int WPB>
+int launch_fwd(const float* x, const float* wp, const float* bias, const float* msk, float* y, const dd_conv_desc* d,
+               hipStream_t st) {
+  using C = StripCfg<CIN, S>;
+  const int Ho = dd_conv_out(d->height, S), Wo = dd_conv_out(d->width, S);
+  const int nstrips = (Wo + 31) / 32, RB = pick_rows(d, Ho), nbands = (Ho + RB - 1) / RB;
+  const long total = (long)d->batch * nstrips * nbands;
+  const size_t lds = C::WFLOATS * 4 + (size_t)WPB * 3 * C::SLOTB;
+  auto k = conv_strip_fwd<CIN, S, EPI, WPB>;
+  if (int rc = allow_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)((total + WPB - 1) / WPB)), dim3(WPB * 64), lds, st, x, wp, bias, msk, y,
+                     d->batch, d->height, d->width, Ho, Wo, nstrips, nbands, RB);
+  DD_LAUNCH_CHECK("conv_strip_fwd");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dd_conv_packed_floats(const dd_conv_desc* d, int32_t kind) {
+  if (check_desc(d)) return -1;
+  if (kind != 0 && d->cin_real != 32) return -1;
+  return d->cin_real == 32 ? 36 * 64 * 4 : 5 * 64 * 4;
+}
+
+int dd_conv_pack(const float* w_oihw, float* packed, const dd_conv_desc* d, int32_t kind, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(w_oihw && packed, DD_ERR_BAD_ARG, "conv_pack: NULL pointer");
+  DD_REQUIRE(kind >= 0 && kind <= 2, DD_ERR_BAD_ARG, "conv_pack: kind %d", kind);
+  DD_REQUIRE(kind == 0 || d->cin_real == 32, DD_ERR_UNSUPPORTED, "conv_pack: dgrad packing needs Cin 32");
+  const int n = d->cin_real == 32 ? 36 * 64 * 4 : 5 * 64 * 4;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed,
+                     d->cin_real, kind);
+  DD_LAUNCH_CHECK("conv_pack");
+  return 0;
+}
+
+int dd_conv_fwd(const float* x, const float* packed_fwd, const float* bias, const float* mask, float* y,
+                const dd_conv_desc* d, int32_t epilogue, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && packed_fwd && y, DD_ERR_BAD_ARG, "conv_fwd: NULL pointer");
+  DD_REQUIRE(epilogue != DD_EPI_RELU_MASK || mask, DD_ERR_BAD_ARG, "conv_fwd: RELU_MASK epilogue needs a mask");
+  DD_REQUIRE((epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU) || bias, DD_ERR_BAD_ARG, "conv_fwd: bias epilogue needs a bias");
+  hipStream_t st = (hipStream_t)stream;
+#define DD_DISPATCH(CIN, S, WPB)                                                                                    \
+  switch (epilogue) {                                                                                               \
+    case DD_EPI_NONE: return launch_fwd<CIN, S, DD_EPI_NONE, WPB>(x, packed_fwd, bias, mask, y, d, st);             \
+    case DD_EPI_BIAS: return launch_fwd<CIN, S, DD_EPI_BIAS, WPB>(x, packed_fwd, bias, mask, y, d, st);             \
+    case DD_EPI_BIAS_RELU: return launch_fwd<CIN, S, DD_EPI_BIAS_RELU, WPB>(x, packed_fwd, bias, mask, y, d, st);   \
+    case DD_EPI_RELU_MASK: return launch_fwd<CIN, S, DD_EPI_RELU_MASK, WPB>(x, packed_fwd, bias, mask, y, d, st);   \
+    default: return dd_fail(DD_ERR_BAD_ARG, "conv_fwd: epilogue %d", epilogue);                                     \
+  }
+  if (d->cin_store == 4) { DD_DISPATCH(4, 1, 8) }
+  if (d->stride == 1) { DD_DISPATCH(32, 1, 8) }
+  DD_DISPATCH(32, 2, 4)
+#undef DD_DISPATCH
+}
+
+int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_src, float* dx, const dd_conv_desc* d,
+                  void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(dy && packed_dgrad && dx, DD_ERR_BAD_ARG, "conv_dgrad: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32, DD_ERR_UNSUPPORTED, "conv_dgrad: Cin %d (the first layer has no data gradient)", d->cin_real);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->stride == 1) {
+    // a stride-1 k3 p1 data gradient IS a k3 p1 convolution of dy with the flipped / transposed weights
+    dd_conv_desc t = *d;
+    return relu_src ? launch_fwd<32, 1, DD_EPI_RELU_MASK, 8>(dy, packed_dgrad, nullptr, relu_src, dx, &t, st)
+                    : launch_fwd<32, 1, DD_EPI_NONE, 8>(dy, packed_dgrad, nullptr, nullptr, dx, &t, st);
+  }
+  using C = StripCfg<32, 1>;
+  constexpr int WPB = 8;
+  const int H = d->height, W = d->width, Ho = dd_conv_out(H, 2), Wo = dd_conv_out(W, 2);
+  const int ns = (W + 1) / 2, nr = (H + 1) / 2;
+  const int nstrips = (ns + 31) / 32, RB = pick_rows(d, nr), nbands = (nr + RB - 1) / RB;
+  const long total = (long)d->batch * nstrips * nbands;
+  const size_t lds = C::WFLOATS * 4 + (size_t)WPB * 3 * C::SLOTB;
+  const unsigned grid = (unsigned)((total + WPB - 1) / WPB);
+  if (relu_src) {
+    auto k = conv_s2_dgrad<WPB, true>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
+                       nstrips, nbands, RB);
+  } else {
+    auto k = conv_s2_dgrad<WPB, false>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
+                       nstrips, nbands, RB);
+  }
+  DD_LAUNCH_CHECK("conv_s2_dgrad");
+  return 0;
+}
+
+static int wgrad_grid(const dd_conv_desc* d) { (void)d; return DD_NUM_CU; }  // 1 block of 4 waves per CU (register-limited to 1 wave/SIMD)
+
+int64_t dd_conv_wgrad_workspace_bytes(const dd_conv_desc* d) {
+  if (check_desc(d)) return -1;
+  const int nt = d->cin_real == 32 ? 9 : 1;
+  return (int64_t)wgrad_grid(d) * 4 * ((int64_t)nt * 1024 + 64) * 4;
+}
+
+int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                  int64_t workspace_bytes, const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && dy && dw_oihw && dbias && workspace, DD_ERR_BAD_ARG, "conv_wgrad: NULL pointer");
+  DD_REQUIRE(workspace_bytes >= dd_conv_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wgrad: workspace %ld < %ld bytes",
+             (long)workspace_bytes, (long)dd_conv_wgrad_workspace_bytes(d));
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int WPB = 4;
+  const int S = d->stride, H = d->height, W = d->width, Ho = dd_conv_out(H, S), Wo = dd_conv_out(W, S);
+  const int nstrips = (Wo + 31) / 32, RB = pick_rows(d, Ho), nbands = (Ho + RB - 1) / RB;
+  const long total = (long)d->batch * nstrips * nbands;
+  int grid = wgrad_grid(d);
+  grid = (int)min((long)grid, (total + WPB - 1) / WPB);
+  const int nw = grid * WPB;
+  const int nt = d->cin_real == 32 ? 9 : 1;
+  float* part = (float*)workspace;
+  float* bpart = part + (size_t)nw * nt * 1024;
+#define DD_WG(CIN, SS)                                                                                              \
+  {                                                                                                                 \
+    auto k = conv_wgrad<CIN, SS, WPB>;                                                                              \
+    const size_t lds = (size_t)WPB * 3 * StripCfg<CIN, SS>::SLOTB;                                                  \
+    if (int rc = allow_lds(k, lds)) return rc;                                                                      \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, H, W, Ho, Wo, nstrips, \
+                       nbands, RB);                                                                                 \
+  }
+  if (d->cin_store == 4) DD_WG(4, 1)
+  else if (S == 1) DD_WG(32, 1)
+  else DD_WG(32, 2)
+#undef DD_WG
+  DD_LAUNCH_CHECK("conv_wgrad");
+  if (d->cin_store == 4)
+    hipLaunchKernelGGL(conv_wgrad_reduce<4>, dim3(nt * 16 + 1), dim3(256), 0, st, part, bpart, dw_oihw, dbias, nw);
+  else
+    hipLaunchKernelGGL(conv_wgrad_reduce<32>, dim3(nt * 16 + 1), dim3(256), 0, st, part, bpart, dw_oihw, dbias, nw);
+  DD_LAUNCH_CHECK("conv_wgrad_reduce");
+  return 0;
+}
+
+int dd_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+  DD_REQUIRE(dy && y && out && n > 0, DD_ERR_BAD_ARG, "relu_bwd: bad argument");
+  DD_REQUIRE(n % 4 == 0, DD_ERR_UNSUPPORTED, "relu_bwd: n %% 4 != 0");
+  const long n4 = n / 4;
+  const int grid = (int)min((n4 + 255) / 256, (long)DD_NUM_CU * 8);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dy, (const f32x4*)y,
+                     (f32x4*)out, n4);
+  DD_LAUNCH_CHECK("relu_bwd");
+  return 0;
+}
+
+}  // extern "C"

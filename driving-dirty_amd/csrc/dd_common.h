@@ -1,0 +1,34 @@
+// Shared helpers for the gfx950 kernels of the hot path (internal; the public ABI is include/dd_hotpath.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dd_hotpath.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// D(32x32) += A(32x2) * B(2x32), exact fp32 (v_mfma_f32_32x32x2_f32, 64 cycles / SIMD).
+// lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
+// D register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+#define DD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+#define DD_NUM_CU 256
+
+int dd_fail(int code, const char* fmt, ...);
+
+#define DD_REQUIRE(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) return dd_fail(code, __VA_ARGS__); \
+  } while (0)
+
+#define DD_LAUNCH_CHECK(what)                                                        \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) return dd_fail(DD_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int dd_conv_out(int in, int stride) { return (in + 2 - 3) / stride + 1; }
+
+__device__ __forceinline__ int dd_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

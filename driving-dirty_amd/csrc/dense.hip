@@ -1,0 +1,267 @@
+// Dense-head pieces of the hot path (all HBM- or latency-bound, no matrix work):
+//   dd_bn_relu_drop_*   BatchNorm1d -> ReLU -> dropout(mask)   reference components.py:104-109 (DenseBlock.forward)
+//   dd_bce_logits       mean BCE-with-logits fwd + bwd + sigmoid in ONE pass over the 640000-wide maps
+//                       (roadmap_bce_v2.py:81,106)
+//   dd_mse              mean squared error fwd + bwd (autoencoder.py:91, roadmap_pretrain_ae.py:100)
+//   dd_adam_step        torch.optim.Adam over one flat buffer (autoencoder.py:119-120)
+#include "dd_common.h"
+
+namespace {
+
+// ---- BatchNorm1d + ReLU + dropout.  One thread per feature; consecutive threads read consecutive
+// features, so every row access is a coalesced 256-byte wave load.  Batch statistics are two-pass
+// (mean, then centred second moment) like torch's CPU kernel, not E[x^2]-E[x]^2.
+__global__ __launch_bounds__(256) void bn_relu_drop_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ rmean, float* __restrict__ rvar, const float* __restrict__ keep, float* __restrict__ y,
+    float* __restrict__ smean, float* __restrict__ sinv, int rows, int feat, float eps, float momentum, float scale,
+    int training) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= feat) return;
+  float mean, invstd;
+  if (training) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(long)r * feat + f];
+    mean = s / rows;
+    float ss = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      const float d = x[(long)r * feat + f] - mean;
+      ss += d * d;
+    }
+    const float var = ss / rows;
+    invstd = 1.0f / sqrtf(var + eps);
+    smean[f] = mean;
+    sinv[f] = invstd;
+    const float unbiased = rows > 1 ? ss / (rows - 1) : var;
+    rmean[f] = (1.f - momentum) * rmean[f] + momentum * mean;
+    rvar[f] = (1.f - momentum) * rvar[f] + momentum * unbiased;
+  } else {
+    mean = rmean[f];
+    invstd = 1.0f / sqrtf(rvar[f] + eps);
+  }
+  const float g = gamma[f] * invstd, b = beta[f];
+  for (int r = 0; r < rows; ++r) {
+    const long i = (long)r * feat + f;
+    float v = fmaxf((x[i] - mean) * g + b, 0.f);
+    if (keep) v = v * keep[i] * scale;
+    y[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_drop_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ keep, const float* __restrict__ smean,
+    const float* __restrict__ sinv, const float* __restrict__ rmean, const float* __restrict__ rvar,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int feat, float eps,
+    float scale, int training) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= feat) return;
+  const float mean = training ? smean[f] : rmean[f];
+  const float invstd = training ? sinv[f] : 1.0f / sqrtf(rvar[f] + eps);
+  const float ks = keep ? scale : 1.f;
+  float sdz = 0.f, sdzx = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const long i = (long)r * feat + f;
+    const float dz = (y[i] > 0.f) ? dy[i] * ks : 0.f;   // y > 0  <=>  ReLU open AND unit kept
+    sdz += dz;
+    sdzx += dz * (x[i] - mean) * invstd;
+  }
+  dbeta[f] = sdz;
+  dgamma[f] = sdzx;
+  const float g = gamma[f] * invstd;
+  const float inv_rows = 1.f / rows;
+  for (int r = 0; r < rows; ++r) {
+    const long i = (long)r * feat + f;
+    const float dz = (y[i] > 0.f) ? dy[i] * ks : 0.f;
+    if (training) {
+      const float xhat = (x[i] - mean) * invstd;
+      dx[i] = g * (dz - inv_rows * (sdz + xhat * sdzx));
+    } else {
+      dx[i] = g * dz;
+    }
+  }
+}
+
+// ---- losses: grid-stride pass with per-thread fp32 partials, wave shuffle + LDS block reduce,
+// one fp64 partial per block, then a single-block fixed-order final sum (deterministic).
+__device__ __forceinline__ double block_sum(float v) {
+  __shared__ double red[4];
+  double d = (double)v;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = d;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                         float* __restrict__ dz, float* __restrict__ probs,
+                                                         double* __restrict__ partial, long n, float gscale) {
+  float s = 0.f;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 zv = ((const f32x4*)z)[i], tv = ((const f32x4*)t)[i];
+    f32x4 g, p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float e = expf(-fabsf(zv[k]));
+      s += fmaxf(zv[k], 0.f) - zv[k] * tv[k] + log1pf(e);
+      const float sig = zv[k] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      p[k] = sig;
+      g[k] = (sig - tv[k]) * gscale;
+    }
+    if (dz) ((f32x4*)dz)[i] = g;
+    if (probs) ((f32x4*)probs)[i] = p;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {   // tail (n % 4 elements)
+    const long i = 4 * n4 + threadIdx.x;
+    const float e = expf(-fabsf(z[i]));
+    s += fmaxf(z[i], 0.f) - z[i] * t[i] + log1pf(e);
+    const float sig = z[i] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    if (dz) dz[i] = (sig - t[i]) * gscale;
+    if (probs) probs[i] = sig;
+  }
+  const double tot = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ da, double* __restrict__ partial, long n,
+                                                  float gscale) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    s += d * d;
+    if (da) da[i] = 2.f * d * gscale;
+  }
+  const double tot = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n,
+                                                         float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+  const long n4 = n / 4;
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+    const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gv[k] * gscale;
+      mv[k] = b1 * mv[k] + (1.f - b1) * gg;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
+      pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
+    }
+    ((f32x4*)p)[i] = pv;
+    ((f32x4*)m)[i] = mv;
+    ((f32x4*)v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+    const long i = 4 * n4 + threadIdx.x;
+    const float gg = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+constexpr int kLossBlocks = DD_NUM_CU * 8;
+
+}  // namespace
+
+extern "C" {
+
+int dd_bn_relu_drop_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        const float* keep, float* y, float* save_mean, float* save_invstd, int32_t rows, int32_t feat,
+                        float eps, float momentum, float scale, int32_t training, void* stream) {
+  DD_REQUIRE(x && gamma && beta && running_mean && running_var && y, DD_ERR_BAD_ARG, "bn_fwd: NULL pointer");
+  DD_REQUIRE(rows > 0 && feat > 0, DD_ERR_BAD_ARG, "bn_fwd: non-positive size");
+  DD_REQUIRE(!training || (save_mean && save_invstd), DD_ERR_BAD_ARG, "bn_fwd: training mode needs save buffers");
+  DD_REQUIRE(!training || rows > 1, DD_ERR_UNSUPPORTED, "bn_fwd: batch statistics need more than 1 row (torch raises too)");
+  hipLaunchKernelGGL(bn_relu_drop_fwd_kernel, dim3((feat + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, running_mean, running_var, keep, y, save_mean, save_invstd, rows, feat, eps, momentum, scale,
+                     training);
+  DD_LAUNCH_CHECK("bn_relu_drop_fwd");
+  return 0;
+}
+
+int dd_bn_relu_drop_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* keep,
+                        const float* save_mean, const float* save_invstd, const float* running_mean,
+                        const float* running_var, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t feat, float eps, float scale,
+                        int32_t training, void* stream) {
+  DD_REQUIRE(dy && x && y && gamma && dx && dgamma && dbeta, DD_ERR_BAD_ARG, "bn_bwd: NULL pointer");
+  DD_REQUIRE(training ? (save_mean && save_invstd) : (running_mean && running_var), DD_ERR_BAD_ARG, "bn_bwd: missing statistics");
+  DD_REQUIRE(rows > 0 && feat > 0, DD_ERR_BAD_ARG, "bn_bwd: non-positive size");
+  hipLaunchKernelGGL(bn_relu_drop_bwd_kernel, dim3((feat + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, x, y,
+                     gamma, keep, save_mean, save_invstd, running_mean, running_var, dx, dgamma,
+                     dbeta, rows, feat, eps, scale, training);
+  DD_LAUNCH_CHECK("bn_relu_drop_bwd");
+  return 0;
+}
+
+int64_t dd_loss_workspace_bytes(int64_t n) {
+  (void)n;
+  return (int64_t)kLossBlocks * sizeof(double);
+}
+
+int dd_bce_logits(const float* logits, const float* target, float* loss_out, float* dlogits, float* probs, int64_t n,
+                  float grad_scale, void* workspace, void* stream) {
+  DD_REQUIRE(logits && target && loss_out && workspace && n > 0, DD_ERR_BAD_ARG, "bce_logits: bad argument");
+  DD_REQUIRE(((uintptr_t)logits | (uintptr_t)target | (uintptr_t)dlogits | (uintptr_t)probs) % 16 == 0, DD_ERR_BAD_ARG,
+             "bce_logits: buffers must be 16-byte aligned");
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)kLossBlocks);
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits, probs,
+                     (double*)workspace, (long)n, grad_scale / (float)n);
+  DD_LAUNCH_CHECK("bce_logits");
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
+                     1.0 / (double)n, loss_out);
+  DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n, float grad_scale, void* workspace,
+           void* stream) {
+  DD_REQUIRE(a && b && loss_out && workspace && n > 0, DD_ERR_BAD_ARG, "mse: bad argument");
+  const int grid = (int)min((n + 255) / 256, (long)kLossBlocks);
+  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, da, (double*)workspace, (long)n,
+                     grad_scale / (float)n);
+  DD_LAUNCH_CHECK("mse");
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
+                     1.0 / (double)n, loss_out);
+  DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 int32_t step, float grad_scale, void* stream) {
+  DD_REQUIRE(p && g && m && v && n > 0 && step >= 1, DD_ERR_BAD_ARG, "adam: bad argument");
+  DD_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, DD_ERR_BAD_ARG, "adam: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)DD_NUM_CU * 8);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
+                     eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  DD_LAUNCH_CHECK("adam");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+// Layout glue of the hot path, fused with the NCHW<->NHWC conversion the MFMA kernels want:
+//   dd_stitch6        6-view reorder + wide stitch (+ masked-view task)   reference roadmap_bce_v2.py:53-64, autoencoder.py:53-73
+//   dd_nchw_to_nhwc / dd_nhwc_to_nchw                                     API edges of Encoder.forward (components.py:40)
+//   dd_pool4_*        max_pool1d(4) over the NCHW-flattened c3 feature    components.py:46-47
+// All of it is HBM-bound byte shuffling: every kernel reads and writes each byte once, 16 bytes per lane
+// on the NHWC side.
+#include "dd_common.h"
+
+namespace {
+
+__constant__ int kViewOrder[6] = {0, 1, 2, 5, 4, 3};
+
+// one thread per wide-image pixel: reads 3 planes (coalesced along x), writes one 16-byte NHWC4 pixel
+__global__ __launch_bounds__(256) void stitch6_kernel(const float* __restrict__ views, f32x4* __restrict__ wide4,
+                                                      float* __restrict__ wide_nchw, float* __restrict__ target,
+                                                      int B, int H, int W, int mask_slot) {
+  const long npx = (long)B * H * 6 * W;
+  const long plane = (long)H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(p % (6 * W));
+    const int yy = (int)((p / (6 * W)) % H);
+    const int b = (int)(p / ((long)6 * W * H));
+    const int slot = xw / W, xx = xw - slot * W;
+    const float* src = views + (((long)b * 6 + kViewOrder[slot]) * 3) * plane + (long)yy * W + xx;
+    float c0 = src[0], c1 = src[plane], c2 = src[2 * plane];
+    if (slot == mask_slot) {
+      if (target) {
+        float* t = target + ((long)b * 3) * plane + (long)yy * W + xx;
+        t[0] = c0; t[plane] = c1; t[2 * plane] = c2;
+      }
+      c0 = c1 = c2 = 0.f;
+    }
+    if (wide4) wide4[p] = f32x4{c0, c1, c2, 0.f};
+    if (wide_nchw) {
+      float* o = wide_nchw + ((long)b * 3) * H * 6 * W + (long)yy * 6 * W + xw;
+      o[0] = c0; o[(long)H * 6 * W] = c1; o[2L * H * 6 * W] = c2;
+    }
+  }
+}
+
+// NCHW -> NHWC(Cs): one thread per (pixel, 4-channel group)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, f32x4* __restrict__ dst,
+                                                           int B, int C, int H, int W, int Cs) {
+  const int groups = Cs / 4;
+  const long plane = (long)H * W;
+  const long total = (long)B * plane * groups;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % plane;
+    const int g = (int)((i / plane) % groups);
+    const int b = (int)(i / (plane * groups));
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * g + k;
+      v[k] = (c < C) ? src[((long)b * C + c) * plane + p] : 0.f;
+    }
+    dst[((long)b * plane + p) * groups + g] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int B, int C, int H, int W, int Cs) {
+  const long plane = (long)H * W;
+  const long total = (long)B * C * plane;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % plane;
+    const int c = (int)((i / plane) % C);
+    const int b = (int)(i / (plane * C));
+    dst[i] = src[((long)b * plane + p) * Cs + c];
+  }
+}
+
+// ---- pool, fast path: H*W % 4 == 0 and C % 4 == 0, so a window of 4 never leaves its channel plane.
+// thread = (quad of 4 consecutive flat pixels, group of 4 channels): 4 x 16-byte loads, 4 outputs.
+__global__ __launch_bounds__(256) void pool4_fwd_quad(const f32x4* __restrict__ feat, float* __restrict__ pooled,
+                                                      int B, long HW, int C) {
+  const int groups = C / 4;
+  const long quads = HW / 4;
+  const long total = (long)B * quads * groups;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long q = (i / groups) % quads;
+    const long b = i / (groups * quads);
+    const f32x4* p = feat + ((b * HW + 4 * q) * groups + g);
+    const f32x4 v0 = p[0], v1 = p[groups], v2 = p[2 * groups], v3 = p[3 * groups];
+    float* o = pooled + b * (quads * C) + q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[(long)(4 * g + k) * quads] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+  }
+}
+
+__global__ __launch_bounds__(256) void pool4_bwd_quad(const float* __restrict__ dpooled,
+                                                      const f32x4* __restrict__ feat, f32x4* __restrict__ dfeat,
+                                                      int B, long HW, int C) {
+  const int groups = C / 4;
+  const long quads = HW / 4;
+  const long total = (long)B * quads * groups;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long q = (i / groups) % quads;
+    const long b = i / (groups * quads);
+    const long base = (b * HW + 4 * q) * groups + g;
+    const f32x4 v0 = feat[base], v1 = feat[base + groups], v2 = feat[base + 2 * groups], v3 = feat[base + 3 * groups];
+    const float* gp = dpooled + b * (quads * C) + q;
+    f32x4 d0, d1, d2, d3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gp[(long)(4 * g + k) * quads];
+      // first maximum wins (torch max_pool1d keeps the earliest index on ties); ReLU backward fused: feat > 0
+      float m = v0[k];
+      int am = 0;
+      if (v1[k] > m) { m = v1[k]; am = 1; }
+      if (v2[k] > m) { m = v2[k]; am = 2; }
+      if (v3[k] > m) { m = v3[k]; am = 3; }
+      const float gv = (m > 0.f) ? gk : 0.f;
+      d0[k] = am == 0 ? gv : 0.f;
+      d1[k] = am == 1 ? gv : 0.f;
+      d2[k] = am == 2 ? gv : 0.f;
+      d3[k] = am == 3 ? gv : 0.f;
+    }
+    dfeat[base] = d0;
+    dfeat[base + groups] = d1;
+    dfeat[base + 2 * groups] = d2;
+    dfeat[base + 3 * groups] = d3;
+  }
+}
+
+// ---- pool, general path (any C, H, W): windows may straddle channel planes; tail elements are dropped.
+__global__ __launch_bounds__(256) void pool4_fwd_any(const float* __restrict__ feat, float* __restrict__ pooled, int B,
+                                                     long HW, int C) {
+  const long per = ((long)C * HW) / 4;
+  const long total = (long)B * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / per, g = i % per;
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long f = 4 * g + k;
+      const float v = feat[(b * HW + f % HW) * C + f / HW];
+      m = (k == 0 || v > m) ? v : m;
+    }
+    pooled[i] = m;
+  }
+}
+
+// one thread per NHWC element of dfeat (so elements in the dropped tail get an explicit zero)
+__global__ __launch_bounds__(256) void pool4_bwd_any(const float* __restrict__ dpooled, const float* __restrict__ feat,
+                                                     float* __restrict__ dfeat, int B, long HW, int C) {
+  const long per = ((long)C * HW) / 4;
+  const long total = (long)B * HW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = (i / C) % HW;
+    const long b = i / ((long)C * HW);
+    const long f = (long)c * HW + p;
+    const long g = f / 4;
+    float out = 0.f;
+    if (g < per) {
+      float m = 0.f;
+      int am = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long fk = 4 * g + k;
+        const float v = feat[(b * HW + fk % HW) * C + fk / HW];
+        if (k == 0 || v > m) { m = v; am = k; }
+      }
+      if (am == (int)(f - 4 * g) && m > 0.f) out = dpooled[b * per + g];
+    }
+    dfeat[i] = out;
+  }
+}
+
+int grid_for(long n) { return (int)min((n + 255) / 256, (long)DD_NUM_CU * 8); }
+
+}  // namespace
+
+extern "C" {
+
+int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* target, int32_t batch, int32_t height,
+               int32_t width, int32_t mask_slot, void* stream) {
+  DD_REQUIRE(views && (wide_nhwc4 || wide_nchw), DD_ERR_BAD_ARG, "stitch6: NULL pointer");
+  DD_REQUIRE(batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "stitch6: non-positive size");
+  DD_REQUIRE(mask_slot >= -1 && mask_slot < 6, DD_ERR_BAD_ARG, "stitch6: mask_slot %d", mask_slot);
+  const long npx = (long)batch * height * 6 * width;
+  hipLaunchKernelGGL(stitch6_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, views, (f32x4*)wide_nhwc4,
+                     wide_nchw, target, batch, height, width, mask_slot);
+  DD_LAUNCH_CHECK("stitch6");
+  return 0;
+}
+
+int dd_nchw_to_nhwc(const float* src, float* dst, int32_t batch, int32_t c, int32_t h, int32_t w, int32_t c_store,
+                    void* stream) {
+  DD_REQUIRE(src && dst && batch > 0 && c > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "nchw_to_nhwc: bad argument");
+  DD_REQUIRE(c_store >= c && c_store % 4 == 0, DD_ERR_UNSUPPORTED, "nchw_to_nhwc: c_store %d for c %d", c_store, c);
+  const long total = (long)batch * h * w * (c_store / 4);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (f32x4*)dst,
+                     batch, c, h, w, c_store);
+  DD_LAUNCH_CHECK("nchw_to_nhwc");
+  return 0;
+}
+
+int dd_nhwc_to_nchw(const float* src, float* dst, int32_t batch, int32_t c, int32_t h, int32_t w, int32_t c_store,
+                    void* stream) {
+  DD_REQUIRE(src && dst && batch > 0 && c > 0 && h > 0 && w > 0 && c_store >= c, DD_ERR_BAD_ARG, "nhwc_to_nchw: bad argument");
+  const long total = (long)batch * c * h * w;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, batch, c,
+                     h, w, c_store);
+  DD_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}
+
+int dd_pool4_fwd(const float* feat, float* pooled, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+  DD_REQUIRE(feat && pooled && batch > 0 && h > 0 && w > 0 && c > 0, DD_ERR_BAD_ARG, "pool4_fwd: bad argument");
+  const long HW = (long)h * w;
+  DD_REQUIRE(((long)c * HW) / 4 > 0, DD_ERR_UNSUPPORTED, "pool4_fwd: fewer than 4 elements");
+  if (HW % 4 == 0 && c % 4 == 0) {
+    const long total = (long)batch * (HW / 4) * (c / 4);
+    hipLaunchKernelGGL(pool4_fwd_quad, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat,
+                       pooled, batch, HW, c);
+  } else {
+    const long total = (long)batch * (((long)c * HW) / 4);
+    hipLaunchKernelGGL(pool4_fwd_any, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pooled, batch, HW,
+                       c);
+  }
+  DD_LAUNCH_CHECK("pool4_fwd");
+  return 0;
+}
+
+int dd_pool4_relu_bwd(const float* dpooled, const float* feat, float* dfeat, int32_t batch, int32_t h, int32_t w,
+                      int32_t c, void* stream) {
+  DD_REQUIRE(dpooled && feat && dfeat && batch > 0 && h > 0 && w > 0 && c > 0, DD_ERR_BAD_ARG, "pool4_bwd: bad argument");
+  const long HW = (long)h * w;
+  if (HW % 4 == 0 && c % 4 == 0) {
+    const long total = (long)batch * (HW / 4) * (c / 4);
+    hipLaunchKernelGGL(pool4_bwd_quad, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dpooled,
+                       (const f32x4*)feat, (f32x4*)dfeat, batch, HW, c);
+  } else {
+    const long total = (long)batch * HW * c;
+    hipLaunchKernelGGL(pool4_bwd_any, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dpooled, feat, dfeat,
+                       batch, HW, c);
+  }
+  DD_LAUNCH_CHECK("pool4_bwd");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+"""torch.autograd.Function shims over the C ABI (``include/dd_hotpath.h``).
+
+The shims own every tensor (the kernels never allocate), pass raw device pointers plus the
+current PyTorch HIP stream, and raise on any non-zero return code.  Activations between conv
+layers are NHWC fp32 tensors ``[B,H,W,C]``; the module layer (components.py) presents them to
+callers as NCHW-shaped channels_last views, which is what the reference returns logically.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_S2 = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(t, name, shape=None):
+    """Validate a kernel operand on the HOST before any launch (a faulting kernel can reset the GPU)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.HotpathError(f"{name}: expected a contiguous fp32 device tensor, got "
+                                f"{getattr(t, 'dtype', type(t))} on {getattr(t, 'device', '?')} "
+                                f"contiguous={getattr(t, 'is_contiguous', lambda: '?')()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.HotpathError(f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+    return t
+
+
+def conv_out(n, stride):
+    return (n + 2 - 3) // stride + 1
+
+
+def conv_desc(batch, h, w, cin_real, stride, rows_per_task=0):
+    return ConvDesc(batch, h, w, cin_real, 4 if cin_real == 3 else cin_real, 32, 3, stride, 1, rows_per_task)
+
+
+# ------------------------------------------------------------------------------------------------ layout
+def stitch6(views, mask_slot=-1, want_nhwc4=True, want_nchw=False, want_target=False):
+    """[B,6,3,H,W] -> wide image (view order [0,1,2,5,4,3]); see dd_stitch6 in dd_hotpath.h."""
+    b, n, c, h, w = views.shape
+    if n != 6 or c != 3:
+        raise _lib.HotpathError(f"stitch6: expected [B,6,3,H,W], got {tuple(views.shape)}")
+    _dev(views, "views")
+    wide4 = torch.empty((b, h, 6 * w, 4), device=views.device, dtype=torch.float32) if want_nhwc4 else None
+    wide = torch.empty((b, 3, h, 6 * w), device=views.device, dtype=torch.float32) if want_nchw else None
+    tgt = torch.empty((b, 3, h, w), device=views.device, dtype=torch.float32) if want_target else None
+    check(_lib.lib().dd_stitch6(_p(views), _p(wide4), _p(wide), _p(tgt), b, h, w, int(mask_slot), _stream()), "dd_stitch6")
+    return wide4, wide, tgt
+
+
+def nchw_to_nhwc(x, c_store):
+    b, c, h, w = x.shape
+    _dev(x, "x")
+    out = torch.empty((b, h, w, c_store), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_nchw_to_nhwc(_p(x), _p(out), b, c, h, w, c_store, _stream()), "dd_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, c):
+    b, h, w, cs = x.shape
+    _dev(x, "x")
+    out = torch.empty((b, c, h, w), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_nhwc_to_nchw(_p(x), _p(out), b, c, h, w, cs, _stream()), "dd_nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv primitives
+def conv_pack(weight, desc, kind):
+    _dev(weight, "weight", (32, desc.cin_real, 3, 3))
+    n = _lib.lib().dd_conv_packed_floats(C.byref(desc), kind)
+    if n <= 0:
+        raise _lib.HotpathError(f"conv_pack: {_lib.lib().dd_last_error().decode()}")
+    packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_pack(_p(weight), _p(packed), C.byref(desc), kind, _stream()), "dd_conv_pack")
+    return packed
+
+
+def conv_fwd(x, packed, bias, desc, epilogue=EPI_BIAS_RELU, mask=None):
+    ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
+    _dev(x, "x", (desc.batch, desc.height, desc.width, desc.cin_store))
+    if bias is not None:
+        _dev(bias, "bias", (32,))
+    if mask is not None:
+        _dev(mask, "mask", (desc.batch, ho, wo, 32))
+    y = torch.empty((desc.batch, ho, wo, 32), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_fwd(_p(x), _p(packed), _p(bias), _p(mask), _p(y), C.byref(desc), epilogue, _stream()), "dd_conv_fwd")
+    return y
+
+
+def conv_dgrad(dy, packed_dgrad, relu_src, desc):
+    ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
+    _dev(dy, "dy", (desc.batch, ho, wo, 32))
+    if relu_src is not None:
+        _dev(relu_src, "relu_src", (desc.batch, desc.height, desc.width, 32))
+    dx = torch.empty((desc.batch, desc.height, desc.width, 32), device=dy.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_dgrad(_p(dy), _p(packed_dgrad), _p(relu_src), _p(dx), C.byref(desc), _stream()), "dd_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(x, dy, desc):
+    ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
+    _dev(x, "x", (desc.batch, desc.height, desc.width, desc.cin_store))
+    _dev(dy, "dy", (desc.batch, ho, wo, 32))
+    nbytes = _lib.lib().dd_conv_wgrad_workspace_bytes(C.byref(desc))
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    dw = torch.empty((32, desc.cin_real, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty(32, device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, C.byref(desc), _stream()), "dd_conv_wgrad")
+    return dw, db
+
+
+def relu_bwd(dy, y):
+    _dev(dy, "dy", y.shape)
+    _dev(y, "y")
+    out = torch.empty_like(y)
+    check(_lib.lib().dd_relu_bwd(_p(dy), _p(y), _p(out), y.numel(), _stream()), "dd_relu_bwd")
+    return out
+
+
+def pool4_fwd(feat):
+    b, h, w, c = feat.shape
+    _dev(feat, "feat")
+    out = torch.empty((b, (c * h * w) // 4), device=feat.device, dtype=torch.float32)
+    check(_lib.lib().dd_pool4_fwd(_p(feat), _p(out), b, h, w, c, _stream()), "dd_pool4_fwd")
+    return out
+
+
+def pool4_relu_bwd(dpooled, feat):
+    b, h, w, c = feat.shape
+    _dev(dpooled, "dpooled", (b, (c * h * w) // 4))
+    _dev(feat, "feat")
+    out = torch.empty_like(feat)
+    check(_lib.lib().dd_pool4_relu_bwd(_p(dpooled), _p(feat), _p(out), b, h, w, c, _stream()), "dd_pool4_relu_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ encoder conv stack
+class EncoderConvStack(torch.autograd.Function):
+    """c1 -> ReLU -> c2 -> ReLU -> c3 (stride 2) -> ReLU [-> NCHW-order max_pool1d(4)] as one autograd node.
+
+    Reference: Encoder.forward, src/autoencoder/components.py:41-47.  Running the three layers as
+    one node lets the backward fuse each ReLU's gradient into the neighbouring kernel (the pool
+    backward masks with c3's output, each data-gradient kernel masks with its layer's input) and
+    keeps every intermediate in NHWC.
+
+    forward(x4 [B,H,W,4], w1,b1,w2,b2,w3,b3, pool) -> feat [B,Ho,Wo,32] (NHWC)   or  pooled [B, 32*Ho*Wo/4]
+    """
+
+    @staticmethod
+    def forward(ctx, x4, w1, b1, w2, b2, w3, b3, pool, rows_per_task):
+        b, h, w, _ = x4.shape
+        d1 = conv_desc(b, h, w, 3, 1, rows_per_task)
+        d2 = conv_desc(b, h, w, 32, 1, rows_per_task)
+        d3 = conv_desc(b, h, w, 32, 2, rows_per_task)
+        a1 = conv_fwd(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
+        a2 = conv_fwd(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
+        a3 = conv_fwd(a2, conv_pack(w3, d3, PACK_FWD), b3, d3)
+        ctx.save_for_backward(x4, a1, a2, a3, w2, w3)
+        ctx.pool = bool(pool)
+        ctx.rows_per_task = rows_per_task
+        if pool:
+            return pool4_fwd(a3)
+        return a3
+
+    @staticmethod
+    def backward(ctx, grad):
+        x4, a1, a2, a3, w2, w3 = ctx.saved_tensors
+        b, h, w, _ = x4.shape
+        rpt = ctx.rows_per_task
+        d1, d2, d3 = conv_desc(b, h, w, 3, 1, rpt), conv_desc(b, h, w, 32, 1, rpt), conv_desc(b, h, w, 32, 2, rpt)
+        grad = grad.contiguous()
+        g3 = pool4_relu_bwd(grad, a3) if ctx.pool else relu_bwd(grad, a3)
+        need = ctx.needs_input_grad
+        dw3, db3 = conv_wgrad(a2, g3, d3) if (need[5] or need[6]) else (None, None)
+        dw2 = db2 = dw1 = db1 = None
+        if need[1] or need[2] or need[3] or need[4]:
+            g2 = conv_dgrad(g3, conv_pack(w3, d3, PACK_DGRAD_S2), a2, d3)
+            del g3
+            if need[3] or need[4]:
+                dw2, db2 = conv_wgrad(a1, g2, d2)
+            if need[1] or need[2]:
+                g1 = conv_dgrad(g2, conv_pack(w2, d2, PACK_DGRAD_S1), a1, d2)
+                del g2
+                dw1, db1 = conv_wgrad(x4, g1, d1)
+        return None, dw1, db1, dw2, db2, dw3, db3, None, None
+
+
+def encoder_conv_stack(x4, c1, c2, c3, pool, rows_per_task=0):
+    return EncoderConvStack.apply(x4, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, pool, rows_per_task)
+
+
+# ------------------------------------------------------------------------------------------------ dense block tail
+class BnReluDrop(torch.autograd.Function):
+    """BatchNorm1d -> ReLU -> dropout(keep mask) in one kernel each way (components.py:105-108)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, keep, training, eps, momentum, scale):
+        rows, feat = x.shape
+        _dev(x, "x")
+        y = torch.empty_like(x)
+        save_mean = torch.empty(feat, device=x.device, dtype=torch.float32)
+        save_inv = torch.empty(feat, device=x.device, dtype=torch.float32)
+        check(_lib.lib().dd_bn_relu_drop_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(keep),
+                                             _p(y), _p(save_mean), _p(save_inv), rows, feat, eps, momentum, scale,
+                                             int(training), _stream()), "dd_bn_relu_drop_fwd")
+        ctx.save_for_backward(x, y, gamma, keep, save_mean, save_inv, running_mean, running_var)
+        ctx.cfg = (bool(training), eps, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, keep, save_mean, save_inv, running_mean, running_var = ctx.saved_tensors
+        training, eps, scale = ctx.cfg
+        rows, feat = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        check(_lib.lib().dd_bn_relu_drop_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(keep), _p(save_mean), _p(save_inv),
+                                             _p(running_mean), _p(running_var), _p(dx), _p(dgamma), _p(dbeta), rows, feat,
+                                             eps, scale, int(training), _stream()), "dd_bn_relu_drop_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def _loss_ws(n, device):
+    return torch.empty(_lib.lib().dd_loss_workspace_bytes(n), device=device, dtype=torch.uint8)
+
+
+class BceWithLogits(torch.autograd.Function):
+    """mean BCE-with-logits; the gradient is produced by the forward's single pass (roadmap_bce_v2.py:106)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _dev(logits, "logits")
+        _dev(target, "target", logits.shape)
+        n = logits.numel()
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dz = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().dd_bce_logits(_p(logits), _p(target), _p(loss), _p(dz), None, n, 1.0, _p(_loss_ws(n, logits.device)),
+                                       _stream()), "dd_bce_logits")
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None
+
+
+class MseLoss(torch.autograd.Function):
+    """mean((pred - target)^2) (autoencoder.py:91; symmetric in its arguments)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _dev(pred, "pred")
+        _dev(target, "target", pred.shape)
+        n = pred.numel()
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        da = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().dd_mse(_p(pred), _p(target), _p(loss), _p(da), n, 1.0, _p(_loss_ws(n, pred.device)), _stream()), "dd_mse")
+        ctx.save_for_backward(da)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (da,) = ctx.saved_tensors
+        return da * g, None
+
+
+def sigmoid_and_loss(logits, target):
+    """One pass: (loss, probs) without autograd -- used by validation."""
+    n = logits.numel()
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    probs = torch.empty_like(logits)
+    check(_lib.lib().dd_bce_logits(_p(logits), _p(target), _p(loss), None, _p(probs), n, 1.0, _p(_loss_ws(n, logits.device)),
+                                   _stream()), "dd_bce_logits")
+    return loss, probs
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _dev(t, name, p.shape)
+    check(_lib.lib().dd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step), grad_scale,
+                                  _stream()), "dd_adam_step")

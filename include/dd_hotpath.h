@@ -1,0 +1,149 @@
+/* dd_hotpath.h -- C ABI of the MI355X-native multi-camera -> BEV training hot path.
+ *
+ * The reference (annikabrundyn/driving-dirty) has no FFI: its hot path is reached through
+ * the PyTorch-Lightning Python surface and ATen ops.  Each entry point below replaces the
+ * ATen op(s) that one reference line invokes; the Python host (driving-dirty_amd/ops.py)
+ * binds them with ctypes and owns every tensor.  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory, sizes as int32/int64, no torch types;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - no allocation, no host synchronisation, no global state besides the thread-local
+ *     error string; scratch memory is a caller-provided workspace sized by *_workspace_bytes;
+ *   - return 0 on success, a DD_ERR_* code otherwise (unsupported shapes are refused,
+ *     never silently approximated); dd_last_error() describes the last failure of the
+ *     calling thread;
+ *   - activations between conv layers are NHWC fp32 (channels innermost); parameters
+ *     stay in PyTorch layouts (Conv2d OIHW, Linear [out,in]) so state_dict round-trips.
+ */
+#ifndef DD_HOTPATH_H
+#define DD_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_ABI_VERSION 1
+
+enum {
+  DD_OK = 0,
+  DD_ERR_UNSUPPORTED = 1, /* shape / option outside what the kernels implement */
+  DD_ERR_BAD_ARG = 2,     /* NULL pointer, non-positive size, misaligned pointer */
+  DD_ERR_LAUNCH = 3,      /* hipLaunch / hipFuncSetAttribute failed */
+  DD_ERR_WORKSPACE = 4    /* workspace too small */
+};
+
+/* Epilogues of the conv kernels. */
+enum {
+  DD_EPI_NONE = 0,      /* y = conv(x)                                   */
+  DD_EPI_BIAS = 1,      /* y = conv(x) + bias                            */
+  DD_EPI_BIAS_RELU = 2, /* y = relu(conv(x) + bias)   (components.py:41-43: F.relu(self.cN(x))) */
+  DD_EPI_RELU_MASK = 3  /* y = conv(x) * (mask > 0)   (autograd of the PREVIOUS layer's ReLU, fused) */
+};
+
+/* 3x3 convolution, padding 1, stride 1 or 2, Cout = 32.
+ * cin_real: channels of the PyTorch weight (3 or 32); cin_store: channels of the NHWC
+ * activation buffer (4 when cin_real == 3, the 4th channel being zero; else 32).
+ * Replaces nn.Conv2d c1/c2/c3 of reference src/autoencoder/components.py:19-21. */
+typedef struct dd_conv_desc {
+  int32_t batch, height, width; /* input spatial size */
+  int32_t cin_real, cin_store, cout;
+  int32_t ksize, stride, pad;
+  int32_t rows_per_task; /* 0 = library default; tuning knob, never changes results */
+} dd_conv_desc;
+
+int dd_abi_version(void);
+const char* dd_last_error(void);
+
+/* ---- layout: 6-view gather (K4) --------------------------------------------------
+ * views [B,6,3,H,W] fp32 -> wide NHWC4 image [B,H,6W,4] with the reference's view order
+ * [0,1,2,5,4,3] (roadmap_bce_v2.py:58-62, autoencoder.py:55-57); channel 3 is zero.
+ * mask_slot in 0..5 blanks that slot of the wide image (autoencoder.py:59-67) and, when
+ * target != NULL, copies its original content to target [B,3,H,W] (NCHW); -1 = no mask.
+ * wide_nchw (optional, may be NULL) also receives the stitched image as [B,3,H,6W] NCHW,
+ * which is what the reference's six_to_one_task / wide_stitch_six_images return. */
+int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* target,
+               int32_t batch, int32_t height, int32_t width, int32_t mask_slot, void* stream);
+
+/* NCHW [B,C,H,W] <-> NHWC [B,H,W,Cs] (Cs >= C; extra channels written as zero / ignored). */
+int dd_nchw_to_nhwc(const float* src, float* dst, int32_t batch, int32_t c, int32_t h, int32_t w,
+                    int32_t c_store, void* stream);
+int dd_nhwc_to_nchw(const float* src, float* dst, int32_t batch, int32_t c, int32_t h, int32_t w,
+                    int32_t c_store, void* stream);
+
+/* ---- conv 3x3 (K1) ----------------------------------------------------------------
+ * Packed weights: the MFMA B-operand image consumed by the kernels (dd_conv_packed_floats
+ * floats).  kind: 0 = forward, 1 = data-gradient of a stride-1 conv (flipped taps,
+ * Cin<->Cout swapped), 2 = data-gradient of a stride-2 conv. */
+int64_t dd_conv_packed_floats(const dd_conv_desc* d, int32_t kind);
+int dd_conv_pack(const float* w_oihw, float* packed, const dd_conv_desc* d, int32_t kind, void* stream);
+
+/* y[B,Ho,Wo,32] = epilogue(conv3x3(x[B,H,W,cin_store], W) ...).  `mask` is only read by
+ * DD_EPI_RELU_MASK and has y's shape. */
+int dd_conv_fwd(const float* x, const float* packed_fwd, const float* bias, const float* mask,
+                float* y, const dd_conv_desc* d, int32_t epilogue, void* stream);
+
+/* dx[B,H,W,32] = conv_transpose(dy[B,Ho,Wo,32], W) * (relu_src > 0 if relu_src != NULL).
+ * relu_src is the conv's INPUT activation (the previous layer's ReLU output), so the previous
+ * ReLU's backward is fused here.  Needs packed kind 1 (stride 1) or 2 (stride 2). */
+int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_src, float* dx,
+                  const dd_conv_desc* d, void* stream);
+
+/* dw_oihw[32,cin_real,3,3], dbias[32] from x[B,H,W,cin_store] and dy[B,Ho,Wo,32]
+ * (dy already multiplied by this layer's ReLU mask).  Deterministic: per-wave partial sums
+ * in `workspace`, then a fixed-order reduction. */
+int64_t dd_conv_wgrad_workspace_bytes(const dd_conv_desc* d);
+int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                  int64_t workspace_bytes, const dd_conv_desc* d, void* stream);
+
+/* out = dy * (y > 0), n elements (ReLU backward as a stand-alone pass). */
+int dd_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);
+
+/* ---- NCHW-order max_pool1d(4) on an NHWC feature (K6) -----------------------------------
+ * feat [B,H,W,C] NHWC.  The reference flattens the NCHW tensor and pools windows of 4 along
+ * that vector (components.py:46-47); pooled[b, g] = max_{i<4} feat_nchw_flat[b, 4g+i],
+ * g < floor(C*H*W/4).  Backward routes dpooled to the first maximum of each window and
+ * multiplies by (feat > 0), i.e. it also applies the backward of the ReLU that produced feat. */
+int dd_pool4_fwd(const float* feat, float* pooled, int32_t batch, int32_t h, int32_t w, int32_t c,
+                 void* stream);
+int dd_pool4_relu_bwd(const float* dpooled, const float* feat, float* dfeat, int32_t batch, int32_t h,
+                      int32_t w, int32_t c, void* stream);
+
+/* ---- dense head pieces (K8, K9) ---------------------------------------------------------
+ * BatchNorm1d (batch statistics when training != 0, else running statistics) -> ReLU ->
+ * dropout with a caller-supplied keep mask (components.py:104-109).  x,y,keep: [rows, feat].
+ * keep may be NULL (no dropout); scale = 1/(1-p).  save_mean/save_invstd [feat] are written in
+ * training mode and consumed by the backward.  Running stats are updated in place with
+ * `momentum` using the unbiased batch variance, as torch.nn.BatchNorm1d does. */
+int dd_bn_relu_drop_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, const float* keep, float* y, float* save_mean,
+                        float* save_invstd, int32_t rows, int32_t feat, float eps, float momentum,
+                        float scale, int32_t training, void* stream);
+int dd_bn_relu_drop_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                        const float* keep, const float* save_mean, const float* save_invstd,
+                        const float* running_mean, const float* running_var, float* dx, float* dgamma, float* dbeta, int32_t rows,
+                        int32_t feat, float eps, float scale, int32_t training, void* stream);
+
+/* Mean binary cross-entropy with logits over n elements (roadmap_bce_v2.py:106), one pass:
+ * loss_out[0] = mean(max(z,0) - z*t + log1p(exp(-|z|))); dlogits (optional) = (sigmoid(z) - t) *
+ * grad_scale / n; probs (optional) = sigmoid(z).  target is fp32 0/1.  partials: workspace of
+ * dd_loss_workspace_bytes(n) bytes. */
+int64_t dd_loss_workspace_bytes(int64_t n);
+int dd_bce_logits(const float* logits, const float* target, float* loss_out, float* dlogits,
+                  float* probs, int64_t n, float grad_scale, void* workspace, void* stream);
+/* Mean squared error mean((a-b)^2) with optional da = 2(a-b)*grad_scale/n (autoencoder.py:91). */
+int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n, float grad_scale,
+           void* workspace, void* stream);
+
+/* ---- optimizer -----------------------------------------------------------------------------
+ * torch.optim.Adam step (autoencoder.py:119-120, roadmap_bce_v2.py:154-157; no weight decay,
+ * no amsgrad) over one flat fp32 buffer: p, g, m, v of n elements; step >= 1. */
+int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DD_HOTPATH_H */

@@ -1,0 +1,134 @@
+"""The CPU oracle (oracle/) against the fixtures captured from the imported reference modules.
+
+fp32 runs use the same torch kernels as the reference did, so they must agree to a few ulp;
+the fp64 fixtures are the tolerance-budget ground truth.
+"""
+import numpy as np
+import pytest
+import torch
+
+from driving_dirty_amd import synth
+from oracle import ae_parts, spatial_parts, steps
+
+torch.set_num_threads(8)
+
+
+def _close(a, b, rtol, atol=0.0):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol + atol / scale, f"max rel-to-peak err {err:.3e} > {rtol:.1e}"
+
+
+def _drop0(m):
+    for mod in m.modules():
+        if isinstance(mod, ae_parts.FcBlock):
+            mod.drop_p = 0.0
+    return m
+
+
+@pytest.mark.parametrize("dt,tag,tol", [(torch.float32, "f32", 2e-6), (torch.float64, "f64", 1e-12)])
+def test_tiny_encoder(golden, dt, tag, tol):
+    g = golden("tiny_encoder")
+    enc = _drop0(synth.fill_module(ae_parts.EncoderNet(16, 8, 3, 16, 22), seed=1)).to(dt)
+    x = synth.hash_uniform((3, 3, 16, 22), synth.key_salt("tiny_x"), 0.0, 1.0).to(dt)
+    wz = synth.hash_uniform((3, 8), synth.key_salt("tiny_wz")).to(dt)
+    enc.train()
+    z = enc(x)
+    (z * wz).sum().backward()
+    _close(z.detach(), g[f"z_{tag}"], tol)
+    for k, p in enc.named_parameters():
+        _close(p.grad, g[f"grad.{k}_{tag}"], 20 * tol)
+    for k, b in enc.named_buffers():
+        _close(b, g[f"buf.{k}_{tag}"], tol)
+    enc.zero_grad()
+    enc.c3_only = True
+    feat = enc(x)
+    wf = synth.hash_uniform(tuple(feat.shape), synth.key_salt("tiny_wf")).to(dt)
+    (feat * wf).sum().backward()
+    _close(feat.detach(), g[f"feat_{tag}"], tol)
+    for k in ("c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias"):
+        _close(dict(enc.named_parameters())[k].grad, g[f"featgrad.{k}_{tag}"], 20 * tol)
+    enc.c3_only = False
+    enc.eval()
+    _close(enc(x).detach(), g[f"z_eval_{tag}"], tol)
+
+
+@pytest.mark.parametrize("dt,tag,tol", [(torch.float32, "f32", 2e-6), (torch.float64, "f64", 1e-12)])
+def test_tiny_decoder(golden, dt, tag, tol):
+    g = golden("tiny_decoder")
+    dec = _drop0(synth.fill_module(ae_parts.DecoderNet(16, 8, 3, 16, 22), seed=2)).to(dt)
+    z = synth.hash_uniform((3, 8), synth.key_salt("tiny_z"), -1.0, 1.0).to(dt).requires_grad_(True)
+    dec.train()
+    y = dec(z)
+    wy = synth.hash_uniform(tuple(y.shape), synth.key_salt("tiny_wy")).to(dt)
+    (y * wy).sum().backward()
+    _close(y.detach(), g[f"y_{tag}"], tol)
+    _close(z.grad, g[f"grad.z_{tag}"], 20 * tol)
+    for k, p in dec.named_parameters():
+        _close(p.grad, g[f"grad.{k}_{tag}"], 20 * tol)
+
+
+def test_default_init_rng_parity(golden):
+    """Constructors draw from the torch RNG in the reference's order: same seed -> same weights."""
+    g = golden("default_init")
+    torch.manual_seed(20200505)
+    enc = ae_parts.EncoderNet(16, 8, 3, 16, 22)
+    dec = ae_parts.DecoderNet(16, 8, 3, 16, 22)
+    torch.manual_seed(20200505)
+    sm, bm, rb = spatial_parts.SpatialMapNet(), spatial_parts.BoxMergeNet(), spatial_parts.RoadBoxMergeNet()
+    for name, m in (("enc", enc), ("dec", dec), ("space", sm), ("boxm", bm), ("rboxm", rb)):
+        sd = m.state_dict()
+        keys = [k[len(name) + 1:] for k in g.files if k.startswith(name + ".")]
+        assert sorted(keys) == sorted(sd.keys())
+        for k, v in sd.items():
+            v = v.double().reshape(-1)
+            got = np.array([v.sum().item(), v.abs().sum().item(), v[0].item(), v[-1].item()])
+            np.testing.assert_allclose(got, g[f"{name}.{k}"], rtol=1e-12, atol=1e-12)
+
+
+def test_stitch_and_mask_task():
+    """Index glue: closed-form check of the view order / stitch and the masked-view task."""
+    b, h, w = 2, 4, 5
+    v = torch.arange(b * 6 * 3 * h * w, dtype=torch.float32).reshape(b, 6, 3, h, w)
+    x = steps.wide_stitch(v)
+    assert x.shape == (b, 3, h, 6 * w)
+    for slot, view in enumerate((0, 1, 2, 5, 4, 3)):
+        assert torch.equal(x[:, :, :, slot * w:(slot + 1) * w], v[:, view])
+    assert torch.equal(steps.wide_stitch(tuple(v)), x)
+    rng = np.random.RandomState(20200505)
+    draws = [int(np.random.RandomState(20200505).randint(0, 5))]
+    x2, y2, t = steps.six_to_one_task(v, rng)
+    assert t == draws[0] and 0 <= t < 5
+    assert torch.equal(y2, x[..., t * w:(t + 1) * w])
+    assert float(x2[..., t * w:(t + 1) * w].abs().sum()) == 0.0
+    keep = torch.ones(6 * w, dtype=torch.bool)
+    keep[t * w:(t + 1) * w] = False
+    assert torch.equal(x2[..., keep], x[..., keep])
+
+
+def test_threat_score_and_collate():
+    a = torch.tensor([[1., 0.], [1., 1.]])
+    b = torch.tensor([[1., 1.], [0., 1.]])
+    assert float(steps.threat_score(a, b)) == pytest.approx(2.0 / (3 + 3 - 2))
+    assert steps.collate([(1, 2, 3), (4, 5, 6)]) == ((1, 4), (2, 5), (3, 6))
+
+
+def test_dropout_is_always_on():
+    """components.py:108 calls F.dropout without training=: active even in eval mode."""
+    blk = ae_parts.FcBlock(8, 64, drop_p=0.5).eval()
+    x = torch.randn(16, 8)
+    out = blk(x)
+    assert (out == 0).float().mean() > 0.5      # relu zeros + dropped units
+    torch.manual_seed(0)
+    a = blk(x)
+    torch.manual_seed(1)
+    b = blk(x)
+    assert not torch.equal(a, b)
+    blk.drop_p = 0.0
+    assert torch.equal(blk(x), blk(x))
+    m = (torch.rand(16, 64) < 0.8).float()
+    blk.drop_p = 0.2
+    ref = torch.relu(blk.fc_bn(blk.fc1(x))) * m / 0.8
+    assert torch.allclose(blk(x, m), ref)
