@@ -29,11 +29,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-def rel_err(got, ref):
+def rel_err(got, ref, floor=1e-30):
+    """max |got-ref| relative to the reference tensor's peak magnitude (at least ``floor``).
+
+    ``floor`` matters for gradients that are mathematically zero (a Linear bias in front of a
+    train-mode BatchNorm): the fp64 reference holds ~1e-15 there, any fp32 path holds ~1e-6.
+    """
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
-    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(floor))
 
 
 def nhwc(x):
@@ -162,7 +167,7 @@ def test_losses(dev, n):
     zd = z.detach().float().to(dev).requires_grad_(True)
     loss = ops.BceWithLogits.apply(zd, t.float().to(dev))
     (loss * 2.0).backward()
-    assert abs(float(loss) - float(ref)) / float(ref) < 1e-6
+    assert abs(float(loss.detach()) - float(ref.detach())) / float(ref.detach()) < 1e-6
     assert rel_err(zd.grad, 2.0 * z.grad) < KERNEL_TOL
     l2, probs = ops.sigmoid_and_loss(zd.detach(), t.float().to(dev))
     assert rel_err(probs, torch.sigmoid(z)) < KERNEL_TOL
@@ -172,7 +177,7 @@ def test_losses(dev, n):
     ad = a.detach().float().to(dev).requires_grad_(True)
     lm = ops.MseLoss.apply(ad, t.float().to(dev))
     lm.backward()
-    assert abs(float(lm) - float(refm)) / float(refm) < 1e-6
+    assert abs(float(lm.detach()) - float(refm.detach())) / float(refm.detach()) < 1e-6
     assert rel_err(ad.grad, a.grad) < KERNEL_TOL
 
 
@@ -189,6 +194,18 @@ def test_adam_matches_torch(dev):
         opt.step()
         ops.adam_step_flat(p, gs.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
     assert rel_err(p, p_ref) < 1e-6
+
+
+def _grad_floor(g, key):
+    """A Linear bias in front of a train-mode BatchNorm has an exactly-zero gradient; in fp32 (the reference's
+    own fp32 run included: 3.6e-5 in the fixture) it is rounding noise of the layer's gradient scale, so it is
+    judged against the peak of that layer's WEIGHT gradient rather than against ~1e-15."""
+    if key.endswith(".fc1.bias"):
+        wk = key[:-len("bias")] + "weight"
+        for cand in (f"grad.{wk}_f64", f"gradsamp.{wk}_f64"):
+            if cand in g.files:
+                return float(np.abs(g[cand]).max())
+    return 1e-30
 
 
 def _tiny_encoder(dev):
@@ -209,7 +226,7 @@ def test_tiny_encoder_against_reference_golden(dev, golden):
     (z * wz).sum().backward()
     assert rel_err(z, torch.from_numpy(g["z_f64"])) < CHAIN_TOL
     for k, p in enc.named_parameters():
-        assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"])) < CHAIN_TOL, k
+        assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"]), floor=_grad_floor(g, k)) < CHAIN_TOL, k
     for k, b in enc.named_buffers():
         assert rel_err(b.float(), torch.from_numpy(g[f"buf.{k}_f64"])) < CHAIN_TOL, k
     enc.zero_grad()
@@ -255,7 +272,7 @@ def test_full_size_roadmap_against_reference_golden(dev, golden):
     named.update(dict(model.ae.encoder.named_parameters()))
     for k, p in named.items():
         if f"grad.{k}_f64" in g.files:
-            assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"])) < CHAIN_TOL, k
+            assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"]), floor=_grad_floor(g, k)) < CHAIN_TOL, k
         else:
             assert rel_err(_samp(p.grad, g[f"gradidx.{k}"]), torch.from_numpy(g[f"gradsamp.{k}_f64"])) < CHAIN_TOL, k
         s = g[f"gradsum.{k}_f64"]
