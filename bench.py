@@ -81,13 +81,26 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
 
 
+def host_cores():
+    """CPU threads this job may really use: affinity, capped by the cgroup quota and by the GPU box's
+    per-GPU CPU share (16); DD_CPU_THREADS overrides."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("DD_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(sample_batch=4, steps=2):
     """The CPU oracle (oracle/: pure-torch restatement of the reference path) timed on this host's cores.
 
     Bounded sample: the same step (stitch -> encoder -> head -> BCE -> backward -> torch Adam) at bs = 4,
     one warm-up + ``steps`` timed steps (~10-30 s)."""
     from oracle import ae_parts, steps as osteps
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(SEED)
     enc = ae_parts.EncoderNet(HIDDEN, LATENT, 3, H, 6 * W)

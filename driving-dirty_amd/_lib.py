@@ -5,6 +5,9 @@ There is no fallback: if the library is missing or a call fails, an exception is
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch has loaded (same soname
+#                              libamdhip64.so.7); loading ours first would put a second runtime in the process
+
 from .build import LIB
 
 _i32, _i64, _f32, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p

