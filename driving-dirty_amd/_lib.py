@@ -42,6 +42,10 @@ SIGNATURES = {
     "dd_loss_workspace_bytes": (_i64, [_i64]),
     "dd_bce_logits": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_mse": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
+    "dd_linear_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "dd_linear_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
+    "dd_linear_dgrad": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
+    "dd_linear_wgrad": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 

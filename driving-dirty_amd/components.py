@@ -37,7 +37,7 @@ class DenseBlock(nn.Module):
     def forward(self, x, keep=None):
         """``keep`` (optional 0/1 tensor) injects the dropout mask; otherwise one is drawn on the device."""
         _require_gpu(x, "DenseBlock")
-        lin = F.linear(x, self.fc1.weight, self.fc1.bias)
+        lin = ops.linear(x, self.fc1.weight, self.fc1.bias)
         bn = self.fc_bn
         p = float(self.drop_p)
         if keep is None and p > 0.0:
@@ -47,7 +47,7 @@ class DenseBlock(nn.Module):
             bn.num_batches_tracked += 1
         momentum = 0.1 if bn.momentum is None else bn.momentum
         scale = 1.0 / (1.0 - p) if p < 1.0 else 0.0
-        return ops.BnReluDrop.apply(lin.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, keep,
+        return ops.BnReluDrop.apply(lin, bn.weight, bn.bias, bn.running_mean, bn.running_var, keep,
                                     training, bn.eps, momentum, scale)
 
 
@@ -79,7 +79,7 @@ class Encoder(nn.Module):
         pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, True, self.rows_per_task)
         h = self.fc1(pooled, keeps[0])
         h = self.fc2(h, keeps[1])
-        return F.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
+        return ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
 
     def forward(self, x, keeps=(None, None)):
         _require_gpu(x, "Encoder")

@@ -235,61 +235,54 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
     f32x4 pre[C::NLOAD];
     load_row<32, 1>(dyb, Ho, Wo, r + 2, s0, lane, pre);
 
-    f32x16 a00, a01, a10, a11;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
-
     const char* row_r = ring + (r % 3) * C::SLOTB;
     const char* row_r1 = ring + ((r + 1) % 3) * C::SLOTB;
-    const int q0 = n, q1 = n + 1;
-    const int sw0 = swz<32>(q0), sw1 = swz<32>(q1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ch = 2 * j + h;
-      const f32x4 A_r_s = *(const f32x4*)(row_r + q0 * 128 + ((ch ^ sw0) << 4));
-      const f32x4 A_r_s1 = *(const f32x4*)(row_r + q1 * 128 + ((ch ^ sw1) << 4));
-      const f32x4 A_r1_s = *(const f32x4*)(row_r1 + q0 * 128 + ((ch ^ sw0) << 4));
-      const f32x4 A_r1_s1 = *(const f32x4*)(row_r1 + q1 * 128 + ((ch ^ sw1) << 4));
-#define DD_TAP(ACC, A, T)                                                        \
-  {                                                                              \
-    const f32x4 w = *(const f32x4*)(wl + ((((T)) * 4 + j) * 64 + lane) * 16);    \
-    ACC = DD_MFMA(A.x, w.x, ACC);                                                \
-    ACC = DD_MFMA(A.y, w.y, ACC);                                                \
-    ACC = DD_MFMA(A.z, w.z, ACC);                                                \
-    ACC = DD_MFMA(A.w, w.w, ACC);                                                \
+    // One parity tile at a time: its ReLU-mask values are requested BEFORE its MFMA chain and consumed after,
+    // so the epilogue never waits on HBM; only one 32x32 accumulator is live.
+    // tap list per tile: (row offset 0/1, pixel offset 0/1, weight tap ky*3+kx)
+#define DD_TILE(PY, PX, NTAP, ...)                                                              \
+  {                                                                                             \
+    constexpr int taps[NTAP][3] = {__VA_ARGS__};                                                \
+    const int yi = 2 * r + (PY);                                                                \
+    const int yic = min(yi, H - 1);                                                             \
+    float mreg[16];                                                                             \
+    if (MASK) {                                                                                 \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                       \
+        const int xi = min(2 * (s0 + dd_acc_row(rr, lane)) + (PX), W - 1);                      \
+        mreg[rr] = msk[((long)(b * H + yic) * W + xi) * 32 + n];                                \
+      }                                                                                         \
+    }                                                                                           \
+    f32x16 acc;                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                \
+    _Pragma("unroll") for (int t = 0; t < NTAP; ++t) {                                          \
+      const char* rowp = taps[t][0] ? row_r1 : row_r;                                           \
+      const int q = n + taps[t][1];                                                             \
+      const char* pa = rowp + q * 128;                                                          \
+      const int sw = swz<32>(q);                                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+        const f32x4 a = *(const f32x4*)(pa + (((2 * j + h) ^ sw) << 4));                        \
+        const f32x4 w = *(const f32x4*)(wl + ((taps[t][2] * 4 + j) * 64 + lane) * 16);          \
+        acc = DD_MFMA(a.x, w.x, acc);                                                           \
+        acc = DD_MFMA(a.y, w.y, acc);                                                           \
+        acc = DD_MFMA(a.z, w.z, acc);                                                           \
+        acc = DD_MFMA(a.w, w.w, acc);                                                           \
+      }                                                                                         \
+    }                                                                                           \
+    if (yi < H) {                                                                               \
+      float* orow = dx + ((long)(b * H + yi) * W) * 32 + n;                                     \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                       \
+        const int xi = 2 * (s0 + dd_acc_row(rr, lane)) + (PX);                                  \
+        float v = acc[rr];                                                                      \
+        if (MASK) v = (mreg[rr] > 0.f) ? v : 0.f;                                               \
+        if (xi < W) orow[(long)xi * 32] = v;                                                    \
+      }                                                                                         \
+    }                                                                                           \
   }
-      DD_TAP(a00, A_r_s, 4)      // (ky,kx) = (1,1)
-      DD_TAP(a01, A_r_s1, 3)     // (1,0)
-      DD_TAP(a01, A_r_s, 5)      // (1,2)
-      DD_TAP(a10, A_r1_s, 1)     // (0,1)
-      DD_TAP(a10, A_r_s, 7)      // (2,1)
-      DD_TAP(a11, A_r1_s1, 0)    // (0,0)
-      DD_TAP(a11, A_r1_s, 2)     // (0,2)
-      DD_TAP(a11, A_r_s1, 6)     // (2,0)
-      DD_TAP(a11, A_r_s, 8)      // (2,2)
-#undef DD_TAP
-    }
-
-#define DD_EMIT(ACC, PY, PX)                                                      \
-  {                                                                               \
-    const int yi = 2 * r + (PY);                                                  \
-    if (yi < H) {                                                                 \
-      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                         \
-        const int xi = 2 * (s0 + dd_acc_row(rr, lane)) + (PX);                    \
-        if (xi < W) {                                                             \
-          const long o = ((long)(b * H + yi) * W + xi) * 32 + n;                  \
-          float v = ACC[rr];                                                      \
-          if (MASK) v = (msk[o] > 0.f) ? v : 0.f;                                 \
-          dx[o] = v;                                                              \
-        }                                                                         \
-      }                                                                           \
-    }                                                                             \
-  }
-    DD_EMIT(a00, 0, 0)
-    DD_EMIT(a01, 0, 1)
-    DD_EMIT(a10, 1, 0)
-    DD_EMIT(a11, 1, 1)
-#undef DD_EMIT
+    DD_TILE(1, 1, 4, {1, 1, 0}, {1, 0, 2}, {0, 1, 6}, {0, 0, 8})   // (ky,kx) = (0,0) (0,2) (2,0) (2,2)
+    DD_TILE(0, 1, 2, {0, 1, 3}, {0, 0, 5})                         // (1,0) (1,2)
+    DD_TILE(1, 0, 2, {1, 0, 1}, {0, 0, 7})                         // (0,1) (2,1)
+    DD_TILE(0, 0, 1, {0, 0, 4})                                    // (1,1)
+#undef DD_TILE
 
     store_row<32, 1, true>(ring + ((r + 2) % 3) * C::SLOTB, lane, pre);
   }

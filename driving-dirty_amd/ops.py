@@ -198,6 +198,54 @@ def encoder_conv_stack(x4, c1, c2, c3, pool, rows_per_task=0):
     return EncoderConvStack.apply(x4, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, pool, rows_per_task)
 
 
+# ------------------------------------------------------------------------------------------------ skinny GEMMs
+def _linear_ws(m, n, k, device):
+    nbytes = _lib.lib().dd_linear_workspace_bytes(m, n, k)
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
+
+
+class Linear(torch.autograd.Function):
+    """y = x W^T + b with nn.Linear's [out, in] weight, all three passes on the fp32 matrix cores
+    (dd_linear_fwd / dgrad / wgrad).  Reference call sites: components.py:105 (DenseBlock.fc1),
+    components.py:51 (fc_z_out), roadmap_bce_v2.py:75 (head)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        m, k = x.shape
+        n = weight.shape[0]
+        _dev(x, "x")
+        _dev(weight, "weight", (n, k))
+        if bias is not None:
+            _dev(bias, "bias", (n,))
+        y = torch.empty((m, n), device=x.device, dtype=torch.float32)
+        ws, nbytes = _linear_ws(m, n, k, x.device)
+        check(_lib.lib().dd_linear_fwd(_p(x), _p(weight), _p(bias), _p(y), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        m, k = x.shape
+        n = weight.shape[0]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ws, nbytes = _linear_ws(m, n, k, x.device)
+            check(_lib.lib().dd_linear_dgrad(_p(dy), _p(weight), _p(dx), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_dgrad")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight)
+            db = torch.empty(n, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            check(_lib.lib().dd_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), m, n, k, _stream()), "dd_linear_wgrad")
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    return Linear.apply(x.contiguous(), weight, bias)
+
+
 # ------------------------------------------------------------------------------------------------ dense block tail
 class BnReluDrop(torch.autograd.Function):
     """BatchNorm1d -> ReLU -> dropout(keep mask) in one kernel each way (components.py:105-108)."""

@@ -49,7 +49,7 @@ class RoadMapBCE(LightningModule):
     def forward(self, x, keeps=(None, None)):
         """-> (logits [B,800,800], sigmoid(logits)).  roadmap_bce_v2.py:66-81."""
         representations = self._encode(x, keeps)
-        y = F.linear(representations, self.fc1.weight, self.fc1.bias)
+        y = ops.linear(representations, self.fc1.weight, self.fc1.bias)
         y = y.reshape(y.size(0), 800, 800)
         return y, torch.sigmoid(y)
 
@@ -109,7 +109,7 @@ class RoadMap(RoadMapBCE):
     """MSE twin (roadmap_pretrain_ae.py): sigmoid inside ``forward``, ``mse_loss(target, pred)``, unfreeze at epoch 30."""
 
     def forward(self, x, keeps=(None, None)):
-        y = torch.sigmoid(F.linear(self._encode(x, keeps), self.fc1.weight, self.fc1.bias))
+        y = torch.sigmoid(ops.linear(self._encode(x, keeps), self.fc1.weight, self.fc1.bias))
         return y.reshape(y.size(0), 800, 800)
 
     def _run_step(self, batch, batch_idx, step_name, keeps=(None, None)):

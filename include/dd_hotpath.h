@@ -137,6 +137,22 @@ int dd_bce_logits(const float* logits, const float* target, float* loss_out, flo
 int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n, float grad_scale,
            void* workspace, void* stream);
 
+/* ---- skinny GEMMs of the dense head (K7): nn.Linear with the weight kept as [out=N, in=K] ------------
+ * Replace F.linear / its autograd for DenseBlock.fc1 (components.py:105), Encoder.fc_z_out (components.py:51)
+ * and the roadmap head (roadmap_bce_v2.py:75).  M = batch rows (<= 64), N and K multiples of 4.
+ *   fwd   y[M,N]  = x[M,K] w[N,K]^T + bias[N]     (bias may be NULL)
+ *   dgrad dx[M,K] = dy[M,N] w[N,K]
+ *   wgrad dw[N,K] = dy[M,N]^T x[M,K];  dbias[N] = sum_m dy[m,:]   (dbias may be NULL)
+ * fwd/dgrad split the long contraction over workgroups and reduce the partial slabs in a fixed order
+ * (deterministic); `workspace` must hold dd_linear_workspace_bytes(m, n, k) bytes. */
+int64_t dd_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
+int dd_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t m, int32_t n, int32_t k,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+int dd_linear_dgrad(const float* dy, const float* w, float* dx, int32_t m, int32_t n, int32_t k, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+int dd_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int32_t m, int32_t n, int32_t k,
+                    void* stream);
+
 /* ---- optimizer -----------------------------------------------------------------------------
  * torch.optim.Adam step (autoencoder.py:119-120, roadmap_bce_v2.py:154-157; no weight decay,
  * no amsgrad) over one flat fp32 buffer: p, g, m, v of n elements; step >= 1. */

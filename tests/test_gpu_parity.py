@@ -157,6 +157,38 @@ def test_bn_relu_dropout(dev, rows, feat, training, drop):
     assert rel_err(rv, blk.fc_bn.running_var) < KERNEL_TOL
 
 
+@pytest.mark.parametrize("m,n,k", [(3, 16, 704), (3, 8, 16), (32, 128, 128), (32, 64, 128), (5, 20, 8), (2, 1000, 64),
+                                   (32, 128, 18816), (33, 260, 72), (64, 36, 132), (4, 640000, 8)])
+def test_linear_fwd_dgrad_wgrad(dev, m, n, k):
+    """Skinny GEMMs (split-K forward, split-N dgrad, register wgrad) vs fp64 torch."""
+    from driving_dirty_amd import ops
+    x = hu((m, k), f"lx{m}{k}").double().requires_grad_(True)
+    w = hu((n, k), f"lw{n}{k}", -0.2, 0.2).double().requires_grad_(True)
+    b = hu((n,), f"lb{n}").double().requires_grad_(True)
+    y_ref = F.linear(x, w, b)
+    gy = hu((m, n), f"lg{m}{n}").double()
+    y_ref.backward(gy)
+    xd = x.detach().float().to(dev).requires_grad_(True)
+    wd = w.detach().float().to(dev).requires_grad_(True)
+    bd = b.detach().float().to(dev).requires_grad_(True)
+    y = ops.linear(xd, wd, bd)
+    y.backward(gy.float().to(dev))
+    assert rel_err(y, y_ref) < KERNEL_TOL
+    assert rel_err(xd.grad, x.grad) < KERNEL_TOL
+    assert rel_err(wd.grad, w.grad) < KERNEL_TOL
+    assert rel_err(bd.grad, b.grad) < KERNEL_TOL
+    y2 = ops.linear(xd.detach(), wd.detach(), None)
+    assert rel_err(y2, y_ref - b.detach()) < KERNEL_TOL
+
+
+def test_linear_refuses_unsupported(dev):
+    from driving_dirty_amd import _lib, ops
+    with pytest.raises(_lib.HotpathError):
+        ops.linear(torch.zeros(3, 6, device=dev), torch.zeros(8, 6, device=dev), None)      # K % 4 != 0
+    with pytest.raises(_lib.HotpathError):
+        ops.linear(torch.zeros(65, 8, device=dev), torch.zeros(8, 8, device=dev), None)     # M > 64
+
+
 @pytest.mark.parametrize("n", [7, 4096, 2 * 640000 + 3])
 def test_losses(dev, n):
     from driving_dirty_amd import ops
@@ -280,13 +312,15 @@ def test_full_size_roadmap_against_reference_golden(dev, golden):
     named = {("head." + k): p for k, p in model.fc1.named_parameters()}
     named.update(dict(model.ae.encoder.named_parameters()))
     for k, p in named.items():
-        if f"grad.{k}_f64" in g.files:
-            assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"]), floor=_grad_floor(g, k)) < _budget(g, f"grad.{k}"), k
+        key = f"grad.{k}" if f"grad.{k}_f64" in g.files else f"gradsamp.{k}"
+        budget = _budget(g, key)
+        if key.startswith("grad."):
+            assert rel_err(p.grad, torch.from_numpy(g[key + "_f64"]), floor=_grad_floor(g, k)) < budget, k
         else:
-            assert rel_err(_samp(p.grad, g[f"gradidx.{k}"]), torch.from_numpy(g[f"gradsamp.{k}_f64"])) < _budget(g, f"gradsamp.{k}"), k
-        s, s32 = g[f"gradsum.{k}_f64"], g[f"gradsum.{k}_f32"]
-        if s[1] > 1e-6:
-            assert abs(float(p.grad.double().abs().sum()) - s[1]) / s[1] < max(CHAIN_TOL, 2 * abs(s32[1] - s[1]) / s[1]), k
+            assert rel_err(_samp(p.grad, g[f"gradidx.{k}"]), torch.from_numpy(g[key + "_f64"])) < budget, k
+        s = g[f"gradsum.{k}_f64"]
+        if s[1] > 1e-6:     # checksum over the WHOLE tensor (the 481 MB fc1 gradient is only sampled above)
+            assert abs(float(p.grad.double().abs().sum()) - s[1]) / s[1] < budget, k
     model.ae.encoder.c3_only = True
     with torch.no_grad():
         feat = model.ae.encoder.forward_nhwc4(__import__("driving_dirty_amd.ops", fromlist=["ops"]).stitch6(views)[0])

@@ -85,7 +85,16 @@ def main():
     wh = torch.randn(640000, 64, device=dev) * 0.1
     dy = torch.randn(b, 128, device=dev)
     dl = torch.randn(b, 640000, device=dev)
+    wfc_g, wh_g, zg = torch.empty_like(wfc), torch.empty_like(wh), torch.empty_like(z)
+    ws = torch.empty(ops._lib.lib().dd_linear_workspace_bytes(b, 640000, 64), device=dev, dtype=torch.uint8)
+    xw = torch.randn(b, pooled.shape[1], device=dev)
     for name, fn, nbytes in [
+        ("fc1_fwd_hip", lambda: ops.Linear.apply(pooled, wfc, None), wfc.numel() * 4),
+        ("fc1_dgrad_hip", lambda: ops._lib.check(ops._lib.lib().dd_linear_dgrad(ops._p(dy), ops._p(wfc), ops._p(xw), b, 128, wfc.shape[1], None, 0, ops._stream()), "dgrad"), wfc.numel() * 4),
+        ("fc1_wgrad_hip", lambda: ops._lib.check(ops._lib.lib().dd_linear_wgrad(ops._p(dy), ops._p(pooled), ops._p(wfc_g), None, b, 128, wfc.shape[1], ops._stream()), "wgrad"), wfc.numel() * 4),
+        ("head_fwd_hip", lambda: ops.Linear.apply(z, wh, None), wh.numel() * 4 + dl.numel() * 4),
+        ("head_dgrad_hip", lambda: ops._lib.check(ops._lib.lib().dd_linear_dgrad(ops._p(dl), ops._p(wh), ops._p(zg), b, 640000, 64, ops._p(ws), ws.numel(), ops._stream()), "dgrad"), wh.numel() * 4 + dl.numel() * 4),
+        ("head_wgrad_hip", lambda: ops._lib.check(ops._lib.lib().dd_linear_wgrad(ops._p(dl), ops._p(z), ops._p(wh_g), None, b, 640000, 64, ops._stream()), "wgrad"), wh.numel() * 4 + dl.numel() * 4),
         ("fc1_fwd_torch", lambda: torch.nn.functional.linear(pooled, wfc), wfc.numel() * 4),
         ("fc1_dgrad_torch", lambda: dy @ wfc, wfc.numel() * 4),
         ("fc1_wgrad_torch", lambda: dy.t() @ pooled, wfc.numel() * 4),
