@@ -1,18 +1,28 @@
 // 3x3 convolution family for the encoder conv stack (reference src/autoencoder/components.py:19-21,41-43)
 // as implicit GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32), NHWC activations.
 //
-// Decomposition ("strip marching"): one WAVE owns a strip of 32 output pixels of one image row band
-// and marches down the rows.  It keeps the three input rows a 3x3 window needs in its own LDS ring
-// (3 slots), prefetches the next row(s) into registers while the matrix cores work on the current
-// row, and never synchronises with another wave: no barrier in the main loop.  The GEMM view is
-// M = 32 pixels, N = 32 output channels, K = 9 taps x Cin; fp32 MFMA issues once per 64 cycles per
-// SIMD, so LDS (2 x ds_read_b128 per 4 MFMAs) and HBM (one 4.3 KB row per 9216 MFMA cycles) are far
-// from binding: the kernels are MFMA-issue bound by construction.
+// Decomposition ("strip marching"): one WAVE owns a strip of 32 output pixels and marches down the rows of
+// an image column.  It keeps the three input rows a 3x3 window needs in its own LDS ring (3 slots),
+// prefetches the next row(s) into registers while the matrix cores work on the current row, and never
+// synchronises with another wave: no barrier in the main loop.  The GEMM view is M = 32 pixels, N = 32
+// output channels, K = 9 taps x Cin; the fp32 MFMA issues once per 64 cycles per SIMD, so LDS (2 x
+// ds_read_b128 per 4 MFMAs) and HBM (one 4.3 KB row per 9216 MFMA cycles) are far from binding: the kernels
+// are MFMA-issue bound by construction.
+//
+// Scheduling: the grid is exactly the number of resident workgroups; the B*strips*rows "row tiles" are cut
+// into one contiguous, equal range per wave (an image column after the other), so every wave does the same
+// number of MFMAs and pays a ring prologue only where its range starts or crosses into the next column.
+//
+// Memory addressing: every global access is a raw buffer load/store whose descriptor covers ONE image row
+// (or zero bytes for a row outside the image).  Out-of-image pixels are then hardware range-check zeros /
+// dropped stores: no clamps, no selects, no branches around memory instructions, and an indexing bug cannot
+// fault the GPU.
 //
 //   conv_strip_fwd <CIN,S,EPI>  forward (bias+ReLU epilogue) and stride-1 data gradient (ReLU-mask epilogue)
 //   conv_s2_dgrad               data gradient of the stride-2 conv, by output parity class (no zero insertion)
-//   conv_wgrad <CIN,S>          weight + bias gradient, persistent waves, register accumulators,
-//                               deterministic two-stage reduction
+//   conv_wgrad <CIN,S>          weight + bias gradient, register accumulators, deterministic two-stage reduction
+#include <stdlib.h>
+
 #include "dd_common.h"
 
 namespace {
@@ -25,9 +35,24 @@ struct StripCfg {
   static constexpr int SLOTB = NPX * PXB;    // one ring slot = one input row of the strip
   static constexpr int NCH = NPX * CHUNKS;
   static constexpr int NLOAD = (NCH + 63) / 64;
+  static constexpr int SPILLB = (NLOAD * 64 - NCH) * 16;  // landing zone of the idle lanes of the last chunk group
+  static constexpr int WAVEB = 3 * SLOTB + SPILLB;        // LDS per wave: 3-slot ring + landing zone
   static constexpr int KGROUPS = (CIN == 32) ? 36 : 5;   // groups of 4 MFMA k-steps
   static constexpr int WFLOATS = KGROUPS * 64 * 4;
 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
 
 // XOR swizzle of the 16-byte chunk index inside a 128-byte pixel so that the ds_read_b128 of 16
 // consecutive pixels (one lane group) covers all 64 banks: pixels q and q+1 differ in address bit 7,
@@ -37,36 +62,44 @@ __device__ __forceinline__ int swz(int q) {
   return CIN == 32 ? ((q >> 1) & 7) : 0;
 }
 
-// Load one row of a strip (NPX pixels starting at gx0, row iy of image `img`) into registers.
-// Out-of-image pixels read a clamped (valid) address and are zeroed afterwards: no branches around loads.
+// Row iy of image `img` ([H][W][CIN] floats): pixels gx0 .. gx0+NPX-1 into registers (zeros outside the image).
 template <int CIN, int S>
 __device__ __forceinline__ void load_row(const float* __restrict__ img, int H, int W, int iy, int gx0, int lane,
                                          f32x4 (&r)[StripCfg<CIN, S>::NLOAD]) {
   using C = StripCfg<CIN, S>;
   const bool rowok = (iy >= 0) && (iy < H);
-  const int iyc = min(max(iy, 0), H - 1);
-  const float* rp = img + (long)iyc * W * CIN;
+  const __amdgpu_buffer_rsrc_t rs = rsrc(img + (long)(rowok ? iy : 0) * W * CIN, rowok ? W * C::PXB : 0);
 #pragma unroll
   for (int i = 0; i < C::NLOAD; ++i) {
     const int c = lane + 64 * i;
     const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
-    const int gx = gx0 + q;
-    const bool ok = rowok && (c < C::NCH) && (gx >= 0) && (gx < W);
-    const int gxc = min(max(gx, 0), W - 1);
-    f32x4 v = *(const f32x4*)(rp + (long)gxc * CIN + ch * 4);
-    r[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    // a negative pixel index gives a huge unsigned offset: out of range -> zero, like the pixels right of the image
+    const int off = (c < C::NCH) ? ((gx0 + q) * C::PXB + ch * 16) : -16;
+    r[i] = bload4(rs, off);
   }
 }
 
+// Registers -> ring slot.  Every lane writes (no exec-masked branch that would drag the matching load and a
+// full vmcnt(0) wait into it): the lanes of the last, partial chunk group land in the wave's `spill` zone.
 template <int CIN, int S, bool SWZ>
-__device__ __forceinline__ void store_row(char* slot, int lane, const f32x4 (&r)[StripCfg<CIN, S>::NLOAD]) {
+__device__ __forceinline__ void store_row(char* slot, char* spill, int lane,
+                                          const f32x4 (&r)[StripCfg<CIN, S>::NLOAD]) {
   using C = StripCfg<CIN, S>;
 #pragma unroll
   for (int i = 0; i < C::NLOAD; ++i) {
     const int c = lane + 64 * i;
     const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
-    if (c < C::NCH) *(f32x4*)(slot + q * C::PXB + ((ch ^ (SWZ ? swz<CIN>(q) : 0)) << 4)) = r[i];
+    char* dst = slot + q * C::PXB + ((ch ^ (SWZ ? swz<CIN>(q) : 0)) << 4);
+    if (64 * (i + 1) > C::NCH) dst = (c < C::NCH) ? dst : spill + (c - C::NCH) * 16;
+    *(f32x4*)dst = r[i];
   }
+}
+
+// The contiguous range of row tiles owned by global wave gw; idx = column * rows + row.
+__device__ __forceinline__ void wave_range(long total, int gw, int nw, long& idx, long& end) {
+  const long per = (total + nw - 1) / nw;
+  idx = (long)gw * per;
+  end = min(idx + per, total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -76,8 +109,7 @@ template <int CIN, int S, int EPI, int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ msk, float* __restrict__ y,
-                                                           int B, int H, int W, int Ho, int Wo, int nstrips,
-                                                           int nbands, int RB) {
+                                                           int B, int H, int W, int Ho, int Wo, int nstrips) {
   using C = StripCfg<CIN, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -89,101 +121,105 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
     for (int i = tid; i < C::WFLOATS / 4; i += WPB * 64) wl4[i] = wg4[i];
   }
   __syncthreads();
-  const long total = (long)B * nbands * nstrips;
-  const long task = (long)blockIdx.x * WPB + wave;
-  if (task >= total) return;
-  const int strip = (int)(task % nstrips);
-  const int band = (int)((task / nstrips) % nbands);
-  const int b = (int)(task / ((long)nstrips * nbands));
-  const int x0 = strip * 32, y0 = band * RB;
-  const int y1 = min(y0 + RB, Ho);
-  char* ring = smem + C::WFLOATS * 4 + wave * 3 * C::SLOTB;
+  char* ring = smem + C::WFLOATS * 4 + wave * C::WAVEB;
+  char* spill = ring + 3 * C::SLOTB;
   const char* wl = smem;
   const int h = lane >> 5, n = lane & 31;
-  const float* xb = x + (long)b * H * W * CIN;
   const float bv = (EPI == DD_EPI_BIAS || EPI == DD_EPI_BIAS_RELU) ? bias[n] : 0.f;
-  const int gx0 = S * x0 - 1;
 
-  {  // prologue: the three rows output row y0 needs
+  long idx, end;
+  wave_range((long)B * nstrips * Ho, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / Ho;
+    const int y0 = (int)(idx - col * Ho);
+    const int y1 = (int)min((long)Ho, y0 + (end - idx));
+    idx += y1 - y0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const float* xb = x + (long)b * H * W * CIN;
+    const int gx0 = S * x0 - 1;
+
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < 3; ++d) {   // prologue: the three rows output row y0 needs
       f32x4 t[C::NLOAD];
       const int iy = S * y0 - 1 + d;
       load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
-      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, lane, t);
+      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
     }
-  }
 
-  for (int yy = y0; yy < y1; ++yy) {
-    // prefetch the S new input rows output row yy+1 needs (overlaps the MFMAs below)
-    f32x4 pre[S][C::NLOAD];
+    for (int yy = y0; yy < y1; ++yy) {
+      // prefetch the S new input rows output row yy+1 needs (in flight under the MFMAs below)
+      f32x4 pre[S][C::NLOAD];
 #pragma unroll
-    for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
+      for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
 
-    float mreg[16];
-    if (EPI == DD_EPI_RELU_MASK) {
+      const long orow = ((long)(b * Ho + yy) * Wo) * 32;
+      float mreg[16];
+      if (EPI == DD_EPI_RELU_MASK) {
+        const __amdgpu_buffer_rsrc_t ms = rsrc(msk + orow, Wo * 128);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int xo = min(x0 + dd_acc_row(r, lane), Wo - 1);
-        mreg[r] = msk[((long)(b * Ho + yy) * Wo + xo) * 32 + n];
+        for (int r = 0; r < 16; ++r) mreg[r] = bload1(ms, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4);
       }
-    }
+      // keep the loads ABOVE the MFMA chain: left alone, hipcc sinks them to their first use (the ring store
+      // behind the chain) and the wave then eats a full HBM round trip per row
+      __builtin_amdgcn_sched_barrier(0);
 
-    f32x16 acc;
+      f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    if (CIN == 32) {
+      if (CIN == 32) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;   // slot of input row S*yy-1+dy
+        for (int dy = 0; dy < 3; ++dy) {
+          const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;   // slot of input row S*yy-1+dy
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int q = S * n + dx;
-          const char* pa = rowb + q * 128;
-          const int sw = swz<32>(q);
+          for (int dx = 0; dx < 3; ++dx) {
+            const int q = S * n + dx;
+            const char* pa = rowb + q * 128;
+            const int sw = swz<32>(q);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f32x4 a = *(const f32x4*)(pa + (((2 * j + h) ^ sw) << 4));
-            const f32x4 w = *(const f32x4*)(wl + (((dy * 3 + dx) * 4 + j) * 64 + lane) * 16);
-            acc = DD_MFMA(a.x, w.x, acc);
-            acc = DD_MFMA(a.y, w.y, acc);
-            acc = DD_MFMA(a.z, w.z, acc);
-            acc = DD_MFMA(a.w, w.w, acc);
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 a = *(const f32x4*)(pa + (((2 * j + h) ^ sw) << 4));
+              const f32x4 w = *(const f32x4*)(wl + (((dy * 3 + dx) * 4 + j) * 64 + lane) * 16);
+              acc = DD_MFMA(a.x, w.x, acc);
+              acc = DD_MFMA(a.y, w.y, acc);
+              acc = DD_MFMA(a.z, w.z, acc);
+              acc = DD_MFMA(a.w, w.w, acc);
+            }
           }
         }
+      } else {  // CIN == 4 (3 real channels): k-step = one channel of a PAIR of taps (lower / upper half-wave)
+#pragma unroll
+        for (int jp = 0; jp < 5; ++jp) {
+          const int tap = min(2 * jp + h, 8);   // tap 9 does not exist: its packed weights are zero
+          const int dy = tap / 3, dx = tap - 3 * dy;
+          const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;
+          const f32x4 a = *(const f32x4*)(rowb + (S * n + dx) * 16);
+          const f32x4 w = *(const f32x4*)(wl + (jp * 64 + lane) * 16);
+          acc = DD_MFMA(a.x, w.x, acc);
+          acc = DD_MFMA(a.y, w.y, acc);
+          acc = DD_MFMA(a.z, w.z, acc);
+        }
       }
-    } else {  // CIN == 4 (3 real channels): k-step = one channel of a PAIR of taps (lower / upper half-wave)
+
+      // retire the prefetched rows into the ring BEFORE the epilogue stores are issued: the wait on the
+      // (long landed) loads then never has to drain this row's stores (vmcnt counts loads and stores together)
 #pragma unroll
-      for (int jp = 0; jp < 5; ++jp) {
-        const int tap = min(2 * jp + h, 8);   // tap 9 does not exist: its packed weights are zero
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;
-        const f32x4 a = *(const f32x4*)(rowb + (S * n + dx) * 16);
-        const f32x4 w = *(const f32x4*)(wl + (jp * 64 + lane) * 16);
-        acc = DD_MFMA(a.x, w.x, acc);
-        acc = DD_MFMA(a.y, w.y, acc);
-        acc = DD_MFMA(a.z, w.z, acc);
+      for (int s = 0; s < S; ++s) {
+        const int iy = S * yy + 2 + s;
+        store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
       }
-    }
 
-    // epilogue: lane = output channel, register = pixel -> 128-byte contiguous stores per pixel
-    float* yrow = y + ((long)(b * Ho + yy) * Wo) * 32;
+      // epilogue: lane = output channel, register = pixel -> 128 contiguous bytes per pixel per store;
+      // pixels right of the image fall outside the row descriptor and are dropped by the hardware
+      const __amdgpu_buffer_rsrc_t ys = rsrc(y + orow, Wo * 128);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int xo = x0 + dd_acc_row(r, lane);
-      float v = acc[r];
-      if (EPI == DD_EPI_BIAS) v += bv;
-      if (EPI == DD_EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
-      if (EPI == DD_EPI_RELU_MASK) v = (mreg[r] > 0.f) ? v : 0.f;
-      if (xo < Wo) yrow[(long)xo * 32 + n] = v;
-    }
-
-    // retire the prefetched rows into the slots of the rows no longer needed
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int iy = S * yy + 2 + s;
-      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, lane, pre[s]);
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (EPI == DD_EPI_BIAS) v += bv;
+        if (EPI == DD_EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
+        if (EPI == DD_EPI_RELU_MASK) v = (mreg[r] > 0.f) ? v : 0.f;
+        bstore1(ys, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4, v);
+      }
     }
   }
 }
@@ -197,8 +233,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
 template <int WPB, bool MASK>
 __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restrict__ dy, const float* __restrict__ wp,
                                                           const float* __restrict__ msk, float* __restrict__ dx,
-                                                          int B, int H, int W, int Ho, int Wo, int nstrips,
-                                                          int nbands, int RB) {
+                                                          int B, int H, int W, int Ho, int Wo, int nstrips) {
   using C = StripCfg<32, 1>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -210,47 +245,51 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
     for (int i = tid; i < C::WFLOATS / 4; i += WPB * 64) wl4[i] = wg4[i];
   }
   __syncthreads();
-  const int nr = (H + 1) / 2;   // output row pairs
-  const long total = (long)B * nbands * nstrips;
-  const long task = (long)blockIdx.x * WPB + wave;
-  if (task >= total) return;
-  const int strip = (int)(task % nstrips);
-  const int band = (int)((task / nstrips) % nbands);
-  const int b = (int)(task / ((long)nstrips * nbands));
-  const int s0 = strip * 32, r0 = band * RB;
-  const int r1 = min(r0 + RB, nr);
-  char* ring = smem + C::WFLOATS * 4 + wave * 3 * C::SLOTB;
+  const int nr = (H + 1) / 2;   // output row pairs per column
+  char* ring = smem + C::WFLOATS * 4 + wave * C::WAVEB;
+  char* spill = ring + 3 * C::SLOTB;
   const char* wl = smem;
   const int h = lane >> 5, n = lane & 31;
-  const float* dyb = dy + (long)b * Ho * Wo * 32;
+
+  long idx, end;
+  wave_range((long)B * nstrips * nr, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / nr;
+    const int r0 = (int)(idx - col * nr);
+    const int r1 = (int)min((long)nr, r0 + (end - idx));
+    idx += r1 - r0;
+    const int b = (int)(col / nstrips), s0 = (int)(col % nstrips) * 32;
+    const float* dyb = dy + (long)b * Ho * Wo * 32;
 
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    f32x4 t[C::NLOAD];
-    load_row<32, 1>(dyb, Ho, Wo, r0 + d, s0, lane, t);
-    store_row<32, 1, true>(ring + ((r0 + d) % 3) * C::SLOTB, lane, t);
-  }
+    for (int d = 0; d < 2; ++d) {
+      f32x4 t[C::NLOAD];
+      load_row<32, 1>(dyb, Ho, Wo, r0 + d, s0, lane, t);
+      store_row<32, 1, true>(ring + ((r0 + d) % 3) * C::SLOTB, spill, lane, t);
+    }
 
-  for (int r = r0; r < r1; ++r) {
-    f32x4 pre[C::NLOAD];
-    load_row<32, 1>(dyb, Ho, Wo, r + 2, s0, lane, pre);
+    for (int r = r0; r < r1; ++r) {
+      f32x4 pre[C::NLOAD];
+      load_row<32, 1>(dyb, Ho, Wo, r + 2, s0, lane, pre);
+      __builtin_amdgcn_sched_barrier(0);   // loads stay above the MFMA chains (see conv_strip_fwd)
 
-    const char* row_r = ring + (r % 3) * C::SLOTB;
-    const char* row_r1 = ring + ((r + 1) % 3) * C::SLOTB;
-    // One parity tile at a time: its ReLU-mask values are requested BEFORE its MFMA chain and consumed after,
-    // so the epilogue never waits on HBM; only one 32x32 accumulator is live.
-    // tap list per tile: (row offset 0/1, pixel offset 0/1, weight tap ky*3+kx)
+      const char* row_r = ring + (r % 3) * C::SLOTB;
+      const char* row_r1 = ring + ((r + 1) % 3) * C::SLOTB;
+      // One parity tile at a time: its ReLU-mask values are requested BEFORE its MFMA chain and consumed after,
+      // so the epilogue never waits on HBM; only one 32x32 accumulator is live.
+      // tap list per tile: (row offset 0/1, pixel offset 0/1, weight tap ky*3+kx)
 #define DD_TILE(PY, PX, NTAP, ...)                                                              \
   {                                                                                             \
     constexpr int taps[NTAP][3] = {__VA_ARGS__};                                                \
     const int yi = 2 * r + (PY);                                                                \
-    const int yic = min(yi, H - 1);                                                             \
+    const long orow = ((long)(b * H + min(yi, H - 1)) * W) * 32;                                \
+    const int obytes = (yi < H) ? W * 128 : 0;                                                  \
     float mreg[16];                                                                             \
     if (MASK) {                                                                                 \
-      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                       \
-        const int xi = min(2 * (s0 + dd_acc_row(rr, lane)) + (PX), W - 1);                      \
-        mreg[rr] = msk[((long)(b * H + yic) * W + xi) * 32 + n];                                \
-      }                                                                                         \
+      const __amdgpu_buffer_rsrc_t ms = rsrc(msk + orow, obytes);                               \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                         \
+        mreg[rr] = bload1(ms, ((2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 32 + n) * 4);         \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
     }                                                                                           \
     f32x16 acc;                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                \
@@ -268,23 +307,20 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
         acc = DD_MFMA(a.w, w.w, acc);                                                           \
       }                                                                                         \
     }                                                                                           \
-    if (yi < H) {                                                                               \
-      float* orow = dx + ((long)(b * H + yi) * W) * 32 + n;                                     \
-      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                       \
-        const int xi = 2 * (s0 + dd_acc_row(rr, lane)) + (PX);                                  \
-        float v = acc[rr];                                                                      \
-        if (MASK) v = (mreg[rr] > 0.f) ? v : 0.f;                                               \
-        if (xi < W) orow[(long)xi * 32] = v;                                                    \
-      }                                                                                         \
+    const __amdgpu_buffer_rsrc_t os = rsrc(dx + orow, obytes);                                  \
+    _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                         \
+      float v = acc[rr];                                                                        \
+      if (MASK) v = (mreg[rr] > 0.f) ? v : 0.f;                                                 \
+      bstore1(os, ((2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 32 + n) * 4, v);                  \
     }                                                                                           \
   }
-    DD_TILE(1, 1, 4, {1, 1, 0}, {1, 0, 2}, {0, 1, 6}, {0, 0, 8})   // (ky,kx) = (0,0) (0,2) (2,0) (2,2)
-    DD_TILE(0, 1, 2, {0, 1, 3}, {0, 0, 5})                         // (1,0) (1,2)
-    DD_TILE(1, 0, 2, {1, 0, 1}, {0, 0, 7})                         // (0,1) (2,1)
-    DD_TILE(0, 0, 1, {0, 0, 4})                                    // (1,1)
+      DD_TILE(1, 1, 4, {1, 1, 0}, {1, 0, 2}, {0, 1, 6}, {0, 0, 8})   // (ky,kx) = (0,0) (0,2) (2,0) (2,2)
+      store_row<32, 1, true>(ring + ((r + 2) % 3) * C::SLOTB, spill, lane, pre);   // slot (r+2)%3 is not read by this pair
+      DD_TILE(0, 1, 2, {0, 1, 3}, {0, 0, 5})                         // (1,0) (1,2)
+      DD_TILE(1, 0, 2, {1, 0, 1}, {0, 0, 7})                         // (0,1) (2,1)
+      DD_TILE(0, 0, 1, {0, 0, 4})                                    // (1,1)
 #undef DD_TILE
-
-    store_row<32, 1, true>(ring + ((r + 2) % 3) * C::SLOTB, lane, pre);
+    }
   }
 }
 
@@ -292,24 +328,22 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
 // weight / bias gradient.  GEMM view: M = 32 output channels, N = 32 input channels (one 32x32 tile per
 // tap, 9 register accumulators), K = pixels.  A = dy (straight from HBM, 256 contiguous bytes per
 // wave-load), B = x rows from the LDS ring (ds_read_b32, 32 consecutive dwords per half-wave).
-// Persistent waves accumulate over all their tasks and write ONE partial each.
+// Each wave accumulates over its whole range and writes ONE partial.
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int S, int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ part, float* __restrict__ bpart, int B,
-                                                       int H, int W, int Ho, int Wo, int nstrips, int nbands,
-                                                       int RB) {
+                                                       int H, int W, int Ho, int Wo, int nstrips) {
   using C = StripCfg<CIN, S>;
   constexpr int NT = (CIN == 32) ? 9 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* ring = smem + wave * 3 * C::SLOTB;
+  char* ring = smem + wave * C::WAVEB;
+  char* spill = ring + 3 * C::SLOTB;
   const int h = lane >> 5, n = lane & 31;
-  const long total = (long)B * nbands * nstrips;
   const int gw = blockIdx.x * WPB + wave;
-  const int nw = gridDim.x * WPB;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -322,29 +356,31 @@ __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__
   const int tap4 = min(n / 3, 8), c4 = n % 3;
   const int dy4 = tap4 / 3, dx4 = tap4 - 3 * dy4;
 
-  for (long task = gw; task < total; task += nw) {
-    const int strip = (int)(task % nstrips);
-    const int band = (int)((task / nstrips) % nbands);
-    const int b = (int)(task / ((long)nstrips * nbands));
-    const int x0 = strip * 32, y0 = band * RB;
-    const int y1 = min(y0 + RB, Ho);
+  long idx, end;
+  wave_range((long)B * nstrips * Ho, gw, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / Ho;
+    const int y0 = (int)(idx - col * Ho);
+    const int y1 = (int)min((long)Ho, y0 + (end - idx));
+    idx += y1 - y0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
     const float* xb = x + (long)b * H * W * CIN;
     const float* dyb = dy + (long)b * Ho * Wo * 32;
     const int gx0 = S * x0 - 1;
+    const int aoff = ((x0 + h) * 32 + n) * 4;   // + 256 bytes per pixel pair
 
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       f32x4 t[C::NLOAD];
       const int iy = S * y0 - 1 + d;
       load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
-      store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, lane, t);
+      store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
     }
     float areg[16];
+    {
+      const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)y0 * Wo * 32, Wo * 128);
 #pragma unroll
-    for (int pp = 0; pp < 16; ++pp) {
-      const int xo = x0 + 2 * pp + h;
-      const float v = dyb[((long)y0 * Wo + min(xo, Wo - 1)) * 32 + n];
-      areg[pp] = (xo < Wo) ? v : 0.f;
+      for (int pp = 0; pp < 16; ++pp) areg[pp] = bload1(as, aoff + pp * 256);
     }
 
     for (int yy = y0; yy < y1; ++yy) {
@@ -353,14 +389,12 @@ __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__
       for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
       float anext[16];
       {
-        const int yn = min(yy + 1, Ho - 1);
+        const bool ok = yy + 1 < Ho;
+        const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? yy + 1 : 0) * Wo * 32, ok ? Wo * 128 : 0);
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-          const int xo = x0 + 2 * pp + h;
-          const float v = dyb[((long)yn * Wo + min(xo, Wo - 1)) * 32 + n];
-          anext[pp] = (xo < Wo) ? v : 0.f;
-        }
+        for (int pp = 0; pp < 16; ++pp) anext[pp] = bload1(as, aoff + pp * 256);
       }
+      __builtin_amdgcn_sched_barrier(0);   // loads stay above the MFMA chains (see conv_strip_fwd)
 
       if (CIN == 32) {
         const char* rb0 = ring + ((S * yy + 0) % 3) * C::SLOTB;
@@ -391,7 +425,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const int iy = S * yy + 2 + s;
-        store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, lane, pre[s]);
+        store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
       }
 #pragma unroll
       for (int pp = 0; pp < 16; ++pp) areg[pp] = anext[pp];
@@ -497,13 +531,17 @@ int check_desc(const dd_conv_desc* d) {
   DD_REQUIRE((d->cin_real == 32 && d->cin_store == 32) || (d->cin_real == 3 && d->cin_store == 4), DD_ERR_UNSUPPORTED,
              "conv: Cin %d stored as %d (supported: 32/32, 3/4)", d->cin_real, d->cin_store);
   DD_REQUIRE(!(d->cin_real == 3 && d->stride == 2), DD_ERR_UNSUPPORTED, "conv: Cin 3 with stride 2");
-  DD_REQUIRE((long)d->height * d->width * 32 < (1L << 31), DD_ERR_UNSUPPORTED, "conv: image too large for 32-bit pixel offsets");
+  DD_REQUIRE((long)d->width * 128 < (1L << 31), DD_ERR_UNSUPPORTED, "conv: row too long for a 32-bit buffer descriptor");
   return 0;
 }
 
-int pick_rows(const dd_conv_desc* d, int rows) {
-  int rb = d->rows_per_task > 0 ? d->rows_per_task : 16;
-  return max(1, min(rb, rows));
+// Workgroups launched = workgroups resident: `per_cu` blocks on each CU (bounded by the LDS ring + registers
+// of the instantiation), fewer when the problem has fewer wave-sized pieces.  rows_per_task (a testing / tuning
+// knob, never changes results) asks for at least that many rows per wave, i.e. fewer and longer ranges.
+int resident_grid(const dd_conv_desc* d, long row_tiles, int wpb, int per_cu) {
+  long blocks = (long)DD_NUM_CU * per_cu;
+  if (d->rows_per_task > 0) blocks = min(blocks, max(1L, row_tiles / d->rows_per_task / wpb));
+  return (int)max(1L, min(blocks, (row_tiles + wpb - 1) / wpb));
 }
 
 template <int CIN, int S, int EPI, int WPB>
@@ -511,13 +549,14 @@ int launch_fwd(const float* x, const float* wp, const float* bias, const float* 
                hipStream_t st) {
   using C = StripCfg<CIN, S>;
   const int Ho = dd_conv_out(d->height, S), Wo = dd_conv_out(d->width, S);
-  const int nstrips = (Wo + 31) / 32, RB = pick_rows(d, Ho), nbands = (Ho + RB - 1) / RB;
-  const long total = (long)d->batch * nstrips * nbands;
-  const size_t lds = C::WFLOATS * 4 + (size_t)WPB * 3 * C::SLOTB;
+  const int nstrips = (Wo + 31) / 32;
+  const size_t lds = C::WFLOATS * 4 + (size_t)WPB * C::WAVEB;
+  const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)(160 * 1024) / lds));
+  const int grid = resident_grid(d, (long)d->batch * nstrips * Ho, WPB, per_cu);
   auto k = conv_strip_fwd<CIN, S, EPI, WPB>;
   if (int rc = allow_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)((total + WPB - 1) / WPB)), dim3(WPB * 64), lds, st, x, wp, bias, msk, y,
-                     d->batch, d->height, d->width, Ho, Wo, nstrips, nbands, RB);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, wp, bias, msk, y, d->batch, d->height, d->width, Ho, Wo,
+                     nstrips);
   DD_LAUNCH_CHECK("conv_strip_fwd");
   return 0;
 }
@@ -573,39 +612,36 @@ int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_
   hipStream_t st = (hipStream_t)stream;
   if (d->stride == 1) {
     // a stride-1 k3 p1 data gradient IS a k3 p1 convolution of dy with the flipped / transposed weights
-    dd_conv_desc t = *d;
-    return relu_src ? launch_fwd<32, 1, DD_EPI_RELU_MASK, 8>(dy, packed_dgrad, nullptr, relu_src, dx, &t, st)
-                    : launch_fwd<32, 1, DD_EPI_NONE, 8>(dy, packed_dgrad, nullptr, nullptr, dx, &t, st);
+    return relu_src ? launch_fwd<32, 1, DD_EPI_RELU_MASK, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st)
+                    : launch_fwd<32, 1, DD_EPI_NONE, 8>(dy, packed_dgrad, nullptr, nullptr, dx, d, st);
   }
   using C = StripCfg<32, 1>;
   constexpr int WPB = 8;
   const int H = d->height, W = d->width, Ho = dd_conv_out(H, 2), Wo = dd_conv_out(W, 2);
   const int ns = (W + 1) / 2, nr = (H + 1) / 2;
-  const int nstrips = (ns + 31) / 32, RB = pick_rows(d, nr), nbands = (nr + RB - 1) / RB;
-  const long total = (long)d->batch * nstrips * nbands;
-  const size_t lds = C::WFLOATS * 4 + (size_t)WPB * 3 * C::SLOTB;
-  const unsigned grid = (unsigned)((total + WPB - 1) / WPB);
+  const int nstrips = (ns + 31) / 32;
+  const size_t lds = C::WFLOATS * 4 + (size_t)WPB * C::WAVEB;
+  const int grid = resident_grid(d, (long)d->batch * nstrips * nr, WPB, 1);
   if (relu_src) {
     auto k = conv_s2_dgrad<WPB, true>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
-                       nstrips, nbands, RB);
+                       nstrips);
   } else {
     auto k = conv_s2_dgrad<WPB, false>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
-                       nstrips, nbands, RB);
+                       nstrips);
   }
   DD_LAUNCH_CHECK("conv_s2_dgrad");
   return 0;
 }
 
-static int wgrad_grid(const dd_conv_desc* d) { (void)d; return DD_NUM_CU; }  // 1 block of 4 waves per CU (register-limited to 1 wave/SIMD)
-
 int64_t dd_conv_wgrad_workspace_bytes(const dd_conv_desc* d) {
   if (check_desc(d)) return -1;
   const int nt = d->cin_real == 32 ? 9 : 1;
-  return (int64_t)wgrad_grid(d) * 4 * ((int64_t)nt * 1024 + 64) * 4;
+  const int64_t waves = 4 * (int64_t)DD_NUM_CU * 2;   // upper bound of resident waves of any instantiation
+  return waves * ((int64_t)nt * 1024 + 64) * 4;
 }
 
 int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
@@ -617,21 +653,19 @@ int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias,
   hipStream_t st = (hipStream_t)stream;
   constexpr int WPB = 4;
   const int S = d->stride, H = d->height, W = d->width, Ho = dd_conv_out(H, S), Wo = dd_conv_out(W, S);
-  const int nstrips = (Wo + 31) / 32, RB = pick_rows(d, Ho), nbands = (Ho + RB - 1) / RB;
-  const long total = (long)d->batch * nstrips * nbands;
-  int grid = wgrad_grid(d);
-  grid = (int)min((long)grid, (total + WPB - 1) / WPB);
-  const int nw = grid * WPB;
+  const int nstrips = (Wo + 31) / 32;
   const int nt = d->cin_real == 32 ? 9 : 1;
+  // Cin 32: 144 accumulator registers -> one wave per SIMD -> one 4-wave block per CU; Cin 3: two
+  const int grid = resident_grid(d, (long)d->batch * nstrips * Ho, WPB, d->cin_store == 4 ? 2 : 1);
+  const int nw = grid * WPB;
   float* part = (float*)workspace;
   float* bpart = part + (size_t)nw * nt * 1024;
 #define DD_WG(CIN, SS)                                                                                              \
   {                                                                                                                 \
     auto k = conv_wgrad<CIN, SS, WPB>;                                                                              \
-    const size_t lds = (size_t)WPB * 3 * StripCfg<CIN, SS>::SLOTB;                                                  \
+    const size_t lds = (size_t)WPB * StripCfg<CIN, SS>::WAVEB;                                                  \
     if (int rc = allow_lds(k, lds)) return rc;                                                                      \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, H, W, Ho, Wo, nstrips, \
-                       nbands, RB);                                                                                 \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, H, W, Ho, Wo, nstrips); \
   }
   if (d->cin_store == 4) DD_WG(4, 1)
   else if (S == 1) DD_WG(32, 1)

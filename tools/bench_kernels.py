@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--h", type=int, default=256)
     ap.add_argument("--w", type=int, default=1836)
+    ap.add_argument("--only", default="", help="comma-separated substrings of case names to run")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     b, h, w = a.batch, a.h, a.w
@@ -63,11 +64,17 @@ def main():
         ("c2_wgrad", lambda: ops.conv_wgrad(a1, g, d2), 2 * px * 32 * 288, px * 256),
         ("c3_wgrad", lambda: ops.conv_wgrad(a1, g3, d3), 2 * pxo * 32 * 288, px * 128 + pxo * 128),
     ]
+    only = [t for t in a.only.split(",") if t]
     for name, fn, flops, nbytes in cases:
+        if only and not any(t in name for t in only):
+            continue
         ms = timeit(fn, a.iters)
         res[name] = {"ms": round(ms, 4), "TF": round(flops / ms / 1e9, 2), "frac_mfma": round(flops / ms / 1e9 / PEAK_TF, 3),
                      "GBs": round(nbytes / ms / 1e6, 1)}
         print(name, res[name], flush=True)
+    if only:
+        print(json.dumps(res))
+        return
     feat = torch.relu(torch.randn(b, ho, wo, 32, device=dev))
     ms = timeit(lambda: ops.pool4_fwd(feat), a.iters)
     res["pool_fwd"] = {"ms": round(ms, 4), "GBs": round(feat.numel() * 5 / ms / 1e6, 1)}
