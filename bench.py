@@ -140,11 +140,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local)
+    # one process per GPU; DD_DIST_BACKEND=gloo + several ranks on ONE card is only a rehearsal of the N > 1
+    # control flow on a single-GPU box (the real backend is nccl = RCCL over xGMI)
+    backend = os.environ.get("DD_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run for N > 1"
 
     from driving_dirty_amd import _lib
@@ -187,7 +193,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.detach())

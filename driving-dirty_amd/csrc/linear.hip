@@ -264,6 +264,72 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   }
 }
 
+// Wide variant for long rows (encoder fc1: K = 940032): one wave = TN n-tiles x 128 consecutive k-columns.
+// Lane r loads 16 bytes = columns 4r..4r+3 of a batch row (512 contiguous bytes per half-wave), which makes
+// four B operands whose "column j" is the strided set {4j + c}; the matching four accumulators hold, per
+// lane, four CONSECUTIVE output columns, so dW leaves as 16-byte stores, 512 contiguous bytes per row.
+template <int TN>
+__global__ __launch_bounds__(256) void linear_wgrad_wide_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                float* __restrict__ dW, float* __restrict__ db, int M,
+                                                                int N, int K, int ngroups_k, long total) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long wt = (long)blockIdx.x * 4 + wave;
+  if (wt >= total) return;
+  const int h = lane >> 5, r = lane & 31;
+  const int kg = (int)(wt % ngroups_k);
+  const int nbase = (int)(wt / ngroups_k) * 32 * TN, kb = kg * 128;
+
+  f32x16 acc[TN][4];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+  float bsum[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) bsum[a] = 0.f;
+  const int kcol = kb + 4 * r;
+  const bool kok = kcol < K;
+
+  for (int m0 = 0; m0 < M; m0 += 32) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int m = m0 + 2 * s + h;
+      const bool mok = m < M;
+      const int mc = min(m, M - 1);
+      const f32x4 xv = *(const f32x4*)(X + (long)mc * K + min(kcol, K - 4));
+      const f32x4 bv = (mok && kok) ? xv : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        const int n = nbase + 32 * a + r;
+        const float v = dY[(long)mc * N + min(n, N - 1)];
+        const float av = (mok && n < N) ? v : 0.f;
+        bsum[a] += av;
+        acc[a][0] = DD_MFMA(av, bv.x, acc[a][0]);
+        acc[a][1] = DD_MFMA(av, bv.y, acc[a][1]);
+        acc[a][2] = DD_MFMA(av, bv.z, acc[a][2]);
+        acc[a][3] = DD_MFMA(av, bv.w, acc[a][3]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = nbase + 32 * a + dd_acc_row(i, lane);
+      if (n < N && kok) *(f32x4*)(dW + (long)n * K + kcol) = f32x4{acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
+    }
+    if (db && kg == 0) {
+      const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
+      const int n = nbase + 32 * a + r;
+      if (h == 0 && n < N) db[n] = tot;
+    }
+  }
+}
+
 int pick_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 0); }   // 64 KB of static LDS caps the batch tile at 64 rows
 
 int pick_split(int blocks_other, int ntiles) {
@@ -350,7 +416,12 @@ int dd_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, in
   DD_REQUIRE(m > 0 && n > 0 && k > 0, DD_ERR_BAD_ARG, "linear_wgrad: non-positive size");
   DD_REQUIRE(dy && x && dw, DD_ERR_BAD_ARG, "linear_wgrad: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (n <= 256 || k > n) {   // few output rows (encoder fc1: N = 128): one k-tile x up to 4 n-tiles per wave
+  if (k >= 512 && k % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dw % 16 == 0)) {   // long rows: 16-byte path
+    const int gk = (k + 127) / 128;
+    const long total = (long)((n + 63) / 64) * gk;
+    hipLaunchKernelGGL((linear_wgrad_wide_kernel<2>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, dy, x, dw,
+                       dbias, m, n, k, gk, total);
+  } else if (n <= 256 || k > n) {   // few output rows: one k-tile x up to 4 n-tiles per wave
     const int gk = (k + 31) / 32;
     const long total = (long)((n + 127) / 128) * gk;
     hipLaunchKernelGGL((linear_wgrad_kernel<4, 1>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, dy, x, dw, dbias,
