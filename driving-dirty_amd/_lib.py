@@ -19,7 +19,16 @@ class ConvDesc(C.Structure):
                                     "ksize", "stride", "pad", "rows_per_task")]
 
 
+class GConvDesc(C.Structure):
+    """struct dd_gconv_desc"""
+    _fields_ = [(n, _i32) for n in ("batch", "in_h", "in_w", "in_cstore", "in_coff", "cin", "out_h", "out_w",
+                                    "omem_h", "omem_w", "out_cstore", "out_coff", "cout", "kh", "kw", "stride_h",
+                                    "stride_w", "dil_h", "dil_w", "pad_h", "pad_w", "div_h", "div_w", "ostride_h",
+                                    "ostride_w", "ooff_h", "ooff_w")]
+
+
 _DP = C.POINTER(ConvDesc)
+_GP = C.POINTER(GConvDesc)
 
 # name -> (restype, argtypes); mirrors include/dd_hotpath.h one to one
 SIGNATURES = {
@@ -42,6 +51,17 @@ SIGNATURES = {
     "dd_loss_workspace_bytes": (_i64, [_i64]),
     "dd_bce_logits": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_mse": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
+    "dd_gconv_packed_floats": (_i64, [_GP]),
+    "dd_gconv_pack": (_i32, [_p, _p, _GP, _i64, _i64, _i64, _i32, _i32, _i32, _p]),
+    "dd_gconv_fwd": (_i32, [_p, _p, _p, _p, _p, _GP, _i32, _p]),
+    "dd_gconv_wgrad_workspace_bytes": (_i64, [_GP]),
+    "dd_gconv_wgrad": (_i32, [_p, _p, _p, _p, _GP, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "dd_deconv2x2_c1_workspace_bytes": (_i64, [_i32]),
+    "dd_deconv2x2_c1_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_deconv2x2_c1_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "dd_view_to_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_add": (_i32, [_p, _p, _p, _i64, _p]),
+    "dd_bce_probs": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_linear_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "dd_linear_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "dd_linear_dgrad": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),

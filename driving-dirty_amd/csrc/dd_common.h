@@ -32,3 +32,27 @@ int dd_fail(int code, const char* fmt, ...);
 static inline int dd_conv_out(int in, int stride) { return (in + 2 - 3) / stride + 1; }
 
 __device__ __forceinline__ int dd_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Raw buffer access: the descriptor (wave-uniform base + byte count) makes the hardware range-check every lane:
+// an out-of-range load returns zeros, an out-of-range store is dropped.  A negative offset is a huge unsigned
+// one, i.e. out of range.  Used for zero padding and ragged edges without branches, and as a guard against faults.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dd_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 dd_bload4(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float dd_bload1(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void dd_bstore1(__amdgpu_buffer_rsrc_t r, int off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
+// The contiguous range [idx, end) of `total` work items owned by piece `i` of `n` equal pieces.
+__device__ __forceinline__ void dd_range(long total, int i, int n, long& idx, long& end) {
+  const long per = (total + n - 1) / n;
+  idx = (long)i * per;
+  end = idx + per < total ? idx + per : total;
+  if (idx > end) idx = end;
+}

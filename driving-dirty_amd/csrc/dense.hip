@@ -126,6 +126,24 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// BCE on probabilities with torch's clamp of the logs at -100 (F.binary_cross_entropy, spatial_w_rm.py:131).
+__global__ __launch_bounds__(256) void bce_probs_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                        float* __restrict__ dp, double* __restrict__ partial, long n,
+                                                        float gscale) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float pv = p[i], tv = t[i];
+    const float lp = fmaxf(logf(pv), -100.f), lq = fmaxf(logf(1.f - pv), -100.f);
+    s -= tv * lp + (1.f - tv) * lq;
+    if (dp) {   // d/dp of the clamped logs: zero where the clamp is active (p < e^-100 never happens in fp32 except p = 0)
+      const float gp = (pv > 0.f) ? 1.f / pv : 0.f, gq = (pv < 1.f) ? 1.f / (1.f - pv) : 0.f;
+      dp[i] = (-(tv * gp) + (1.f - tv) * gq) * gscale;
+    }
+  }
+  const double tot = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ da, double* __restrict__ partial, long n,
                                                   float gscale) {
@@ -232,6 +250,19 @@ int dd_bce_logits(const float* logits, const float* target, float* loss_out, flo
   hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits, probs,
                      (double*)workspace, (long)n, grad_scale / (float)n);
   DD_LAUNCH_CHECK("bce_logits");
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
+                     1.0 / (double)n, loss_out);
+  DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_bce_probs(const float* probs, const float* target, float* loss_out, float* dprobs, int64_t n, float grad_scale,
+                 void* workspace, void* stream) {
+  DD_REQUIRE(probs && target && loss_out && workspace && n > 0, DD_ERR_BAD_ARG, "bce_probs: bad argument");
+  const int grid = (int)min((n + 255) / 256, (long)kLossBlocks);
+  hipLaunchKernelGGL(bce_probs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, probs, target, dprobs,
+                     (double*)workspace, (long)n, grad_scale / (float)n);
+  DD_LAUNCH_CHECK("bce_probs");
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
                      1.0 / (double)n, loss_out);
   DD_LAUNCH_CHECK("loss_final");

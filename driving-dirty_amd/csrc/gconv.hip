@@ -1,0 +1,585 @@
+// Generic NHWC convolution on the fp32 matrix cores: every Conv2d / ConvTranspose2d of the path that is not one
+// of the encoder's three k3 p1 layers (those have the LDS-ring kernels in conv3x3.hip).
+//
+//   decoder           ConvTranspose2d 64->32 k3 p1, 32->32 k3 p1, 32->32 k2 s2, 32->3 k1   components.py:70-73,89-92
+//   SpatialMappingCNN Conv2d 3->32 k(1,50)/(52,1) s(3,2), 32->32 k3                         spatial_bb/components.py:18-26
+//   *MergingCNN       Conv2d 32->32 k(1,24) s(1,7), 1->32 k7 s3 d3 p1, 32->32 k3 d3,
+//                     ConvTranspose2d k2 s2, and the dilated k7/k8 d7/d8/d3 up-convs          spatial_bb/components.py:88-93,129-139
+//
+// GEMM view: M = 32 output pixels along x (one wave), N = 32 or 64 output channels, K = taps x Cin walked in
+// 16-byte "chunks" (4 channels of one tap).  There is no input tile in LDS: dilated taps are up to 49 pixels
+// apart, so a halo tile would be mostly holes; instead the A operand is gathered straight from L1/L2 with one
+// buffer_load_dwordx4 per lane per 4 MFMAs (the fp32 MFMA needs 256 cycles for those four, the gather ~32), the
+// B operand is the packed weight image streamed from L2 with lane-linear 16-byte loads.  A per-workgroup LDS
+// table turns the chunk index into (row offset, column offset, channel) so the inner loop has no integer
+// division.  Loads run one 4-group set ahead of the MFMAs (register ping-pong).
+// Zero padding, ragged edges, divisibility holes of transposed gathers: out-of-range buffer offsets.
+#include "dd_common.h"
+
+namespace {
+
+constexpr int GU = 4;   // chunk-pair groups per pipeline set
+
+template <bool DIV>
+__device__ __forceinline__ int gather_offset(const dd_gconv_desc& d, int yo, int xo, int row_off, int col_off, int chan) {
+  int yn = yo * d.stride_h + row_off, xn = xo * d.stride_w + col_off;
+  bool ok = true;
+  if (DIV) {
+    ok = (yn >= 0) && (xn >= 0) && (yn % d.div_h == 0) && (xn % d.div_w == 0);
+    yn = yn / d.div_h;
+    xn = xn / d.div_w;
+  }
+  ok = ok && ((unsigned)yn < (unsigned)d.in_h) && ((unsigned)xn < (unsigned)d.in_w);
+  return ok ? ((yn * d.in_w + xn) * d.in_cstore + chan) * 4 : -16;
+}
+
+__device__ __forceinline__ int out_offset(const dd_gconv_desc& d, int yo, int xo, int chan) {
+  const bool ok = (xo < d.out_w) && (chan < d.cout);
+  return ok ? (((yo * d.ostride_h + d.ooff_h) * d.omem_w + xo * d.ostride_w + d.ooff_w) * d.out_cstore + d.out_coff + chan) * 4
+            : -16;
+}
+
+template <int NT, bool DIV>
+__global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, const float* __restrict__ msk,
+                                                        float* __restrict__ y, const dd_gconv_desc d, int ngroups,
+                                                        int epi) {
+  extern __shared__ __attribute__((aligned(16))) int2 tab[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C4 = d.cin >> 2, nchunks = d.kh * d.kw * C4;
+  for (int q = tid; q < 2 * ngroups; q += blockDim.x) {
+    int2 e;
+    if (q < nchunks) {
+      const int tap = q / C4, c4 = q - tap * C4;
+      const int ky = tap / d.kw, kx = tap - ky * d.kw;
+      e.x = ky * d.dil_h - d.pad_h;
+      e.y = ((kx * d.dil_w - d.pad_w) << 10) | (d.in_coff + c4 * 4);
+    } else {   // padding chunk: its packed weights are zero, its coordinate is out of range
+      e.x = 1 << 24;
+      e.y = 0;
+    }
+    tab[q] = e;
+  }
+  __syncthreads();
+  const int h = lane >> 5, n = lane & 31;
+  const int nstrips = (d.out_w + 31) / 32;
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU || epi == DD_EPI_BIAS_SIGMOID) && nt * 32 + n < d.cout)
+                 ? bias[nt * 32 + n] : 0.f;
+
+  long idx, end;
+  dd_range((long)d.batch * nstrips * d.out_h, blockIdx.x * (blockDim.x >> 6) + wave, gridDim.x * (blockDim.x >> 6), idx, end);
+  for (; idx < end; ++idx) {
+    const long col = idx / d.out_h;
+    const int yo = (int)(idx - col * d.out_h);
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    const int xo = x0 + n;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    f32x4 A0[GU], A1[GU], B0[GU][NT], B1[GU][NT];
+#define DD_LOAD_SET(G0, A, Bw)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                                   \
+    const int2 e = tab[2 * ((G0) + u) + h];                                                          \
+    A[u] = dd_bload4(xs, gather_offset<DIV>(d, yo, xo, e.x, e.y >> 10, e.y & 1023));                 \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                \
+      Bw[u][nt] = *(const f32x4*)(wp + ((long)(((G0) + u) * NT + nt) * 64 + lane) * 4);              \
+  }
+#define DD_COMPUTE_SET(A, Bw)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < GU; ++u) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
+    acc[nt] = DD_MFMA(A[u].x, Bw[u][nt].x, acc[nt]);                                                 \
+    acc[nt] = DD_MFMA(A[u].y, Bw[u][nt].y, acc[nt]);                                                 \
+    acc[nt] = DD_MFMA(A[u].z, Bw[u][nt].z, acc[nt]);                                                 \
+    acc[nt] = DD_MFMA(A[u].w, Bw[u][nt].w, acc[nt]);                                                 \
+  }
+    DD_LOAD_SET(0, A0, B0)
+    for (int g = 0; g < ngroups; g += 2 * GU) {   // ngroups is a multiple of GU
+      const bool more1 = g + GU < ngroups, more2 = g + 2 * GU < ngroups;
+      if (more1) { DD_LOAD_SET(g + GU, A1, B1) }
+      __builtin_amdgcn_sched_barrier(0);          // set k+1 is requested before set k is multiplied
+      DD_COMPUTE_SET(A0, B0)
+      if (more2) { DD_LOAD_SET(g + 2 * GU, A0, B0) }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) { DD_COMPUTE_SET(A1, B1) }
+    }
+#undef DD_LOAD_SET
+#undef DD_COMPUTE_SET
+
+    const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+    const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int off = out_offset(d, yo, x0 + dd_acc_row(r, lane), nt * 32 + n);
+        float v = acc[nt][r] + bv[nt];
+        if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (epi == DD_EPI_BIAS_SIGMOID) v = 1.f / (1.f + expf(-v));
+        if (epi == DD_EPI_RELU_MASK) v = (dd_bload1(ms, off) > 0.f) ? v : 0.f;
+        dd_bstore1(ys, off, v);
+      }
+    }
+  }
+}
+
+// packed[((g*NT + nt)*64 + lane)*4 + i] = W(n = nt*32 + lane&31, c = 4*(chunk % C4) + i, tap = chunk / C4),
+// chunk = 2g + (lane>>5).
+__global__ void gconv_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int ngroups, int nt_count, int C4,
+                                  int T, long w_off, long sn, long sc, int flip, int n_real, int c_real) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)ngroups * nt_count * 256;
+  if (idx >= total) return;
+  const int i = idx & 3, lane = (idx >> 2) & 63;
+  const long gn = idx >> 8;
+  const int nt = (int)(gn % nt_count), g = (int)(gn / nt_count);
+  const int q = 2 * g + (lane >> 5);
+  const int tap = q / C4, c = 4 * (q - tap * C4) + i, n = nt * 32 + (lane & 31);
+  float v = 0.f;
+  if (tap < T && n < n_real && c < c_real) v = w[w_off + n * sn + c * sc + (flip ? T - 1 - tap : tap)];
+  p[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// One wave = one 32-channel slice of dy (A operand) x NB column tiles of the (tap, cin) space (B operand), over a
+// contiguous range of output row tiles; waves of a workgroup share the range so dy comes out of L1.
+template <int NB>
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ part, float* __restrict__ bpart,
+                                                          const dd_gconv_desc d, int njg, int nto, int nranges) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  const int njobs = nto * njg;
+  const int job = gw % njobs, range = gw / njobs;
+  if (range >= nranges) return;
+  const int ot = job / njg, jg = job - ot * njg;
+  const int h = lane >> 5, n = lane & 31;
+  const int J = d.kh * d.kw * d.cin;
+
+  int rowoff[NB], coloff[NB], chan[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int j = (jg * NB + k) * 32 + n;
+    if (j < J) {
+      const int tap = j / d.cin, c = j - tap * d.cin;
+      const int ky = tap / d.kw, kx = tap - ky * d.kw;
+      rowoff[k] = ky * d.dil_h - d.pad_h;
+      coloff[k] = kx * d.dil_w - d.pad_w;
+      chan[k] = d.in_coff + c;
+    } else {
+      rowoff[k] = 1 << 24;
+      coloff[k] = 0;
+      chan[k] = 0;
+    }
+  }
+  f32x16 acc[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  float bsum = 0.f;
+
+  const int nstrips = (d.out_w + 31) / 32;
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+  long idx, end;
+  dd_range((long)d.batch * nstrips * d.out_h, range, nranges, idx, end);
+  for (; idx < end; ++idx) {
+    const long col = idx / d.out_h;
+    const int yo = (int)(idx - col * d.out_h);
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    const __amdgpu_buffer_rsrc_t gs = dd_rsrc(dy + (long)b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {   // 8 pixel pairs at a time: 8 x (1 + NB) loads in flight, then 8 x NB MFMAs
+      float av[8], bw[8][NB];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int xo = x0 + 2 * (half * 8 + s) + h;
+        av[s] = dd_bload1(gs, out_offset(d, yo, xo, ot * 32 + n));
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+          bw[s][k] = dd_bload1(xs, gather_offset<false>(d, yo, xo, rowoff[k], coloff[k], chan[k]));   // av = 0 beyond out_w
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bsum += av[s];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = DD_MFMA(av[s], bw[s][k], acc[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[((((long)range * njobs + job) * NB + k) * 16 + r) * 64 + lane] = acc[k][r];
+  if (jg == 0) bpart[((long)range * nto + ot) * 64 + lane] = bsum;
+}
+
+// dw[w_off + o*sn + c*sc + tap'] (+)= sum over ranges; one thread per accumulator element.
+__global__ __launch_bounds__(256) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
+                                                          int nranges, int njobs, int nb, int njg, int T, int cin,
+                                                          long w_off, long sn, long sc, int flip, int n_real, int c_real,
+                                                          int accumulate) {
+  const long per = (long)njobs * nb * 1024;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per) return;
+  float s0 = 0.f, s1 = 0.f;
+  int r = 0;
+  for (; r + 2 <= nranges; r += 2) {
+    s0 += part[(long)r * per + e];
+    s1 += part[(long)(r + 1) * per + e];
+  }
+  if (r < nranges) s0 += part[(long)r * per + e];
+  const float s = s0 + s1;
+  const int lane = e & 63, reg = (e >> 6) & 15;
+  const long jk = e >> 10;
+  const int k = (int)(jk % nb), job = (int)(jk / nb);
+  const int ot = job / njg, jg = job - ot * njg;
+  const int o = ot * 32 + dd_acc_row(reg, lane);
+  const int j = (jg * nb + k) * 32 + (lane & 31);
+  if (j >= T * cin) return;
+  const int tap = j / cin, c = j - tap * cin;
+  if (o >= n_real || c >= c_real) return;
+  const long wi = w_off + o * sn + c * sc + (flip ? T - 1 - tap : tap);
+  dw[wi] = accumulate ? dw[wi] + s : s;
+}
+
+__global__ __launch_bounds__(64) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
+                                                        int nranges, int nto, int n_real, int accumulate) {
+  const int ot = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int r = 0; r < nranges; ++r) s += bpart[((long)r * nto + ot) * 64 + lane];
+  s += __shfl_xor(s, 32);
+  const int o = ot * 32 + lane;
+  if (lane < 32 && o < n_real) db[o] = accumulate ? db[o] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------- small helpers
+__global__ __launch_bounds__(256) void view_to_nhwc4_kernel(const float* __restrict__ views, f32x4* __restrict__ out, int B,
+                                                            int H, int W, int view, int tf) {
+  const int Ho = (tf == 1 || tf == 2) ? W : H, Wo = (tf == 1 || tf == 2) ? H : W;
+  const long total = (long)B * Ho * Wo, plane = (long)H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(p % Wo), i = (int)((p / Wo) % Ho);
+    const int b = (int)(p / ((long)Wo * Ho));
+    int ys, xs;
+    if (tf == 0) { ys = i; xs = j; }
+    else if (tf == 1) { ys = j; xs = W - 1 - i; }         // rot90(k=1, dims [2,3]): out[i][j] = in[j][W-1-i]
+    else if (tf == 2) { ys = H - 1 - j; xs = i; }         // rot90(k=1, dims [3,2]): out[i][j] = in[H-1-j][i]
+    else { ys = H - 1 - i; xs = W - 1 - j; }              // flip([2,3])
+    const float* src = views + (((long)b * 6 + view) * 3) * plane + (long)ys * W + xs;
+    out[p] = f32x4{src[0], src[plane], src[2 * plane], 0.f};
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                                  f32x4* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
+// ---- last layer of the box heads: ConvTranspose2d(C -> 1, k2 s2) + sigmoid (spatial_bb/components.py:93,139,117,168).
+// One output channel cannot feed a 32-wide MFMA column; it is 4*C MACs per input pixel: a VALU kernel, HBM-bound.
+template <int C>
+__global__ __launch_bounds__(256) void deconv2x2_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               long npix, int w) {
+  float wr[C][4];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) wr[c][ph] = wt[c * 4 + ph];
+  const float b0 = bias[0];
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    float z[4] = {b0, b0, b0, b0};
+#pragma unroll
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const f32x4 v = *(const f32x4*)(x + p * C + c4 * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) z[ph] += v[i] * wr[c4 * 4 + i][ph];
+    }
+    const long row = p / w, col = p - row * w;          // row runs over B*h
+    float* o = out + (2 * row) * (2L * w) + 2 * col;
+    o[0] = 1.f / (1.f + expf(-z[0]));
+    o[1] = 1.f / (1.f + expf(-z[1]));
+    o[2L * w] = 1.f / (1.f + expf(-z[2]));
+    o[2L * w + 1] = 1.f / (1.f + expf(-z[3]));
+  }
+}
+
+// dz = dprob * p * (1-p);  dx[c] = (x[c] > 0) * sum_ph dz[ph] * Wt[c][ph];  per-block partials of dWt, dbias.
+template <int C>
+__global__ __launch_bounds__(256) void deconv2x2_c1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                               const float* __restrict__ probs,
+                                                               const float* __restrict__ dprobs, float* __restrict__ dx,
+                                                               float* __restrict__ partial, long npix, int w) {
+  __shared__ float red[4][C * 4 + 1];
+  float wr[C][4];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) wr[c][ph] = wt[c * 4 + ph];
+  float gw[C][4], gb = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) gw[c][ph] = 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const long row = p / w, col = p - row * w;
+    const long o = (2 * row) * (2L * w) + 2 * col;
+    const long oo[4] = {o, o + 1, o + 2L * w, o + 2L * w + 1};
+    float dz[4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const float pr = probs[oo[ph]];
+      dz[ph] = dprobs[oo[ph]] * pr * (1.f - pr);
+      gb += dz[ph];
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const f32x4 v = *(const f32x4*)(x + p * C + c4 * 4);
+      f32x4 g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c4 * 4 + i;
+        float s = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          s += dz[ph] * wr[c][ph];
+          gw[c][ph] += v[i] * dz[ph];
+        }
+        g[i] = v[i] > 0.f ? s : 0.f;
+      }
+      *(f32x4*)(dx + p * C + c4 * 4) = g;
+    }
+  }
+  // block reduction of the C*4 + 1 sums: wave shuffle, then the 4 waves in a fixed order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      float v = gw[c][ph];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if (lane == 0) red[wave][c * 4 + ph] = v;
+    }
+  {
+    float v = gb;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) red[wave][C * 4] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x <= C * 4)
+    partial[(long)blockIdx.x * (C * 4 + 1) + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void deconv2x2_c1_reduce(const float* __restrict__ partial, float* __restrict__ dwt,
+                                                          float* __restrict__ db, int nblocks, int nvals) {
+  const int i = threadIdx.x;
+  if (i >= nvals) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * nvals + i];
+  if (i < nvals - 1) dwt[i] = s; else db[0] = s;
+}
+
+int check_gdesc(const dd_gconv_desc* d) {
+  DD_REQUIRE(d != nullptr, DD_ERR_BAD_ARG, "gconv: NULL descriptor");
+  DD_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->out_h > 0 && d->out_w > 0 && d->omem_h > 0 && d->omem_w > 0,
+             DD_ERR_BAD_ARG, "gconv: non-positive size");
+  DD_REQUIRE(d->cin > 0 && d->cin % 4 == 0 && d->in_coff % 4 == 0 && d->in_cstore % 4 == 0 && d->in_coff + d->cin <= d->in_cstore,
+             DD_ERR_UNSUPPORTED, "gconv: input channel slice [%d,+%d) of %d must be 4-aligned", d->in_coff, d->cin, d->in_cstore);
+  DD_REQUIRE(d->in_cstore < 1024, DD_ERR_UNSUPPORTED, "gconv: more than 1020 stored input channels");
+  DD_REQUIRE(d->cout > 0 && d->cout <= 64 && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_cstore, DD_ERR_UNSUPPORTED,
+             "gconv: output channel slice [%d,+%d) of %d (Cout <= 64)", d->out_coff, d->cout, d->out_cstore);
+  DD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->div_h > 0 &&
+                 d->div_w > 0 && d->ostride_h > 0 && d->ostride_w > 0 && d->ooff_h >= 0 && d->ooff_w >= 0,
+             DD_ERR_BAD_ARG, "gconv: bad kernel geometry");
+  DD_REQUIRE((long)d->kw * d->dil_w + d->pad_w < (1 << 20), DD_ERR_UNSUPPORTED, "gconv: tap offset too large");
+  DD_REQUIRE((d->out_h - 1) * d->ostride_h + d->ooff_h < d->omem_h && (d->out_w - 1) * d->ostride_w + d->ooff_w < d->omem_w,
+             DD_ERR_BAD_ARG, "gconv: output lattice leaves the output buffer");
+  DD_REQUIRE((long)d->in_h * d->in_w * d->in_cstore * 4 < (1L << 31) && (long)d->omem_h * d->omem_w * d->out_cstore * 4 < (1L << 31),
+             DD_ERR_UNSUPPORTED, "gconv: one image exceeds 2 GB");
+  return 0;
+}
+
+int groups_of(const dd_gconv_desc* d) {
+  const int nchunks = d->kh * d->kw * (d->cin / 4);
+  const int g = (nchunks + 1) / 2;
+  return (g + GU - 1) / GU * GU;
+}
+
+int pick_nb(int nj) {
+  int best = 1, cost = nj;
+  for (int nb = 2; nb <= 4; ++nb) {
+    const int c = (nj + nb - 1) / nb * nb;
+    if (c <= cost) { cost = c; best = nb; }
+  }
+  return best;
+}
+
+struct WgradPlan { int nto, nj, nb, njg, njobs, nranges, blocks; };
+
+WgradPlan wgrad_plan(const dd_gconv_desc* d) {
+  WgradPlan p;
+  p.nto = (d->cout + 31) / 32;
+  p.nj = (d->kh * d->kw * d->cin + 31) / 32;
+  p.nb = pick_nb(p.nj);
+  p.njg = (p.nj + p.nb - 1) / p.nb;
+  p.njobs = p.nto * p.njg;
+  const long tiles = (long)d->batch * ((d->out_w + 31) / 32) * d->out_h;
+  const long waves = 2L * DD_NUM_CU * 4;   // two 4-wave workgroups per CU
+  p.nranges = (int)max(1L, min(tiles, waves / p.njobs));
+  p.blocks = (p.nranges * p.njobs + 3) / 4;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dd_gconv_packed_floats(const dd_gconv_desc* d) {
+  if (check_gdesc(d)) return -1;
+  return (int64_t)groups_of(d) * ((d->cout + 31) / 32) * 256;
+}
+
+int dd_gconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc, int32_t flip,
+                  int32_t n_real, int32_t c_real, void* stream) {
+  if (int rc = check_gdesc(d)) return rc;
+  DD_REQUIRE(w && packed, DD_ERR_BAD_ARG, "gconv_pack: NULL pointer");
+  DD_REQUIRE(n_real > 0 && n_real <= d->cout && c_real > 0 && c_real <= d->cin, DD_ERR_BAD_ARG, "gconv_pack: n_real/c_real");
+  const int ng = groups_of(d), nt = (d->cout + 31) / 32;
+  const long total = (long)ng * nt * 256;
+  hipLaunchKernelGGL(gconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, ng,
+                     nt, d->cin / 4, d->kh * d->kw, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real);
+  DD_LAUNCH_CHECK("gconv_pack");
+  return 0;
+}
+
+int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                 int32_t epilogue, void* stream) {
+  if (int rc = check_gdesc(d)) return rc;
+  DD_REQUIRE(x && packed && y, DD_ERR_BAD_ARG, "gconv_fwd: NULL pointer");
+  DD_REQUIRE(epilogue >= DD_EPI_NONE && epilogue <= DD_EPI_BIAS_SIGMOID, DD_ERR_BAD_ARG, "gconv_fwd: epilogue %d", epilogue);
+  DD_REQUIRE(epilogue != DD_EPI_RELU_MASK || mask, DD_ERR_BAD_ARG, "gconv_fwd: RELU_MASK needs a mask");
+  DD_REQUIRE(!(epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU || epilogue == DD_EPI_BIAS_SIGMOID) || bias, DD_ERR_BAD_ARG,
+             "gconv_fwd: bias epilogue needs a bias");
+  hipStream_t st = (hipStream_t)stream;
+  const int ng = groups_of(d), nt = (d->cout + 31) / 32;
+  const bool div = d->div_h > 1 || d->div_w > 1;
+  const long tiles = (long)d->batch * ((d->out_w + 31) / 32) * d->out_h;
+  const int grid = (int)max(1L, min((long)DD_NUM_CU, (tiles + 7) / 8));   // one 8-wave workgroup per CU, all resident
+  const size_t lds = (size_t)2 * ng * sizeof(int2);
+  DD_REQUIRE(lds <= 64 * 1024, DD_ERR_UNSUPPORTED, "gconv_fwd: tap table of %zu bytes", lds);
+#define DD_GF(NT, DIV) hipLaunchKernelGGL((gconv_fwd_kernel<NT, DIV>), dim3(grid), dim3(512), lds, st, x, packed, bias, mask, y, *d, ng, epilogue)
+  if (nt == 1) { if (div) DD_GF(1, true); else DD_GF(1, false); }
+  else { if (div) DD_GF(2, true); else DD_GF(2, false); }
+#undef DD_GF
+  DD_LAUNCH_CHECK("gconv_fwd");
+  return 0;
+}
+
+int64_t dd_gconv_wgrad_workspace_bytes(const dd_gconv_desc* d) {
+  if (check_gdesc(d)) return -1;
+  const WgradPlan p = wgrad_plan(d);
+  return ((int64_t)p.nranges * p.njobs * p.nb * 1024 + (int64_t)p.nranges * p.nto * 64) * 4;
+}
+
+int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dd_gconv_desc* d, int64_t w_off, int64_t sn,
+                   int64_t sc, int32_t flip, int32_t n_real, int32_t c_real, int32_t accumulate, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  if (int rc = check_gdesc(d)) return rc;
+  DD_REQUIRE(x && dy && dw && workspace, DD_ERR_BAD_ARG, "gconv_wgrad: NULL pointer");
+  DD_REQUIRE(d->div_h == 1 && d->div_w == 1, DD_ERR_UNSUPPORTED, "gconv_wgrad: divisibility mode has no weight gradient");
+  DD_REQUIRE(workspace_bytes >= dd_gconv_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "gconv_wgrad: workspace too small");
+  DD_REQUIRE(n_real > 0 && n_real <= d->cout && c_real > 0 && c_real <= d->cin, DD_ERR_BAD_ARG, "gconv_wgrad: n_real/c_real");
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = wgrad_plan(d);
+  float* part = (float*)workspace;
+  float* bpart = part + (size_t)p.nranges * p.njobs * p.nb * 1024;
+#define DD_GW(NB) hipLaunchKernelGGL((gconv_wgrad_kernel<NB>), dim3(p.blocks), dim3(256), 0, st, x, dy, part, bpart, *d, p.njg, p.nto, p.nranges)
+  switch (p.nb) {
+    case 1: DD_GW(1); break;
+    case 2: DD_GW(2); break;
+    case 3: DD_GW(3); break;
+    default: DD_GW(4); break;
+  }
+#undef DD_GW
+  DD_LAUNCH_CHECK("gconv_wgrad");
+  const long per = (long)p.njobs * p.nb * 1024;
+  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, dw, p.nranges, p.njobs, p.nb,
+                     p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
+  DD_LAUNCH_CHECK("gconv_wgrad_reduce");
+  if (dbias) {
+    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(64), 0, st, bpart, dbias, p.nranges, p.nto, n_real, accumulate & 2);
+    DD_LAUNCH_CHECK("gconv_bias_reduce");
+  }
+  return 0;
+}
+
+int64_t dd_deconv2x2_c1_workspace_bytes(int32_t c) { return (int64_t)DD_NUM_CU * 4 * (c * 4 + 1) * 4; }
+
+int dd_deconv2x2_c1_fwd(const float* x, const float* wt, const float* bias, float* probs, int32_t batch, int32_t h, int32_t w,
+                        int32_t c, void* stream) {
+  DD_REQUIRE(x && wt && bias && probs && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "deconv2x2_c1_fwd: bad argument");
+  DD_REQUIRE(c == 8, DD_ERR_UNSUPPORTED, "deconv2x2_c1: Cin %d (the box heads end in 8 -> 1)", c);
+  const long npix = (long)batch * h * w;
+  hipLaunchKernelGGL(deconv2x2_c1_fwd_kernel<8>, dim3((unsigned)min((npix + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
+                     (hipStream_t)stream, x, wt, bias, probs, npix, w);
+  DD_LAUNCH_CHECK("deconv2x2_c1_fwd");
+  return 0;
+}
+
+int dd_deconv2x2_c1_bwd(const float* x, const float* wt, const float* probs, const float* dprobs, float* dx, float* dwt,
+                        float* dbias, int32_t batch, int32_t h, int32_t w, int32_t c, void* workspace, void* stream) {
+  DD_REQUIRE(x && wt && probs && dprobs && dx && dwt && dbias && workspace && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG,
+             "deconv2x2_c1_bwd: bad argument");
+  DD_REQUIRE(c == 8, DD_ERR_UNSUPPORTED, "deconv2x2_c1: Cin %d (the box heads end in 8 -> 1)", c);
+  const long npix = (long)batch * h * w;
+  const int grid = (int)min((npix + 255) / 256, (long)DD_NUM_CU * 4);
+  hipLaunchKernelGGL(deconv2x2_c1_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, wt, probs, dprobs, dx,
+                     (float*)workspace, npix, w);
+  DD_LAUNCH_CHECK("deconv2x2_c1_bwd");
+  hipLaunchKernelGGL(deconv2x2_c1_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, dwt, dbias, grid,
+                     c * 4 + 1);
+  DD_LAUNCH_CHECK("deconv2x2_c1_reduce");
+  return 0;
+}
+
+int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t height, int32_t width, int32_t view,
+                     int32_t transform, void* stream) {
+  DD_REQUIRE(views && out && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "view_to_nhwc4: bad argument");
+  DD_REQUIRE(view >= 0 && view < 6 && transform >= 0 && transform <= 3, DD_ERR_BAD_ARG, "view_to_nhwc4: view %d transform %d", view, transform);
+  const long total = (long)batch * height * width;
+  hipLaunchKernelGGL(view_to_nhwc4_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
+                     (hipStream_t)stream, views, (f32x4*)out, batch, height, width, view, transform);
+  DD_LAUNCH_CHECK("view_to_nhwc4");
+  return 0;
+}
+
+int dd_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  DD_REQUIRE(a && b && out && n > 0 && n % 4 == 0, DD_ERR_BAD_ARG, "add: bad argument");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)a, (const f32x4*)b, (f32x4*)out, n4);
+  DD_LAUNCH_CHECK("add");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+"""Host-side planning for the generic NHWC convolution kernels (``dd_gconv_*``, csrc/gconv.hip).
+
+A ``Layer`` describes one ``nn.Conv2d`` / ``nn.ConvTranspose2d`` of the reference in its own terms (kernel,
+stride, dilation, padding, output_padding) and knows how to express its forward, its data gradient and its
+weight gradient as launches of the ONE implicit-GEMM kernel family:
+
+  Conv2d                      forward: plain;            dgrad: flipped taps, pad' = d(k-1)-p, div = stride
+  ConvTranspose2d stride 1    forward: flipped taps, pad' = d(k-1)-p (+output_padding rows/cols);  dgrad: plain conv
+  ConvTranspose2d k = s = 2   forward: 4 launches of a 1x1 conv, one per output phase;  dgrad: k2 s2 conv
+Buffers are NHWC; a layer may read a channel slice of its input buffer and write a channel slice / a
+sub-rectangle of its output buffer (mosaic tiling and channel concat without copies).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import GConvDesc, check
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK, EPI_BIAS_SIGMOID = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.HotpathError(f"{name}: expected a contiguous fp32 device tensor")
+    return t
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+@dataclass
+class View:
+    """A rectangular, channel-sliced window of an NHWC buffer [B, mem_h, mem_w, cstore]."""
+    buf: torch.Tensor
+    coff: int = 0
+    chans: int = None
+    off_h: int = 0
+    off_w: int = 0
+    h: int = None
+    w: int = None
+
+    def __post_init__(self):
+        b, mh, mw, cs = self.buf.shape
+        self.chans = cs - self.coff if self.chans is None else self.chans
+        self.h = mh - self.off_h if self.h is None else self.h
+        self.w = mw - self.off_w if self.w is None else self.w
+        if self.off_h or self.off_w:
+            assert self.coff % 1 == 0
+
+
+def _desc(batch, src, dst, cin, cout, k, stride=(1, 1), dil=(1, 1), pad=(0, 0), div=(1, 1), out_hw=None,
+          ostride=(1, 1), ooff=(0, 0)):
+    """src/dst: View.  src window offsets are folded into the padding (a shifted origin)."""
+    _, imh, imw, ics = src.buf.shape
+    _, omh, omw, ocs = dst.buf.shape
+    assert src.off_h == 0 and src.off_w == 0, "input windows are not needed by this path"
+    oh, ow = out_hw if out_hw is not None else (dst.h, dst.w)
+    return GConvDesc(batch, imh, imw, ics, src.coff, cin, oh, ow, omh, omw, ocs, dst.coff, cout, k[0], k[1],
+                     stride[0], stride[1], dil[0], dil[1], pad[0], pad[1], div[0], div[1], ostride[0], ostride[1],
+                     dst.off_h + ooff[0], dst.off_w + ooff[1])
+
+
+def _pack(w, d, w_off, sn, sc, flip, n_real, c_real):
+    n = _lib.lib().dd_gconv_packed_floats(C.byref(d))
+    if n <= 0:
+        raise _lib.HotpathError(f"gconv: {_lib.lib().dd_last_error().decode()}")
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().dd_gconv_pack(_p(w), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_gconv_pack")
+    return packed
+
+
+def _fwd(x, packed, bias, mask, y, d, epi):
+    check(_lib.lib().dd_gconv_fwd(_p(x), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_gconv_fwd")
+
+
+def _wgrad(x, dy, dw, db, d, w_off, sn, sc, flip, n_real, c_real, accumulate):
+    nbytes = _lib.lib().dd_gconv_wgrad_workspace_bytes(C.byref(d))
+    if nbytes <= 0:
+        raise _lib.HotpathError(f"gconv_wgrad: {_lib.lib().dd_last_error().decode()}")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().dd_gconv_wgrad(_p(x), _p(dy), _p(dw), _p(db), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real,
+                                    int(accumulate), _p(ws), nbytes, _stream()), "dd_gconv_wgrad")
+
+
+class Layer:
+    """One Conv2d (``transposed=False``, weight OIHW) or ConvTranspose2d (``transposed=True``, weight IOHW)."""
+
+    def __init__(self, cin, cout, k, stride=1, dil=1, pad=0, transposed=False, output_padding=0):
+        self.cin, self.cout = cin, cout
+        self.k, self.stride, self.dil, self.pad = _pair(k), _pair(stride), _pair(dil), _pair(pad)
+        self.opad = _pair(output_padding)
+        self.transposed = transposed
+        self.T = self.k[0] * self.k[1]
+        self.cin_store = (cin + 3) // 4 * 4
+        self.k2s2 = transposed and self.k == (2, 2) and self.stride == (2, 2)
+        if transposed and not self.k2s2 and self.stride != (1, 1):
+            raise _lib.HotpathError("ConvTranspose2d: only stride 1 (dilated) and k2 s2 are built")
+
+    # ---- shapes
+    def out_hw(self, h, w):
+        k, s, d, p = self.k, self.stride, self.dil, self.pad
+        if self.transposed:
+            return tuple((n - 1) * s[i] - 2 * p[i] + d[i] * (k[i] - 1) + self.opad[i] + 1 for i, n in enumerate((h, w)))
+        return tuple((n + 2 * p[i] - d[i] * (k[i] - 1) - 1) // s[i] + 1 for i, n in enumerate((h, w)))
+
+    def _flip_pad(self):
+        return tuple(self.dil[i] * (self.k[i] - 1) - self.pad[i] for i in range(2))
+
+    # ---- forward: writes dst (View) from src (View)
+    def forward(self, weight, bias, src, dst, epilogue, mask=None):
+        b = src.buf.shape[0]
+        cs = src.chans if src.chans % 4 == 0 else self.cin_store
+        _chk(weight, "weight")
+        if not self.transposed:
+            d = _desc(b, src, dst, cs, self.cout, self.k, self.stride, self.dil, self.pad)
+            pk = _pack(weight, d, 0, self.cin * self.T, self.T, False, self.cout, self.cin)
+            _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
+        elif self.k2s2:
+            ih, iw = src.buf.shape[1:3]
+            for ph in range(4):
+                d = _desc(b, src, dst, cs, self.cout, (1, 1), out_hw=(ih, iw), ostride=(2, 2), ooff=(ph // 2, ph % 2))
+                pk = _pack(weight, d, ph, 4, self.cout * 4, False, self.cout, self.cin)
+                _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
+        else:
+            d = _desc(b, src, dst, cs, self.cout, self.k, (1, 1), self.dil, self._flip_pad())
+            pk = _pack(weight, d, 0, self.T, self.cout * self.T, True, self.cout, self.cin)
+            _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
+
+    # ---- data gradient: dsrc (View with the input's geometry, >= 4-aligned channels) from ddst (View of dy)
+    def backward_data(self, weight, ddst, dsrc, relu_src=None):
+        """dsrc.buf[..., dsrc.coff : +cin] = dL/dx (x masked by ``relu_src > 0`` when given)."""
+        b = ddst.buf.shape[0]
+        epi = EPI_RELU_MASK if relu_src is not None else EPI_NONE
+        cin_out = self.cin
+        for n0 in range(0, cin_out, 64):                    # the kernel writes at most 64 channels per launch
+            nn = min(64, cin_out - n0)
+            out = View(dsrc.buf, dsrc.coff + n0, nn, dsrc.off_h, dsrc.off_w, dsrc.h, dsrc.w)
+            msk = relu_src
+            if not self.transposed:
+                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, self.k, (1, 1),
+                          self.dil, self._flip_pad(), div=self.stride)
+                pk = _pack(weight, d, n0 * self.T, self.T, self.cin * self.T, True, nn, self.cout)
+            elif self.k2s2:
+                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, (2, 2), (2, 2))
+                pk = _pack(weight, d, n0 * self.cout * 4, self.cout * 4, 4, False, nn, self.cout)
+            else:
+                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, self.k, (1, 1),
+                          self.dil, self.pad)
+                pk = _pack(weight, d, n0 * self.cout * self.T, self.cout * self.T, self.T, False, nn, self.cout)
+            _fwd(ddst.buf, pk, None, msk, out.buf, d, epi)
+
+    # ---- weight (+bias) gradient
+    def backward_weight(self, src, ddst, want_bias=True):
+        b = src.buf.shape[0]
+        dev = src.buf.device
+        cs = src.chans if src.chans % 4 == 0 else self.cin_store
+        if self.transposed:
+            dw = torch.empty((self.cin, self.cout) + self.k, device=dev, dtype=torch.float32)
+        else:
+            dw = torch.empty((self.cout, self.cin) + self.k, device=dev, dtype=torch.float32)
+        db = torch.empty(self.cout, device=dev, dtype=torch.float32) if want_bias else None
+        if not self.transposed:
+            d = _desc(b, src, ddst, cs, self.cout, self.k, self.stride, self.dil, self.pad)
+            _wgrad(src.buf, ddst.buf, dw, db, d, 0, self.cin * self.T, self.T, False, self.cout, self.cin, 0)
+        elif self.k2s2:
+            ih, iw = src.buf.shape[1:3]
+            for ph in range(4):
+                d = _desc(b, src, ddst, cs, self.cout, (1, 1), out_hw=(ih, iw), ostride=(2, 2), ooff=(ph // 2, ph % 2))
+                _wgrad(src.buf, ddst.buf, dw, db, d, ph, 4, self.cout * 4, False, self.cout, self.cin, 2 if ph > 0 else 0)
+        else:
+            d = _desc(b, src, ddst, cs, self.cout, self.k, (1, 1), self.dil, self._flip_pad())
+            _wgrad(src.buf, ddst.buf, dw, db, d, 0, self.T, self.cout * self.T, True, self.cout, self.cin, 0)
+        return dw, db
+
+
+def view_to_nhwc4(views, view, transform):
+    """views [B,6,3,H,W] -> one view as NHWC4 with SpatialMappingCNN's rot90/flip applied (see dd_view_to_nhwc4)."""
+    b, _, _, h, w = views.shape
+    oh, ow = (w, h) if transform in (1, 2) else (h, w)
+    out = torch.empty((b, oh, ow, 4), device=views.device, dtype=torch.float32)
+    check(_lib.lib().dd_view_to_nhwc4(_p(_chk(views, "views")), _p(out), b, h, w, view, transform, _stream()), "dd_view_to_nhwc4")
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    check(_lib.lib().dd_add(_p(_chk(a, "a")), _p(_chk(b, "b")), _p(out), a.numel(), _stream()), "dd_add")
+    return out

@@ -137,6 +137,70 @@ int dd_bce_logits(const float* logits, const float* target, float* loss_out, flo
 int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n, float grad_scale,
            void* workspace, void* stream);
 
+/* ---- generic NHWC convolution (K1/K2/K3/K5 of SURVEY 2.3: every other Conv2d / ConvTranspose2d of the path) ---
+ * One implicit-GEMM kernel family for the decoder (components.py:70-73,89-92) and the spatial bounding-box
+ * heads (spatial_bb/components.py:18-26,129-139): any kernel size, stride, dilation and padding, Cin a multiple
+ * of 4 channels taken from a channel slice of the input buffer, Cout <= 64 written into a channel slice and a
+ * strided / offset pixel lattice of the output buffer.  The same forward kernel also runs
+ *   - ConvTranspose2d stride 1 (dilated): a convolution with flipped taps and pad = dil*(k-1) - pad;
+ *   - ConvTranspose2d k2 s2: four 1x1 convolutions, one per output phase (ostride 2, ooff = phase);
+ *   - the data gradient of a stride-1 conv (flipped taps, channels swapped) and of a strided conv
+ *     (div_h/div_w = stride: a tap contributes only where the coordinate divides);
+ *   - rot90 / flip / mosaic tiling / channel concat of SpatialMappingCNN and *MergingCNN (components.py:43-73,159):
+ *     the views are re-laid once by dd_view_to_nhwc4 and every conv writes straight into its tile / channel slice.
+ * Input coordinate of output pixel (yo, xo) and tap (ky, kx):  num = yo*stride + k*dil - pad; with div > 1 the tap
+ * is skipped unless num % div == 0, and the coordinate is num / div.  Out-of-image coordinates read zeros. */
+enum { DD_EPI_BIAS_SIGMOID = 4 };
+
+typedef struct dd_gconv_desc {
+  int32_t batch;
+  int32_t in_h, in_w, in_cstore, in_coff, cin;          /* input buffer [B,in_h,in_w,in_cstore]; channels [in_coff, in_coff+cin) */
+  int32_t out_h, out_w;                                 /* output pixels computed per image */
+  int32_t omem_h, omem_w, out_cstore, out_coff, cout;   /* output buffer [B,omem_h,omem_w,out_cstore]; channels [out_coff, out_coff+cout) */
+  int32_t kh, kw, stride_h, stride_w, dil_h, dil_w, pad_h, pad_w;
+  int32_t div_h, div_w;                                 /* 1 = ordinary convolution */
+  int32_t ostride_h, ostride_w, ooff_h, ooff_w;         /* output pixel (yo,xo) lands at (yo*ostride_h+ooff_h, xo*ostride_w+ooff_w) */
+} dd_gconv_desc;
+
+/* Weight image for the kernels: element (n, c, tap) is read from w[w_off + n*sn + c*sc + (flip ? T-1-tap : tap)];
+ * n < n_real output channels, c < c_real input channels (zero beyond).  (sn, sc) express OIHW, IOHW, and the
+ * transposed views needed by data gradients without copying the parameter. */
+int64_t dd_gconv_packed_floats(const dd_gconv_desc* d);
+int dd_gconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc,
+                  int32_t flip, int32_t n_real, int32_t c_real, void* stream);
+/* y = epilogue(conv(x)); `mask` (DD_EPI_RELU_MASK only) has the output buffer's geometry. */
+int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y,
+                 const dd_gconv_desc* d, int32_t epilogue, void* stream);
+/* Weight gradient of y = conv(x): dw[w_off + n*sn + c*sc + (flip ? T-1-tap : tap)] = sum over pixels of
+ * dy[..., n] * x[tap-shifted ..., c]  (dy has the OUTPUT buffer geometry of `d`);  dbias[n] = sum dy (may be NULL).
+ * accumulate: bit 0 adds into dw, bit 1 adds into dbias instead of overwriting (the four phases of a k2 s2
+ * transposed conv write disjoint weights but share one bias). */
+int64_t dd_gconv_wgrad_workspace_bytes(const dd_gconv_desc* d);
+int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dd_gconv_desc* d, int64_t w_off,
+                   int64_t sn, int64_t sc, int32_t flip, int32_t n_real, int32_t c_real, int32_t accumulate,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Last layer of the box heads, ConvTranspose2d(8 -> 1, k2 s2) + sigmoid (spatial_bb/components.py:139,168):
+ * x [B,h,w,8] NHWC, wt [8,1,2,2] (IOHW), probs [B,2h,2w].  The backward takes dL/dprobs, applies the sigmoid's
+ * derivative, returns dx already masked by (x > 0) (x is a ReLU output), dwt and dbias (deterministic). */
+int64_t dd_deconv2x2_c1_workspace_bytes(int32_t c);
+int dd_deconv2x2_c1_fwd(const float* x, const float* wt, const float* bias, float* probs, int32_t batch, int32_t h, int32_t w,
+                        int32_t c, void* stream);
+int dd_deconv2x2_c1_bwd(const float* x, const float* wt, const float* probs, const float* dprobs, float* dx, float* dwt,
+                        float* dbias, int32_t batch, int32_t h, int32_t w, int32_t c, void* workspace, void* stream);
+
+/* One camera view of views[B,6,3,H,W] -> NHWC4 [B,H',W',4] with the geometric transform SpatialMappingCNN applies
+ * before its strip convs (spatial_bb/components.py:43-65): 0 = none, 1 = rot90(k=1, dims [2,3]) (view 4, "b"),
+ * 2 = rot90(k=1, dims [3,2]) (view 1, "f"), 3 = flip([2,3]) (views 5 and 2).  Rotations swap H and W. */
+int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t height, int32_t width, int32_t view,
+                     int32_t transform, void* stream);
+/* out[i] = a[i] + b[i] (gradient fan-in of the shared views / feature), n % 4 == 0. */
+int dd_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* Mean binary cross-entropy on PROBABILITIES (spatial_w_rm.py:131 F.binary_cross_entropy; log clamped at -100 like
+ * torch) with optional dprobs = (-(t/p) + (1-t)/(1-p)) * grad_scale / n. */
+int dd_bce_probs(const float* probs, const float* target, float* loss_out, float* dprobs, int64_t n, float grad_scale,
+                 void* workspace, void* stream);
+
 /* ---- skinny GEMMs of the dense head (K7): nn.Linear with the weight kept as [out=N, in=K] ------------
  * Replace F.linear / its autograd for DenseBlock.fc1 (components.py:105), Encoder.fc_z_out (components.py:51)
  * and the roadmap head (roadmap_bce_v2.py:75).  M = batch rows (<= 64), N and K multiples of 4.

@@ -1,0 +1,133 @@
+"""GPU parity of the generic convolution kernels (dd_gconv_*) for every Conv2d / ConvTranspose2d configuration of
+the decoder and the spatial box heads, at small spatial sizes, against fp64 torch (the oracle's arithmetic)."""
+import pytest
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from driving_dirty_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from driving_dirty_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def hu(shape, name, lo=-1.0, hi=1.0):
+    return synth.hash_uniform(shape, synth.key_salt(name), lo, hi)
+
+
+def to_nhwc(t, cstore):
+    b, c, h, w = t.shape
+    out = torch.zeros(b, h, w, cstore)
+    out[..., :c] = t.permute(0, 2, 3, 1)
+    return out
+
+
+# (name, module factory, input [B,C,H,W])
+CASES = [
+    ("strip_1x50", lambda: nn.Conv2d(3, 32, (1, 50), stride=(3, 2)), (2, 3, 16, 120)),
+    ("strip_52x1", lambda: nn.Conv2d(3, 32, (52, 1), stride=(3, 2), padding=1), (2, 3, 120, 16)),
+    ("out_conv_k3", lambda: nn.Conv2d(32, 32, 3), (1, 32, 12, 40)),
+    ("ss_conv_1x24_s7", lambda: nn.Conv2d(32, 32, (1, 24), stride=(1, 7)), (2, 32, 5, 100)),
+    ("rm_conv_1_k7s3d3", lambda: nn.Conv2d(1, 32, 7, stride=3, dilation=3, padding=1), (1, 1, 60, 64)),
+    ("rm_conv_2_k3d3", lambda: nn.Conv2d(32, 32, 3, dilation=3), (1, 32, 20, 45)),
+    ("up1_96_64_k7d7", lambda: nn.ConvTranspose2d(96, 64, 7, dilation=7), (1, 96, 9, 20)),
+    ("up2_64_32_k7d7", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (1, 64, 6, 37)),
+    ("up3_32_16_k7d7", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (2, 32, 5, 9)),
+    ("up4_16_8_k7d3", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (1, 16, 11, 35)),
+    ("dc1_64_32_k3p1", lambda: nn.ConvTranspose2d(64, 32, 3, padding=1), (2, 64, 8, 11)),
+    ("dc2_32_32_k3p1", lambda: nn.ConvTranspose2d(32, 32, 3, padding=1), (2, 32, 8, 37)),
+    ("dc3_k2s2", lambda: nn.ConvTranspose2d(32, 32, 2, stride=2), (2, 32, 8, 11)),
+    ("dc4_32_3_k1", lambda: nn.ConvTranspose2d(32, 3, 1), (2, 32, 16, 22)),
+    ("bm_up1_64_32_k8d8", lambda: nn.ConvTranspose2d(64, 32, 8, dilation=8), (1, 64, 5, 7)),
+    ("bm_up3_k6d6_op2", lambda: nn.ConvTranspose2d(16, 8, 6, dilation=6, output_padding=2), (1, 16, 7, 9)),
+]
+
+
+@pytest.mark.parametrize("name,make,shape", CASES, ids=[c[0] for c in CASES])
+def test_layer_fwd_dgrad_wgrad(dev, name, make, shape):
+    from driving_dirty_amd import gconv
+    torch.manual_seed(0)
+    mod = synth.fill_module(make(), seed=21).double()
+    x = hu(shape, "gx" + name, 0.0, 1.0).double().requires_grad_(True)
+    y_ref = F.relu(mod(x))
+    gy = hu(tuple(y_ref.shape), "gg" + name).double()
+    gy_m = gy * (y_ref > 0)
+    y_ref.backward(gy)
+
+    tr = isinstance(mod, nn.ConvTranspose2d)
+    layer = gconv.Layer(mod.in_channels, mod.out_channels, mod.kernel_size, mod.stride, mod.dilation, mod.padding,
+                        transposed=tr, output_padding=mod.output_padding if tr else 0)
+    b, cin, h, w = shape
+    oh, ow = layer.out_hw(h, w)
+    assert (oh, ow) == tuple(y_ref.shape[2:])
+    cis, cos = (cin + 3) // 4 * 4, (mod.out_channels + 3) // 4 * 4
+    xb = to_nhwc(x.detach().float(), cis).to(dev)
+    wd, bd = mod.weight.detach().float().to(dev), mod.bias.detach().float().to(dev)
+    yb = torch.zeros(b, oh, ow, cos, device=dev)
+    layer.forward(wd, bd, gconv.View(xb, 0, cis), gconv.View(yb, 0, mod.out_channels), gconv.EPI_BIAS_RELU)
+    assert rel_err(yb[..., :mod.out_channels].permute(0, 3, 1, 2), y_ref) < TOL
+
+    gb = to_nhwc(gy_m.float(), cos).to(dev)
+    dw, db = layer.backward_weight(gconv.View(xb, 0, cis), gconv.View(gb, 0, mod.out_channels))
+    assert rel_err(dw, mod.weight.grad) < TOL
+    assert rel_err(db, mod.bias.grad) < TOL
+
+    dxb = torch.zeros(b, h, w, cis, device=dev)
+    layer.backward_data(wd, gconv.View(gb, 0, cos), gconv.View(dxb, 0, cin))
+    assert rel_err(dxb[..., :cin].permute(0, 3, 1, 2), x.grad) < TOL
+    # fused ReLU mask of the producer of x
+    xm = (x.detach() - 0.5).float()
+    mb = to_nhwc(xm, cis).to(dev)
+    dxm = torch.zeros(b, h, w, cis, device=dev)
+    layer.backward_data(wd, gconv.View(gb, 0, cos), gconv.View(dxm, 0, cin), relu_src=mb)
+    assert rel_err(dxm[..., :cin].permute(0, 3, 1, 2), x.grad * (xm > 0)) < TOL
+
+
+def test_channel_slices_and_mosaic(dev):
+    """A conv reading a channel slice and writing a sub-rectangle + channel slice of a bigger buffer (the tiling /
+    concat of spatial_bb/components.py:70-73,159 done by addressing instead of torch.cat)."""
+    from driving_dirty_amd import gconv
+    mod = synth.fill_module(nn.Conv2d(32, 32, 3, padding=1), seed=5).double()
+    x = hu((2, 32, 6, 33), "slx").double()
+    ref = F.relu(mod(x))
+    big_in = torch.full((2, 6, 33, 96), 7.0)
+    big_in[..., 32:64] = x.permute(0, 2, 3, 1).float()
+    big_out = torch.full((2, 20, 70, 64), -3.0, device=dev)
+    layer = gconv.Layer(32, 32, 3, pad=1)
+    layer.forward(mod.weight.float().to(dev), mod.bias.float().to(dev), gconv.View(big_in.to(dev), 32, 32),
+                  gconv.View(big_out, 16, 32, off_h=5, off_w=30, h=6, w=33), gconv.EPI_BIAS_RELU)
+    assert rel_err(big_out[:, 5:11, 30:63, 16:48].permute(0, 3, 1, 2), ref) < TOL
+    untouched = big_out.clone()
+    untouched[:, 5:11, 30:63, 16:48] = -3.0
+    assert float((untouched + 3.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("view,tf", [(3, 0), (4, 1), (1, 2), (5, 3)])
+def test_view_transform(dev, view, tf):
+    from driving_dirty_amd import gconv
+    v = hu((2, 6, 3, 10, 14), "vt", 0.0, 1.0)
+    ref = v[:, view]
+    if tf == 1:
+        ref = torch.rot90(ref, 1, [2, 3])
+    elif tf == 2:
+        ref = torch.rot90(ref, 1, [3, 2])
+    elif tf == 3:
+        ref = torch.flip(ref, [2, 3])
+    out = gconv.view_to_nhwc4(v.to(dev), view, tf)
+    assert torch.equal(out[..., :3].permute(0, 3, 1, 2).cpu(), ref)
+    assert float(out[..., 3].abs().max()) == 0.0
