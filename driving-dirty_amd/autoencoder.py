@@ -1,9 +1,5 @@
-"""``BasicAE``: the masked-view autoencoder LightningModule (reference src/autoencoder/autoencoder.py).
-
-Round-1 scope: the encoder half runs on the HIP hot path; the decoder (SURVEY.md section 8f row 1:
-DenseBlock 128 -> 1,253,376 and the ConvTranspose2d stack) is not built yet, so ``forward`` /
-``training_step`` of the AE pre-training task raise ``NotImplementedError`` instead of falling back to
-another backend.  ``six_to_one_task`` and the encoder are complete and used by the roadmap model.
+"""``BasicAE``: the masked-view autoencoder LightningModule (reference src/autoencoder/autoencoder.py) on the HIP
+hot path: 6-view gather + blanking, encoder, decoder and the MSE loss all run behind the C ABI.
 """
 from argparse import ArgumentParser
 
@@ -11,7 +7,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .components import Encoder
+from .components import Decoder, Encoder
 from .lightning import LightningModule, hparam
 
 
@@ -29,7 +25,11 @@ class BasicAE(LightningModule):
         self.hparams = hparams
         self.encoder = self.init_encoder(self.hidden_dim, self.latent_dim, self.in_channels, self.input_height,
                                          self.input_width)
-        self.decoder = None     # next row of SURVEY.md section 8(f)
+        self.decoder = self.init_decoder(self.hidden_dim, self.latent_dim, self.in_channels, self.output_height,
+                                         self.output_width)
+
+    def init_decoder(self, hidden_dim, latent_dim, in_channels, output_height, output_width):
+        return Decoder(hidden_dim, latent_dim, in_channels, output_height, output_width)
 
     def init_encoder(self, hidden_dim, latent_dim, in_channels, input_height, input_width):
         return Encoder(hidden_dim, latent_dim, in_channels, input_height, input_width)
@@ -48,11 +48,36 @@ class BasicAE(LightningModule):
         assert y.size(-1) == x.size(-1)
         return wide, y
 
-    def forward(self, z):
-        raise NotImplementedError("BasicAE.forward = decoder(z): the decoder is not built yet (SURVEY.md 8f row 1)")
+    def forward(self, z, keeps=(None, None)):
+        return self.decoder(z, keeps)                                   # autoencoder.py:75-76
+
+    def _run_step(self, batch, batch_idx, step_name, keeps=None):
+        """autoencoder.py:78-93: mask one view, encode, decode, ``mse_loss(y, y_hat)``."""
+        keeps = keeps or {}
+        target_img_index = int(np.random.randint(0, 5))
+        wide4, _, y = ops.stitch6(batch.contiguous(), mask_slot=target_img_index, want_target=True)
+        z = self.encoder.forward_nhwc4(wide4, keeps.get("enc", (None, None)))
+        y_hat = self(z, keeps.get("dec", (None, None)))
+        if self.logger is not None and batch_idx % self.hparams.output_img_freq == 0:
+            self._log_images(y, y_hat, step_name)
+        return ops.MseLoss.apply(y_hat, y)
+
+    def _log_images(self, y, y_hat, step_name, limit=1):
+        exp = self.logger.experiment
+        step = self.trainer.global_step if self.trainer is not None else 0
+        exp.add_image(f"{step_name}_predicted_images", y_hat[:limit][0], step)
+        exp.add_image(f"{step_name}_target_images", y[:limit][0], step)
 
     def training_step(self, batch, batch_idx):
-        raise NotImplementedError("AE pre-training needs the decoder (SURVEY.md 8f row 1)")
+        train_loss = self._run_step(batch, batch_idx, step_name="train")
+        return {"loss": train_loss, "log": {"train_loss": train_loss}}
+
+    def validation_step(self, batch, batch_idx):
+        return {"val_loss": self._run_step(batch, batch_idx, step_name="valid")}
+
+    def validation_epoch_end(self, outputs):
+        avg_val_loss = torch.stack([x["val_loss"] for x in outputs]).mean()
+        return {"val_loss": avg_val_loss, "log": {"avg_val_loss": avg_val_loss}}
 
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate)     # autoencoder.py:119-120

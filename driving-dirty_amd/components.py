@@ -51,6 +51,37 @@ class DenseBlock(nn.Module):
                                     training, bn.eps, momentum, scale)
 
 
+class Decoder(nn.Module):
+    """latent -> image: 2 DenseBlocks, view [B,64,h,w], 4 ConvTranspose2d (reference components.py:55-93)."""
+
+    def __init__(self, hidden_dim, latent_dim, in_channels, output_height, output_width):
+        super().__init__()
+        if in_channels != 3:
+            raise ValueError("the MI355X decoder is built for 3-channel images")
+        # RNG parity with the reference's sizing dry run (components.py:75-83): one rand + four throw-away convs
+        torch.rand(1, in_channels, output_height, output_width)
+        nn.Conv2d(in_channels, 32, 1)
+        nn.Conv2d(32, 32, 2, stride=2)
+        nn.Conv2d(32, 32, 3, padding=1)
+        nn.Conv2d(32, 64, 3, padding=1)
+        self.deconv_dim_h = (output_height - 2) // 2 + 1
+        self.deconv_dim_w = (output_width - 2) // 2 + 1
+        self.latent_dim = latent_dim
+        self.fc1 = DenseBlock(latent_dim, hidden_dim)
+        self.fc2 = DenseBlock(hidden_dim, self.deconv_dim_h * self.deconv_dim_w * 64)
+        self.dc1 = nn.ConvTranspose2d(64, 32, kernel_size=3, padding=1)
+        self.dc2 = nn.ConvTranspose2d(32, 32, kernel_size=3, padding=1)
+        self.dc3 = nn.ConvTranspose2d(32, 32, kernel_size=2, stride=2)
+        self.dc4 = nn.ConvTranspose2d(32, in_channels, kernel_size=1, stride=1)
+
+    def forward(self, z, keeps=(None, None)):
+        from .heads import DecoderConvStack
+        _require_gpu(z, "Decoder")
+        h = self.fc2(self.fc1(z, keeps[0]), keeps[1])
+        return DecoderConvStack.apply(h, self.deconv_dim_h, self.deconv_dim_w, self.dc1.weight, self.dc1.bias, self.dc2.weight,
+                                      self.dc2.bias, self.dc3.weight, self.dc3.bias, self.dc4.weight, self.dc4.bias)
+
+
 class Encoder(nn.Module):
     def __init__(self, hidden_dim, latent_dim, in_channels, input_height, input_width):
         super().__init__()

@@ -1,0 +1,254 @@
+"""Autograd nodes for the decoder conv stack and the spatial bounding-box heads, built on the generic NHWC
+convolution kernels (gconv.py).  Each node runs a whole reference module as one hand-ordered chain, so every
+ReLU backward is fused into a neighbouring kernel's epilogue, tiling / concat are done by addressing, and all
+intermediates stay NHWC.
+
+  DecoderConvStack   reference Decoder.forward conv part          src/autoencoder/components.py:88-92
+  SpatialMapFn       reference SpatialMappingCNN.forward          spatial_bb/components.py:28-77
+  MergeFn            reference RoadMapBoxesMergingCNN / BoxesMergingCNN.forward   spatial_bb/components.py:141-170, 95-119
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .gconv import EPI_BIAS, EPI_BIAS_RELU, Layer, View, _p, _stream, add, view_to_nhwc4
+
+
+def as_nhwc(t, cstore):
+    """NCHW-shaped tensor -> NHWC buffer [B,H,W,cstore]; free when ``t`` already is a channels-last view."""
+    b, c, h, w = t.shape
+    v = t.permute(0, 2, 3, 1)
+    if c == cstore and v.is_contiguous():
+        return v
+    return ops.nchw_to_nhwc(t.contiguous(), cstore)
+
+
+def _zeros(shape, dev):
+    return torch.zeros(shape, device=dev, dtype=torch.float32)
+
+
+def _empty(shape, dev):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ decoder
+class DecoderConvStack(torch.autograd.Function):
+    """[B, 64*dh*dw] (NCHW-flat, as fc2 emits it) -> [B,3,2dh,2dw]:  dc1 k3 p1 +ReLU, dc2 k3 p1 +ReLU, dc3 k2 s2 +ReLU, dc4 k1."""
+
+    L1 = Layer(64, 32, 3, pad=1, transposed=True)
+    L2 = Layer(32, 32, 3, pad=1, transposed=True)
+    L3 = Layer(32, 32, 2, stride=2, transposed=True)
+    L4 = Layer(32, 3, 1, transposed=True)
+
+    @staticmethod
+    def forward(ctx, h, dh, dw, w1, b1, w2, b2, w3, b3, w4, b4):
+        cls = DecoderConvStack
+        b, dev = h.shape[0], h.device
+        x0 = ops.nchw_to_nhwc(h.contiguous().view(b, 64, dh, dw), 64)
+        a1, a2 = _empty((b, dh, dw, 32), dev), _empty((b, dh, dw, 32), dev)
+        a3, y4 = _empty((b, 2 * dh, 2 * dw, 32), dev), _zeros((b, 2 * dh, 2 * dw, 4), dev)
+        cls.L1.forward(w1, b1, View(x0), View(a1), EPI_BIAS_RELU)
+        cls.L2.forward(w2, b2, View(a1), View(a2), EPI_BIAS_RELU)
+        cls.L3.forward(w3, b3, View(a2), View(a3), EPI_BIAS_RELU)
+        cls.L4.forward(w4, b4, View(a3), View(y4, 0, 3), EPI_BIAS)
+        ctx.save_for_backward(x0, a1, a2, a3, w1, w2, w3, w4)
+        ctx.dims = (dh, dw)
+        return ops.nhwc_to_nchw(y4, 3)
+
+    @staticmethod
+    def backward(ctx, gy):
+        cls = DecoderConvStack
+        x0, a1, a2, a3, w1, w2, w3, w4 = ctx.saved_tensors
+        b, dev = x0.shape[0], x0.device
+        g4 = ops.nchw_to_nhwc(gy.contiguous(), 4)
+        dw4, db4 = cls.L4.backward_weight(View(a3), View(g4, 0, 3))
+        g3 = _empty(a3.shape, dev)
+        cls.L4.backward_data(w4, View(g4), View(g3), relu_src=a3)
+        dw3, db3 = cls.L3.backward_weight(View(a2), View(g3))
+        g2 = _empty(a2.shape, dev)
+        cls.L3.backward_data(w3, View(g3), View(g2), relu_src=a2)
+        dw2, db2 = cls.L2.backward_weight(View(a1), View(g2))
+        g1 = _empty(a1.shape, dev)
+        cls.L2.backward_data(w2, View(g2), View(g1), relu_src=a1)
+        dw1, db1 = cls.L1.backward_weight(View(x0), View(g1))
+        gh = None
+        if ctx.needs_input_grad[0]:
+            g0 = _empty(x0.shape, dev)
+            cls.L1.backward_data(w1, View(g1), View(g0))
+            gh = ops.nhwc_to_nchw(g0, 64).view(b, -1)
+        return gh, None, None, dw1, db1, dw2, db2, dw3, db3, dw4, db4
+
+
+# ------------------------------------------------------------------------------------------------ spatial map
+# (attribute, view index, transform, tile row, tile col): mosaic  BL FL / B F / BR FR  (components.py:9-13,70-73)
+_TILES = (("bl_conv", 3, 0, 0, 0), ("fl_conv", 0, 0, 0, 1), ("b_conv", 4, 1, 1, 0), ("f_conv", 1, 2, 1, 1),
+          ("br_conv", 5, 3, 2, 0), ("fr_conv", 2, 3, 2, 1))
+_ORDER = ("f_conv", "fl_conv", "fr_conv", "b_conv", "bl_conv", "br_conv", "out_conv")   # parameter order of the module
+
+
+class SpatialMapFn(torch.autograd.Function):
+    """views [B,6,3,H,W] -> spatial map [B,256,256,32] (NHWC).  The six strip convs write their tile of the
+    258x258 mosaic directly; rot90 / flip happen in the one pass that lays a view out as NHWC4."""
+
+    SIDE = Layer(3, 32, (1, 50), stride=(3, 2))
+    FRONT = Layer(3, 32, (52, 1), stride=(3, 2), pad=1)
+    OUT = Layer(32, 32, 3)
+
+    @staticmethod
+    def _strip(name):
+        return SpatialMapFn.FRONT if name in ("f_conv", "b_conv") else SpatialMapFn.SIDE
+
+    @staticmethod
+    def forward(ctx, views, *params):
+        cls = SpatialMapFn
+        p = {n: (params[2 * i], params[2 * i + 1]) for i, n in enumerate(_ORDER)}
+        b, dev = views.shape[0], views.device
+        th = tw = None
+        mosaic = None
+        for name, vi, tf, tr, tc in _TILES:
+            xv = view_to_nhwc4(views, vi, tf)
+            oh, ow = cls._strip(name).out_hw(xv.shape[1], xv.shape[2])
+            if mosaic is None:
+                th, tw = oh, ow
+                mosaic = _empty((b, 3 * th, 2 * tw, 32), dev)
+            assert (oh, ow) == (th, tw), "the six strip convs must produce equal tiles"
+            cls._strip(name).forward(p[name][0], p[name][1], View(xv), View(mosaic, 0, 32, tr * th, tc * tw, th, tw), EPI_BIAS_RELU)
+        oh, ow = cls.OUT.out_hw(3 * th, 2 * tw)
+        out = _empty((b, oh, ow, 32), dev)
+        cls.OUT.forward(p["out_conv"][0], p["out_conv"][1], View(mosaic), View(out), EPI_BIAS_RELU)
+        ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
+        ctx.tile = (th, tw)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cls = SpatialMapFn
+        views, mosaic, out, w_out = ctx.saved_tensors
+        th, tw = ctx.tile
+        g = ops.relu_bwd(gout.contiguous(), out)
+        grads = {}
+        grads["out_conv"] = cls.OUT.backward_weight(View(mosaic), View(g))
+        gm = _empty(mosaic.shape, mosaic.device)
+        cls.OUT.backward_data(w_out, View(g), View(gm), relu_src=mosaic)
+        for name, vi, tf, tr, tc in _TILES:
+            xv = view_to_nhwc4(views, vi, tf)                      # recomputed: cheaper than keeping six NHWC4 copies
+            grads[name] = cls._strip(name).backward_weight(View(xv), View(gm, 0, 32, tr * th, tc * tw, th, tw))
+        flat = []
+        for n in _ORDER:
+            flat += list(grads[n])
+        return (None, *flat)
+
+
+# ------------------------------------------------------------------------------------------------ merging heads
+class MergeFn(torch.autograd.Function):
+    """ssr [B,128,918,32], spatial map [B,256,256,32] (both NHWC) and, for the road-map variant, rm [B,800,800,4]
+    (NHWC4 of the 1-channel mask) -> box-mask probabilities [B,800,800].
+
+    The channel concat (components.py:109,159) is a 64- or 96-channel NHWC buffer that ss_deconv and rm_conv_2
+    write by channel slice; up_conv_N run as flipped-tap dilated gathers; the last ConvTranspose2d(8->1,k2,s2)+sigmoid
+    has its own VALU kernel."""
+
+    SS_CONV = Layer(32, 32, (1, 24), stride=(1, 7))
+    SS_DECONV = Layer(32, 32, 2, stride=2, transposed=True)
+    RM1 = Layer(1, 32, 7, stride=3, dil=3, pad=1)
+    RM2 = Layer(32, 32, 3, dil=3)
+    UPS_RM = (Layer(96, 64, 7, dil=7, transposed=True), Layer(64, 32, 7, dil=7, transposed=True),
+              Layer(32, 16, 7, dil=7, transposed=True), Layer(16, 8, 7, dil=3, transposed=True))
+    UPS_PLAIN = (Layer(64, 32, 8, dil=8, transposed=True), Layer(32, 16, 8, dil=8, transposed=True),
+                 Layer(16, 8, 6, dil=6, transposed=True, output_padding=2))
+
+    @staticmethod
+    def forward(ctx, ssr, space, rm4, with_rm, *params):
+        cls = MergeFn
+        ups = cls.UPS_RM if with_rm else cls.UPS_PLAIN
+        it = iter(params)
+        nxt = lambda: (next(it), next(it))          # noqa: E731
+        p_ssc, p_ssd = nxt(), nxt()
+        p_rm1, p_rm2 = (nxt(), nxt()) if with_rm else (None, None)
+        p_up = [nxt() for _ in ups]
+        p_last = nxt()
+        b, dev = ssr.shape[0], ssr.device
+        sh, sw = cls.SS_CONV.out_hw(ssr.shape[1], ssr.shape[2])
+        s1 = _empty((b, sh, sw, 32), dev)
+        cls.SS_CONV.forward(p_ssc[0], p_ssc[1], View(ssr), View(s1), EPI_BIAS_RELU)
+        ch, cw = 2 * sh, 2 * sw
+        assert (ch, cw) == tuple(space.shape[1:3]), "ssr and spatial map must meet at the same size"
+        cat = _empty((b, ch, cw, 96 if with_rm else 64), dev)
+        cls.SS_DECONV.forward(p_ssd[0], p_ssd[1], View(s1), View(cat, 0, 32), EPI_BIAS_RELU)
+        cat[..., 32:64].copy_(space)
+        r1 = None
+        if with_rm:
+            rh, rw = cls.RM1.out_hw(rm4.shape[1], rm4.shape[2])
+            r1 = _empty((b, rh, rw, 32), dev)
+            cls.RM1.forward(p_rm1[0], p_rm1[1], View(rm4), View(r1), EPI_BIAS_RELU)
+            assert cls.RM2.out_hw(rh, rw) == (ch, cw)
+            cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
+        acts = [cat]
+        for layer, (w, bias) in zip(ups, p_up):
+            src = acts[-1]
+            oh, ow = layer.out_hw(src.shape[1], src.shape[2])
+            dst = _empty((b, oh, ow, layer.cout), dev)
+            layer.forward(w, bias, View(src), View(dst), EPI_BIAS_RELU)
+            acts.append(dst)
+        u = acts[-1]
+        probs = _empty((b, 2 * u.shape[1], 2 * u.shape[2]), dev)
+        check(_lib.lib().dd_deconv2x2_c1_fwd(_p(u), _p(p_last[0]), _p(p_last[1]), _p(probs), b, u.shape[1], u.shape[2], 8,
+                                             _stream()), "dd_deconv2x2_c1_fwd")
+        ctx.with_rm = with_rm
+        ctx.save_for_backward(ssr, s1, rm4 if with_rm else None, r1, probs, p_ssc[0], p_ssd[0],
+                              p_rm2[0] if with_rm else None, p_last[0], *[w for w, _ in p_up], *acts)
+        ctx.nup = len(ups)
+        return probs
+
+    @staticmethod
+    def backward(ctx, gprobs):
+        cls = MergeFn
+        with_rm, nup = ctx.with_rm, ctx.nup
+        ups = cls.UPS_RM if with_rm else cls.UPS_PLAIN
+        sv = ctx.saved_tensors
+        ssr, s1, rm4, r1, probs, w_ssc, w_ssd, w_rm2, w_last = sv[:9]
+        w_up, acts = sv[9:9 + nup], sv[9 + nup:]
+        cat, u = acts[0], acts[-1]
+        b, dev = ssr.shape[0], ssr.device
+        # last layer: sigmoid' and the ReLU mask of u are applied inside
+        gu = _empty(u.shape, dev)
+        dw_last, db_last = torch.empty_like(w_last), _empty((1,), dev)
+        ws = torch.empty(_lib.lib().dd_deconv2x2_c1_workspace_bytes(8), device=dev, dtype=torch.uint8)
+        check(_lib.lib().dd_deconv2x2_c1_bwd(_p(u), _p(w_last), _p(probs), _p(gprobs.contiguous()), _p(gu), _p(dw_last), _p(db_last),
+                                             b, u.shape[1], u.shape[2], 8, _p(ws), _stream()), "dd_deconv2x2_c1_bwd")
+        g = gu
+        g_up = []
+        for i in range(nup - 1, -1, -1):
+            layer, src = ups[i], acts[i]
+            g_up.append(layer.backward_weight(View(src), View(g)))
+            gsrc = _empty(src.shape, dev)
+            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src)     # masks with the producer's ReLU output
+            g = gsrc
+        g_up.reverse()
+        gcat = g                                                                 # [B,256,256,64|96], already ReLU-masked
+        g_space = gcat[..., 32:64].contiguous() if ctx.needs_input_grad[1] else None
+        # NOTE: the spatial map slice was masked with (space > 0): that IS the backward of SpatialMapFn's final ReLU,
+        # which SpatialMapFn.backward applies again (idempotent).
+        g_rm2 = g_rm1 = (None, None)
+        if with_rm:
+            g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))
+            gr1 = _empty(r1.shape, dev)
+            cls.RM2.backward_data(w_rm2, View(gcat, 64, 32), View(gr1), relu_src=r1)
+            g_rm1 = cls.RM1.backward_weight(View(rm4), View(gr1))
+        g_ssd = cls.SS_DECONV.backward_weight(View(s1), View(gcat, 0, 32))
+        gs1 = _empty(s1.shape, dev)
+        cls.SS_DECONV.backward_data(w_ssd, View(gcat, 0, 32), View(gs1), relu_src=s1)
+        g_ssc = cls.SS_CONV.backward_weight(View(ssr), View(gs1))
+        g_ssr = None
+        if ctx.needs_input_grad[0]:
+            g_ssr = _empty(ssr.shape, dev)
+            cls.SS_CONV.backward_data(w_ssc, View(gs1), View(g_ssr), relu_src=ssr)   # ssr is the encoder's ReLU output
+        flat = [*g_ssc, *g_ssd]
+        if with_rm:
+            flat += [*g_rm1, *g_rm2]
+        for gw in g_up:
+            flat += list(gw)
+        flat += [dw_last, db_last]
+        return (g_ssr, g_space, None, None, *flat)

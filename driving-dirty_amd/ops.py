@@ -325,6 +325,27 @@ class MseLoss(torch.autograd.Function):
         return da * g, None
 
 
+class BceProbs(torch.autograd.Function):
+    """mean F.binary_cross_entropy on probabilities (spatial_w_rm.py:131), gradient from the same pass."""
+
+    @staticmethod
+    def forward(ctx, probs, target):
+        _dev(probs, "probs")
+        _dev(target, "target", probs.shape)
+        n = probs.numel()
+        loss = torch.empty((), device=probs.device, dtype=torch.float32)
+        dp = torch.empty_like(probs) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().dd_bce_probs(_p(probs), _p(target), _p(loss), _p(dp), n, 1.0, _p(_loss_ws(n, probs.device)), _stream()),
+              "dd_bce_probs")
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g, None
+
+
 def sigmoid_and_loss(logits, target):
     """One pass: (loss, probs) without autograd -- used by validation."""
     n = logits.numel()

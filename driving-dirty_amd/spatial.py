@@ -1,0 +1,181 @@
+"""Spatial bounding-box heads on the HIP hot path: ``SpatialMappingCNN``, ``RoadMapBoxesMergingCNN``,
+``BoxesMergingCNN`` (reference src/bounding_box_model/spatial_bb/components.py) and the ``BBSpatialRoadMap``
+LightningModule (reference spatial_bb/spatial_w_rm.py, registry name ``spatial_rm``).  Same constructors,
+parameter names, construction order (default init parity) and ``forward`` signatures; the modules only hold
+parameters, the arithmetic is ``heads.SpatialMapFn`` / ``heads.MergeFn``.
+"""
+from argparse import ArgumentParser
+
+import torch
+from torch import nn
+
+from . import ops
+from .autoencoder import BasicAE
+from .heads import MergeFn, SpatialMapFn, _ORDER, as_nhwc
+from .lightning import LightningModule, hparam
+
+
+def _gpu(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: the hot path runs on MI355X only (got a {t.device} tensor)")
+
+
+class SpatialMappingCNN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.f_conv = nn.Conv2d(3, 32, kernel_size=(52, 1), stride=(3, 2), padding=(1))
+        self.fl_conv = nn.Conv2d(3, 32, kernel_size=(1, 50), stride=(3, 2))
+        self.fr_conv = nn.Conv2d(3, 32, kernel_size=(1, 50), stride=(3, 2))
+        self.b_conv = nn.Conv2d(3, 32, kernel_size=(52, 1), stride=(3, 2), padding=(1))
+        self.bl_conv = nn.Conv2d(3, 32, kernel_size=(1, 50), stride=(3, 2))
+        self.br_conv = nn.Conv2d(3, 32, kernel_size=(1, 50), stride=(3, 2))
+        self.out_conv = nn.Conv2d(32, 32, kernel_size=(3, 3))
+
+    def forward(self, x):
+        """(b, 6, 3, 256, 306) -> (b, 32, 256, 256), returned as an NCHW-shaped view of the NHWC result."""
+        _gpu(x, "SpatialMappingCNN")
+        params = []
+        for n in _ORDER:
+            m = getattr(self, n)
+            params += [m.weight, m.bias]
+        return SpatialMapFn.apply(x.contiguous(), *params).permute(0, 3, 1, 2)
+
+
+class _Merging(nn.Module):
+    with_rm = False
+
+    def _params(self, names):
+        out = []
+        for n in names:
+            m = getattr(self, n)
+            out += [m.weight, m.bias]
+        return out
+
+    def _run(self, ssr, spatial_map, rm):
+        _gpu(ssr, type(self).__name__)
+        names = ["ss_conv", "ss_deconv"] + (["rm_conv_1", "rm_conv_2"] if self.with_rm else []) + self.up_names
+        rm4 = ops.nchw_to_nhwc(rm.contiguous(), 4) if self.with_rm else None
+        probs = MergeFn.apply(as_nhwc(ssr, 32), as_nhwc(spatial_map, 32), rm4, self.with_rm, *self._params(names))
+        return probs.unsqueeze(1)                        # [B,1,800,800] like the reference
+
+
+class BoxesMergingCNN(_Merging):
+    up_names = ["up_conv_1", "up_conv_2", "up_conv_3", "up_conv_4"]
+
+    def __init__(self):
+        super().__init__()
+        self.ss_conv = nn.Conv2d(32, 32, kernel_size=(1, 24), stride=(1, 7))
+        self.ss_deconv = nn.ConvTranspose2d(32, 32, kernel_size=2, stride=2)
+        self.up_conv_1 = nn.ConvTranspose2d(64, 32, kernel_size=8, stride=1, dilation=8)
+        self.up_conv_2 = nn.ConvTranspose2d(32, 16, kernel_size=8, stride=1, dilation=8)
+        self.up_conv_3 = nn.ConvTranspose2d(16, 8, kernel_size=6, stride=1, dilation=6, output_padding=2)
+        self.up_conv_4 = nn.ConvTranspose2d(8, 1, kernel_size=2, stride=2)
+
+    def forward(self, ssr, spatial_map):
+        return self._run(ssr, spatial_map, None)
+
+
+class RoadMapBoxesMergingCNN(_Merging):
+    with_rm = True
+    up_names = ["up_conv_1", "up_conv_2", "up_conv_3", "up_conv_4", "up_conv_5"]
+
+    def __init__(self):
+        super().__init__()
+        self.ss_conv = nn.Conv2d(32, 32, kernel_size=(1, 24), stride=(1, 7))
+        self.ss_deconv = nn.ConvTranspose2d(32, 32, kernel_size=2, stride=2)
+        self.rm_conv_1 = nn.Conv2d(1, 32, kernel_size=7, stride=3, dilation=3, padding=1)
+        self.rm_conv_2 = nn.Conv2d(32, 32, kernel_size=3, stride=1, dilation=3)
+        self.up_conv_1 = nn.ConvTranspose2d(96, 64, kernel_size=7, stride=1, dilation=7)
+        self.up_conv_2 = nn.ConvTranspose2d(64, 32, kernel_size=7, stride=1, dilation=7)
+        self.up_conv_3 = nn.ConvTranspose2d(32, 16, kernel_size=7, stride=1, dilation=7)
+        self.up_conv_4 = nn.ConvTranspose2d(16, 8, kernel_size=7, stride=1, dilation=3)
+        self.up_conv_5 = nn.ConvTranspose2d(8, 1, kernel_size=2, stride=2)
+
+    def forward(self, ssr, spatial_map, rm):
+        return self._run(ssr, spatial_map, rm)
+
+
+class BBSpatialRoadMap(LightningModule):
+    """spatial_w_rm.py:25-167.  ``bb_coord_to_map`` (PIL polygon rasteriser, src/utils/bb_to_img.py) is host-side
+    target preparation outside the hot path: batches may carry a pre-rasterised ``'bb_map'`` [800,800] tensor in each
+    target dict (what the bench and tests use); otherwise a rasteriser must be supplied as ``hparams.rasterizer``."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        self.output_dim = 800 * 800
+        pre = hparam(hparams, "pretrained_ae", None)
+        self.ae = pre if pre is not None else BasicAE.load_from_checkpoint(self.hparams.pretrained_path)
+        self.frozen = True
+        self.ae.freeze()
+        self.ae.encoder.c3_only = True
+        self.ae.decoder = None
+        self.space_map_cnn = SpatialMappingCNN()
+        self.box_merge = RoadMapBoxesMergingCNN()
+
+    def wide_stitch_six_images(self, x):
+        return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
+
+    def forward(self, x, rm):
+        """x [b,6,3,256,306], rm [b,1,800,800] -> [b,800,800].  spatial_w_rm.py:67-83."""
+        space_rep = self.space_map_cnn(x)
+        ssr = self.ae.encoder.forward_nhwc4(ops.stitch6(x.contiguous())[0])
+        yhat = self.box_merge(ssr, space_rep, rm)
+        return yhat.squeeze(1)
+
+    def bb_coord_to_map(self, target):
+        maps = []
+        for sample in target:
+            if "bb_map" in sample:
+                maps.append(sample["bb_map"])
+            else:
+                raster = hparam(self.hparams, "rasterizer", None)
+                if raster is None:
+                    raise RuntimeError("targets carry no pre-rasterised 'bb_map' and no hparams.rasterizer was given")
+                maps.append(torch.as_tensor(raster(sample["bounding_box"])))
+        return torch.stack(maps, dim=0)
+
+    def _run_step(self, batch, batch_idx, step_name):
+        sample, target, road_image = batch
+        sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+        target_bb_img = self.bb_coord_to_map(target).to(sample.device).type_as(sample)
+        rm = torch.stack(tuple(road_image), dim=0).float().unsqueeze(1)
+        pred_bb_img = self(sample, rm)
+        batch_size = target_bb_img.size(0)
+        target_bb_img = target_bb_img.reshape(batch_size, -1)
+        pred_bb_img = pred_bb_img.reshape(batch_size, -1)
+        if hparam(self.hparams, "mse_loss", False):
+            loss = ops.MseLoss.apply(pred_bb_img, target_bb_img)
+        else:
+            loss = ops.BceProbs.apply(pred_bb_img, target_bb_img)
+        return loss, target_bb_img, pred_bb_img
+
+    def training_step(self, batch, batch_idx):
+        if self.current_epoch >= self.hparams.unfreeze_epoch_no and self.frozen:
+            self.frozen = False
+            self.ae.unfreeze()
+        train_loss, _, _ = self._run_step(batch, batch_idx, step_name="train")
+        return {"loss": train_loss, "log": {"train_loss": train_loss}}
+
+    def validation_step(self, batch, batch_idx):
+        val_loss, _, _ = self._run_step(batch, batch_idx, step_name="valid")
+        return {"val_loss": val_loss}
+
+    def validation_epoch_end(self, outputs):
+        avg_val_loss = torch.stack([x["val_loss"] for x in outputs]).mean()
+        return {"val_loss": avg_val_loss, "log": {"avg_val_loss": avg_val_loss}}
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate)
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        p = ArgumentParser(parents=[parent_parser], add_help=False)
+        p.add_argument("--learning_rate", type=float, default=1e-3)
+        p.add_argument("--unfreeze_epoch_no", type=int, default=0)
+        p.add_argument("--batch_size", type=int, default=16)
+        p.add_argument("--mse_loss", action="store_true")
+        p.add_argument("--link", type=str, default="/scratch/ab8690/DLSP20Dataset/data")
+        p.add_argument("--pretrained_path", type=str, default="")
+        p.add_argument("--output_img_freq", type=int, default=500)
+        return p

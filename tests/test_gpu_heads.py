@@ -1,0 +1,163 @@
+"""GPU parity of the decoder / autoencoder step and the spatial bounding-box heads against the fixtures captured
+from the reference's own modules (tests/golden/tiny_decoder.npz, spatial_heads.npz) and against the CPU oracle."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from driving_dirty_amd import synth
+
+pytestmark = pytest.mark.gpu
+CHAIN_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from driving_dirty_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref, floor=1e-30):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(floor))
+
+
+def _budget(g, key):
+    a, b = g[key + "_f64"], g[key + "_f32"]
+    ref_dev = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-30))
+    return max(CHAIN_TOL, 2.0 * ref_dev) if ref_dev < 1.0 else CHAIN_TOL
+
+
+def _floor(g, key):
+    if key.endswith(".fc1.bias"):
+        wk = "grad." + key[:-len("bias")] + "weight_f64"
+        if wk in g.files:
+            return float(np.abs(g[wk]).max())
+    return 1e-30
+
+
+def _samp(t, idx):
+    return t.detach().reshape(-1)[torch.from_numpy(idx).to(t.device)]
+
+
+def test_tiny_decoder_against_reference_golden(dev, golden):
+    from driving_dirty_amd.components import Decoder
+    g = golden("tiny_decoder")
+    dec = synth.fill_module(Decoder(16, 8, 3, 16, 22), seed=2).to(dev)
+    dec.fc1.drop_p = dec.fc2.drop_p = 0.0
+    z = synth.hash_uniform((3, 8), synth.key_salt("tiny_z"), -1.0, 1.0).to(dev).requires_grad_(True)
+    dec.train()
+    y = dec(z)
+    assert y.shape == (3, 3, 16, 22)
+    wy = synth.hash_uniform(tuple(y.shape), synth.key_salt("tiny_wy")).to(dev)
+    (y * wy).sum().backward()
+    assert rel_err(y, torch.from_numpy(g["y_f64"])) < _budget(g, "y")
+    assert rel_err(z.grad, torch.from_numpy(g["grad.z_f64"])) < _budget(g, "grad.z")
+    for k, p in dec.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(g[f"grad.{k}_f64"]), floor=_floor(g, k)) < _budget(g, f"grad.{k}"), k
+
+
+def test_autoencoder_step_against_oracle(dev):
+    """BasicAE.training_step (mask one view, encode, decode, MSE) vs the CPU oracle on the same seeded inputs."""
+    from driving_dirty_amd.autoencoder import BasicAE
+    from oracle import ae_parts, steps
+    hp = Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132, output_height=16, output_width=22,
+                   learning_rate=1e-3, output_img_freq=500)
+    ae = BasicAE(hp)
+    synth.fill_module(ae, seed=13)
+    enc = ae_parts.EncoderNet(16, 8, 3, 16, 132).double()
+    dec = ae_parts.DecoderNet(16, 8, 3, 16, 22).double()
+    enc.load_state_dict(ae.encoder.state_dict())
+    dec.load_state_dict(ae.decoder.state_dict())
+    ae = ae.to(dev)
+    for m in (ae.encoder.fc1, ae.encoder.fc2, ae.decoder.fc1, ae.decoder.fc2, enc.fc1, enc.fc2, dec.fc1, dec.fc2):
+        m.drop_p = 0.0
+    views = synth.camera_batch(3, 16, 22, seed=13)
+    np.random.seed(20200505)
+    out = ae.training_step(views.to(dev), 0)
+    out["loss"].backward()
+    ref_loss, _ = steps.ae_loss(enc, dec, views.double(), np.random.RandomState(20200505))
+    ref_loss.backward()
+    assert abs(float(out["loss"].detach()) - float(ref_loss.detach())) / float(ref_loss.detach()) < 1e-4
+    ref = dict(("encoder." + k, p) for k, p in enc.named_parameters())
+    ref.update(("decoder." + k, p) for k, p in dec.named_parameters())
+    for k, p in ae.named_parameters():
+        scale = max(float(ref[k].grad.abs().max()), 1e-3 * float(ref[k[:-4] + "weight"].grad.abs().max()) if k.endswith("bias") else 0.0)
+        assert rel_err(p.grad, ref[k].grad, floor=scale) < CHAIN_TOL, k
+    # the reference's API: six_to_one_task returns the NCHW wide image and the blanked view
+    np.random.seed(20200505)
+    x, y = ae.six_to_one_task(views.to(dev))
+    xr, yr, t = steps.six_to_one_task(views, np.random.RandomState(20200505))
+    assert torch.equal(x.cpu(), xr) and torch.equal(y.cpu(), yr)
+
+
+def test_spatial_heads_against_reference_golden(dev, golden):
+    """SpatialMappingCNN + RoadMapBoxesMergingCNN (and BoxesMergingCNN forward) at the reference's sizes, B = 1."""
+    from driving_dirty_amd.spatial import BoxesMergingCNN, RoadMapBoxesMergingCNN, SpatialMappingCNN
+    g = golden("spatial_heads")
+    sm = synth.fill_module(SpatialMappingCNN(), seed=5).to(dev)
+    rb = synth.fill_module(RoadMapBoxesMergingCNN(), seed=6).to(dev)
+    bm = synth.fill_module(BoxesMergingCNN(), seed=7).to(dev)
+    views = synth.camera_batch(1, seed=5).to(dev)
+    rm = synth.road_maps(1, seed=5).float().unsqueeze(1).to(dev)
+    ssr = synth.hash_uniform((1, 32, 128, 918), synth.key_salt("ssr"), 0.0, 1.0).to(dev).requires_grad_(True)
+    space = sm(views)
+    assert space.shape == (1, 32, 256, 256)
+    pred = rb(ssr, space, rm)
+    assert pred.shape == (1, 1, 800, 800)
+    wy = synth.hash_uniform(tuple(pred.shape), synth.key_salt("sp_wy")).to(dev)
+    (pred * wy).sum().backward()
+    assert rel_err(_samp(space.contiguous(), g["space_idx"]), torch.from_numpy(g["space_samp_f64"])) < _budget(g, "space_samp")
+    s = g["space_sum_f64"]
+    assert abs(float(space.double().abs().sum()) - s[1]) / s[1] < CHAIN_TOL
+    assert rel_err(_samp(pred, g["pred_idx"]), torch.from_numpy(g["pred_samp_f64"])) < _budget(g, "pred_samp")
+    s = g["pred_sum_f64"]
+    assert abs(float(pred.double().abs().sum()) - s[1]) / s[1] < CHAIN_TOL
+    assert rel_err(_samp(ssr.grad, g["ssrgrad_idx"]), torch.from_numpy(g["ssrgrad_samp_f64"])) < _budget(g, "ssrgrad_samp")
+    for name, m in (("space", sm), ("rboxm", rb)):
+        for k, p in m.named_parameters():
+            key = f"grad.{name}.{k}" if f"grad.{name}.{k}_f64" in g.files else f"gradsamp.{name}.{k}"
+            ref = torch.from_numpy(g[key + "_f64"])
+            got = p.grad if key.startswith("grad.") else _samp(p.grad, g[f"gradidx.{name}.{k}"])
+            assert rel_err(got, ref) < _budget(g, key), (name, k)
+    with torch.no_grad():
+        pred2 = bm(ssr.detach(), space.detach())
+    assert rel_err(_samp(pred2, g["pred_nomap_idx"]), torch.from_numpy(g["pred_nomap_samp_f64"])) < _budget(g, "pred_nomap_samp")
+
+
+def test_bbox_training_step_against_oracle(dev):
+    """BBSpatialRoadMap.training_step (frozen encoder, BCE on probabilities) vs the CPU oracle, reference sizes, B = 1."""
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.spatial import BBSpatialRoadMap
+    from oracle import ae_parts, spatial_parts, steps
+    ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8))
+    model = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=5, learning_rate=1e-3, output_img_freq=500, mse_loss=False))
+    synth.fill_module(model, seed=17)
+    enc = ae_parts.EncoderNet(16, 8, 3, 256, 1836)
+    enc.load_state_dict(model.ae.encoder.state_dict())
+    enc.c3_only = True
+    smr, rbr = spatial_parts.SpatialMapNet(), spatial_parts.RoadBoxMergeNet()
+    smr.load_state_dict(model.space_map_cnn.state_dict())
+    rbr.load_state_dict(model.box_merge.state_dict())
+    model = model.to(dev)
+    views = synth.camera_batch(1, seed=17)
+    road = synth.road_maps(1, seed=17)
+    tgt = (synth.hash_uniform((1, 800, 800), synth.key_salt("bbt"), 0.0, 1.0) < 0.02).float()
+    batch = (tuple(views.to(dev)), ({"bb_map": tgt[0].to(dev)},), tuple(road.to(dev)))
+    out = model.training_step(batch, 0)          # epoch 0 < unfreeze_epoch_no: encoder stays frozen (config 3)
+    out["loss"].backward()
+    assert all(p.grad is None for p in model.ae.parameters())
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.requires_grad_(False)
+    ref_loss, _ = steps.bbox_loss(enc, smr, rbr, views, road.float().unsqueeze(1), tgt)
+    ref_loss.backward()
+    assert abs(float(out["loss"].detach()) - float(ref_loss.detach())) / float(ref_loss.detach()) < 1e-4
+    for (k, p), (_, q) in zip(list(model.space_map_cnn.named_parameters()) + list(model.box_merge.named_parameters()),
+                              list(smr.named_parameters()) + list(rbr.named_parameters())):
+        assert rel_err(p.grad, q.grad) < 5e-3, k     # fp32 torch CPU is the yardstick here (not fp64)

@@ -132,3 +132,22 @@ def test_dropout_is_always_on():
     blk.drop_p = 0.2
     ref = torch.relu(blk.fc_bn(blk.fc1(x))) * m / 0.8
     assert torch.allclose(blk(x, m), ref)
+
+
+def test_product_modules_default_init_parity(golden):
+    """The drop-in modules (driving_dirty_amd.*) construct with the reference's RNG order too (CPU-only check)."""
+    from driving_dirty_amd.components import Decoder, Encoder
+    from driving_dirty_amd.spatial import BoxesMergingCNN, RoadMapBoxesMergingCNN, SpatialMappingCNN
+    g = golden("default_init")
+    torch.manual_seed(20200505)
+    enc = Encoder(16, 8, 3, 16, 22)
+    dec = Decoder(16, 8, 3, 16, 22)
+    torch.manual_seed(20200505)
+    sm, bm, rb = SpatialMappingCNN(), BoxesMergingCNN(), RoadMapBoxesMergingCNN()
+    for name, m in (("enc", enc), ("dec", dec), ("space", sm), ("boxm", bm), ("rboxm", rb)):
+        sd = m.state_dict()
+        assert sorted(k[len(name) + 1:] for k in g.files if k.startswith(name + ".")) == sorted(sd.keys())
+        for k, v in sd.items():
+            v = v.double().reshape(-1)
+            got = np.array([v.sum().item(), v.abs().sum().item(), v[0].item(), v[-1].item()])
+            np.testing.assert_allclose(got, g[f"{name}.{k}"], rtol=1e-12, atol=1e-12)
