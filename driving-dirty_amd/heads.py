@@ -22,7 +22,7 @@ def as_nhwc(t, cstore):
     v = t.permute(0, 2, 3, 1)
     if c == cstore and v.is_contiguous():
         return v
-    return ops.nchw_to_nhwc(t.contiguous(), cstore)
+    return ops.ToNHWC.apply(t, cstore)
 
 
 def _zeros(shape, dev):

@@ -73,6 +73,19 @@ def nhwc_to_nchw(x, c):
     return out
 
 
+class ToNHWC(torch.autograd.Function):
+    """Differentiable NCHW -> NHWC(c_store) re-layout (API edges: callers may hand in ordinary NCHW tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, c_store):
+        ctx.c = x.shape[1]
+        return nchw_to_nhwc(x.contiguous(), c_store)
+
+    @staticmethod
+    def backward(ctx, g):
+        return nhwc_to_nchw(g.contiguous(), ctx.c), None
+
+
 # ------------------------------------------------------------------------------------------------ conv primitives
 def conv_pack(weight, desc, kind):
     _dev(weight, "weight", (32, desc.cin_real, 3, 3))
