@@ -257,11 +257,16 @@ __global__ __launch_bounds__(256) void gconv_wgrad_reduce(const float* __restric
   dw[wi] = accumulate ? dw[wi] + s : s;
 }
 
-__global__ __launch_bounds__(64) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
-                                                        int nranges, int nto, int n_real, int accumulate) {
-  const int ot = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
+                                                         int nranges, int nto, int n_real, int accumulate) {
+  __shared__ float red[4][64];
+  const int ot = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   float s = 0.f;
-  for (int r = 0; r < nranges; ++r) s += bpart[((long)r * nto + ot) * 64 + lane];
+  for (int r = g; r < nranges; r += 4) s += bpart[((long)r * nto + ot) * 64 + lane];
+  red[g][lane] = s;
+  __syncthreads();
+  if (g != 0) return;
+  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
   s += __shfl_xor(s, 32);
   const int o = ot * 32 + lane;
   if (lane < 32 && o < n_real) db[o] = accumulate ? db[o] + s : s;
@@ -390,12 +395,17 @@ __global__ __launch_bounds__(256) void deconv2x2_c1_bwd_kernel(const float* __re
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(64) void deconv2x2_c1_reduce(const float* __restrict__ partial, float* __restrict__ dwt,
-                                                          float* __restrict__ db, int nblocks, int nvals) {
-  const int i = threadIdx.x;
-  if (i >= nvals) return;
+__global__ __launch_bounds__(256) void deconv2x2_c1_reduce(const float* __restrict__ partial, float* __restrict__ dwt,
+                                                           float* __restrict__ db, int nblocks, int nvals) {
+  __shared__ float red[4][64];
+  const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * nvals + i];
+  if (i < nvals)
+    for (int b = g; b < nblocks; b += 4) s += partial[(long)b * nvals + i];
+  red[g][i] = s;
+  __syncthreads();
+  if (g != 0 || i >= nvals) return;
+  s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
   if (i < nvals - 1) dwt[i] = s; else db[0] = s;
 }
 
@@ -527,7 +537,7 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
                      p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
   DD_LAUNCH_CHECK("gconv_wgrad_reduce");
   if (dbias) {
-    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(64), 0, st, bpart, dbias, p.nranges, p.nto, n_real, accumulate & 2);
+    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(256), 0, st, bpart, dbias, p.nranges, p.nto, n_real, accumulate & 2);
     DD_LAUNCH_CHECK("gconv_bias_reduce");
   }
   return 0;
@@ -556,7 +566,7 @@ int dd_deconv2x2_c1_bwd(const float* x, const float* wt, const float* probs, con
   hipLaunchKernelGGL(deconv2x2_c1_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, wt, probs, dprobs, dx,
                      (float*)workspace, npix, w);
   DD_LAUNCH_CHECK("deconv2x2_c1_bwd");
-  hipLaunchKernelGGL(deconv2x2_c1_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, dwt, dbias, grid,
+  hipLaunchKernelGGL(deconv2x2_c1_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dwt, dbias, grid,
                      c * 4 + 1);
   DD_LAUNCH_CHECK("deconv2x2_c1_reduce");
   return 0;

@@ -1,0 +1,69 @@
+"""Full-size (BASELINE config 2: bs = 32, 256 x 1836) checks of the conv kernels through size-independent
+properties, since the CPU oracle cannot finish these sizes in seconds:
+  linearity     conv(a*x + b*z) = a*conv(x) + b*conv(z)                (no bias, no ReLU)
+  adjointness   <dgrad(g), x> = <g, conv(x)>  and  <wgrad(x, g), W> = <g, conv(x)>   (fwd / dgrad / wgrad agree)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B, H, W = 32, 256, 1836
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from driving_dirty_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("cin,stride", [(3, 1), (32, 1), (32, 2)])
+def test_full_size_linearity_and_adjointness(dev, cin, stride):
+    from driving_dirty_amd import ops
+    g = torch.Generator(device=dev).manual_seed(cin * 10 + stride)
+    cs = 4 if cin == 3 else 32
+    d = ops.conv_desc(B, H, W, cin, stride)
+    x = torch.randn(B, H, W, cs, device=dev, generator=g)
+    z = torch.randn(B, H, W, cs, device=dev, generator=g)
+    if cin == 3:
+        x[..., 3] = 0
+        z[..., 3] = 0
+    wt = torch.randn(32, cin, 3, 3, device=dev, generator=g) * 0.1
+    pk = ops.conv_pack(wt, d, ops.PACK_FWD)
+    yx = ops.conv_fwd(x, pk, None, d, ops.EPI_NONE)
+    yz = ops.conv_fwd(z, pk, None, d, ops.EPI_NONE)
+    ylin = ops.conv_fwd(2.0 * x - 0.5 * z, pk, None, d, ops.EPI_NONE)
+    err = float((ylin - (2.0 * yx - 0.5 * yz)).abs().max() / ylin.abs().max())
+    assert err < 1e-5, err
+    gy = torch.randn(yx.shape, device=dev, generator=g)
+    ref = dot(gy, yx)
+    dw, db = ops.conv_wgrad(x, gy, d)
+    assert abs(dot(dw, wt) - ref) / abs(ref) < 1e-4
+    assert abs(float(db.double().sum()) - float(gy.double().sum())) / float(gy.double().abs().sum()) < 1e-6
+    if cin == 32:
+        kind = ops.PACK_DGRAD_S1 if stride == 1 else ops.PACK_DGRAD_S2
+        dx = ops.conv_dgrad(gy, ops.conv_pack(wt, d, kind), None, d)
+        assert abs(dot(dx, x) - ref) / abs(ref) < 1e-4
+        # ReLU-mask epilogue = elementwise product with (mask > 0)
+        dxm = ops.conv_dgrad(gy, ops.conv_pack(wt, d, kind), z, d)
+        assert torch.equal(dxm, dx * (z > 0))
+
+
+def test_full_size_pool_roundtrip(dev):
+    """pool backward routes each pooled gradient to exactly one element of its window (sum preserved)."""
+    from driving_dirty_amd import ops
+    feat = torch.rand(B, 128, 918, 32, device=dev) + 0.01
+    pooled = ops.pool4_fwd(feat)
+    assert pooled.shape == (B, 940032)
+    gp = torch.rand_like(pooled)
+    dfeat = ops.pool4_relu_bwd(gp, feat)
+    assert abs(float(dfeat.double().sum()) - float(gp.double().sum())) / float(gp.double().sum()) < 1e-9
+    assert int((dfeat != 0).sum()) == pooled.numel()
+    # the maximum of every window, gathered back through the routing, reproduces the pooled values
+    assert abs(dot(dfeat, feat) - dot(gp, pooled)) / dot(gp, pooled) < 1e-6
