@@ -61,7 +61,7 @@ def test_full_size_pool_roundtrip(dev):
     feat = torch.rand(B, 128, 918, 32, device=dev) + 0.01
     pooled = ops.pool4_fwd(feat)
     assert pooled.shape == (B, 940032)
-    gp = torch.rand_like(pooled)
+    gp = torch.rand_like(pooled) + 0.5          # strictly positive: every routed gradient is visible
     dfeat = ops.pool4_relu_bwd(gp, feat)
     assert abs(float(dfeat.double().sum()) - float(gp.double().sum())) / float(gp.double().sum()) < 1e-9
     assert int((dfeat != 0).sum()) == pooled.numel()
