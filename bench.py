@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
     a = ap.parse_args()
 
@@ -164,6 +165,8 @@ def main():
     model.zero_grad(set_to_none=True)
     opt = HipAdam(model.parameters(), lr=1e-3)
     sync = GradSync(model)
+    if not a.no_adam_overlap:
+        opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if world > 1 else None)
     batch = synthetic_batch(dev, BATCH, rank)
     timer = KernelTimer()
     timer.install()

@@ -26,6 +26,7 @@ class GradSync:
         self.big_numel = big_numel
         self.params = [p for p in module.parameters()]
         self._handles = []
+        self._by_param = {}
         self._small = []
         self._hooks = []
         if self.world > 1:
@@ -40,9 +41,17 @@ class GradSync:
         if p.grad is None:
             return
         if p.grad.numel() >= self.big_numel:
-            self._handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append(work)
+            self._by_param[p] = work
         else:
             self._small.append(p)
+
+    def wait_param(self, p):
+        """Make the CURRENT stream wait for the all-reduce of ``p`` (no-op when p went the small-tensor way)."""
+        work = self._by_param.get(p)
+        if work is not None:
+            work.wait()
 
     def finish(self):
         """Reduce the small gradients in one message and wait for everything in flight."""
@@ -56,7 +65,7 @@ class GradSync:
                 off += n
         for h in self._handles:
             h.wait()
-        self._handles, self._small = [], []
+        self._handles, self._small, self._by_param = [], [], {}
 
     def remove(self):
         for h in self._hooks:
