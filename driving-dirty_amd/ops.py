@@ -156,6 +156,12 @@ def pool4_relu_bwd(dpooled, feat):
     return out
 
 
+# Callbacks fired when backward enters its long MFMA-bound stretch (the c2 weight / data gradient kernels, ~4.4 ms
+# at bs = 32 that use a third of the HBM bandwidth): the place to start bandwidth-bound side work such as the
+# optimizer pass of already-finished gradients (optim.HipAdam.overlap_with_backward).
+MFMA_PHASE_HOOKS = []
+
+
 # ------------------------------------------------------------------------------------------------ encoder conv stack
 class EncoderConvStack(torch.autograd.Function):
     """c1 -> ReLU -> c2 -> ReLU -> c3 (stride 2) -> ReLU [-> NCHW-order max_pool1d(4)] as one autograd node.
@@ -198,6 +204,8 @@ class EncoderConvStack(torch.autograd.Function):
         if need[1] or need[2] or need[3] or need[4]:
             g2 = conv_dgrad(g3, conv_pack(w3, d3, PACK_DGRAD_S2), a2, d3)
             del g3
+            for hook in MFMA_PHASE_HOOKS:
+                hook()
             if need[3] or need[4]:
                 dw2, db2 = conv_wgrad(a1, g2, d2)
             if need[1] or need[2]:

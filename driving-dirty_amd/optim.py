@@ -13,6 +13,7 @@ class HipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._side = None
+        self._pending = []
         self._early = set()
         self._hooks = []
         self._scale = 1.0
@@ -43,25 +44,35 @@ class HipAdam(torch.optim.Optimizer):
         self._side = torch.cuda.Stream()
         self._scale = grad_scale
         self._sync = grad_sync
+        self._pending = []
+        ops.MFMA_PHASE_HOOKS.append(self._flush_pending)
         for group in self.param_groups:
             for p in group["params"]:
                 if p.requires_grad and p.numel() >= big_numel:
                     self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, g=group: self._early_step(q, g)))
 
-    @torch.no_grad()
     def _early_step(self, p, group):
-        if p.grad is None:
+        if p.grad is not None:
+            self._pending.append((p, group))      # launched when backward reaches its MFMA-bound stretch
+
+    @torch.no_grad()
+    def _flush_pending(self):
+        if not self._pending:
             return
         ev = torch.cuda.current_stream().record_event()
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
-            if self._sync is not None:
-                self._sync.wait_param(p)          # the side stream (not the host) waits for this tensor's all-reduce
-            self._update(p, group, self._scale)
-        self._early.add(p)
+            for p, group in self._pending:
+                if self._sync is not None:
+                    self._sync.wait_param(p)      # the side stream (not the host) waits for this tensor's all-reduce
+                self._update(p, group, self._scale)
+                self._early.add(p)
+        self._pending = []
 
     @torch.no_grad()
     def step(self, grad_scale=1.0):
+        if self._side is not None:
+            self._flush_pending()                 # backward never reached an MFMA phase hook (other models)
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None or p in self._early:
