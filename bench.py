@@ -81,6 +81,20 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
 
 
+def measured_traffic():
+    """HBM bytes per c2-forward launch from the committed rocprofv3 PMC passes (profiles/*_c2_fwd_traffic.json,
+    written by tools/pmc_traffic.py); None when no such profile exists.  PMC collection needs the profiler, so it
+    cannot be live inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c2_fwd_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def host_cores():
     """CPU threads this job may really use: affinity, capped by the cgroup quota and by the GPU box's
     per-GPU CPU share (16); DD_CPU_THREADS overrides."""
@@ -218,7 +232,7 @@ def main():
                                                  / (PEAK_F32_MFMA_TF * world), 4),
             "roofline": {"kernel": "conv_strip_fwd<CIN=32,S=1> (c2 forward, 74% of encoder FLOPs fwd)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": measured_traffic(),
                          "launch_ms": round(k_ms, 4), "launches_timed": len(timer.pairs)},
         }
         if not a.no_cpu_baseline and world == 1:
