@@ -112,6 +112,13 @@ class Encoder(nn.Module):
         h = self.fc2(h, keeps[1])
         return ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
 
+    def forward_both(self, x4, keeps=(None, None)):
+        """One pass of the conv stack feeding BOTH exits the reference's ``c3_only`` switch chooses between
+        (components.py:44-45): returns (conv feature [B,32,H/2,W/2], latent z).  Used by the joint roadmap + box model."""
+        feat, pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, 2, self.rows_per_task)
+        h = self.fc2(self.fc1(pooled, keeps[0]), keeps[1])
+        return feat.permute(0, 3, 1, 2), ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
+
     def forward(self, x, keeps=(None, None)):
         _require_gpu(x, "Encoder")
         return self.forward_nhwc4(ops.nchw_to_nhwc(x.contiguous(), 4), keeps)

@@ -1,0 +1,52 @@
+"""``JointRoadMapBBox``: BASELINE.json config 4, the joint roadmap + bounding-box multi-task step.
+
+The reference has no joint model: its ``c3_only`` switch (components.py:44-45) makes the two heads mutually
+exclusive users of the encoder.  This is a build-side composition of rows a8 + a11 of SURVEY.md 8(a): ONE pass of
+the encoder conv stack feeds both the latent path (pool -> dense blocks -> Linear(64, 640000) -> BCE-with-logits,
+roadmap_bce_v2.py:66-108) and the box path (SpatialMappingCNN + RoadMapBoxesMergingCNN -> BCE on probabilities,
+spatial_w_rm.py:67-131); the losses add, the two gradients of the shared c3 feature add inside the encoder's
+backward.  Parity is checked per head against the oracle (tests/test_gpu_heads.py).
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .autoencoder import BasicAE
+from .lightning import LightningModule, hparam
+from .spatial import RoadMapBoxesMergingCNN, SpatialMappingCNN
+
+
+class JointRoadMapBBox(LightningModule):
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        pre = hparam(hparams, "pretrained_ae", None)
+        self.ae = pre if pre is not None else BasicAE.load_from_checkpoint(self.hparams.pretrained_path)
+        self.ae.decoder = None
+        self.ae.encoder.c3_only = False
+        self.fc1 = nn.Linear(self.ae.latent_dim, 800 * 800)          # roadmap head, roadmap_bce_v2.py:50
+        self.space_map_cnn = SpatialMappingCNN()                      # spatial_w_rm.py:50-52
+        self.box_merge = RoadMapBoxesMergingCNN()
+
+    def forward(self, x, rm):
+        """x [B,6,3,256,306], rm [B,1,800,800] -> (roadmap logits [B,800,800], box probabilities [B,800,800])."""
+        x = x.contiguous()
+        feat, z = self.ae.encoder.forward_both(ops.stitch6(x)[0])
+        logits = ops.linear(z, self.fc1.weight, self.fc1.bias).reshape(-1, 800, 800)
+        boxes = self.box_merge(feat, self.space_map_cnn(x), rm).squeeze(1)
+        return logits, boxes
+
+    def training_step(self, batch, batch_idx):
+        sample, target, road_image = batch
+        sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+        target_rm = torch.stack(tuple(road_image), dim=0).float()
+        target_bb = torch.stack([t["bb_map"] for t in target], dim=0).to(sample.device).float()
+        logits, boxes = self(sample, target_rm.unsqueeze(1))
+        b = target_rm.size(0)
+        loss_rm = ops.BceWithLogits.apply(logits.reshape(b, -1), target_rm.reshape(b, -1))
+        loss_bb = ops.BceProbs.apply(boxes.reshape(b, -1), target_bb.reshape(b, -1))
+        loss = loss_rm + loss_bb
+        return {"loss": loss, "log": {"train_loss": loss, "roadmap_loss": loss_rm, "bbox_loss": loss_bb}}
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate)

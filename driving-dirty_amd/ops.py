@@ -131,6 +131,14 @@ def conv_wgrad(x, dy, desc):
     return dw, db
 
 
+def add(a, b):
+    _dev(a, "a")
+    _dev(b, "b", a.shape)
+    out = torch.empty_like(a)
+    check(_lib.lib().dd_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "dd_add")
+    return out
+
+
 def relu_bwd(dy, y):
     _dev(dy, "dy", y.shape)
     _dev(y, "y")
@@ -184,20 +192,30 @@ class EncoderConvStack(torch.autograd.Function):
         a2 = conv_fwd(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
         a3 = conv_fwd(a2, conv_pack(w3, d3, PACK_FWD), b3, d3)
         ctx.save_for_backward(x4, a1, a2, a3, w2, w3)
-        ctx.pool = bool(pool)
+        ctx.pool = int(pool)                  # 0: conv feature, 1: pooled vector, 2: both (joint roadmap + box model)
         ctx.rows_per_task = rows_per_task
-        if pool:
+        if ctx.pool == 2:
+            return a3, pool4_fwd(a3)
+        if ctx.pool:
             return pool4_fwd(a3)
         return a3
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, grad_pooled=None):
         x4, a1, a2, a3, w2, w3 = ctx.saved_tensors
         b, h, w, _ = x4.shape
         rpt = ctx.rows_per_task
         d1, d2, d3 = conv_desc(b, h, w, 3, 1, rpt), conv_desc(b, h, w, 32, 1, rpt), conv_desc(b, h, w, 32, 2, rpt)
-        grad = grad.contiguous()
-        g3 = pool4_relu_bwd(grad, a3) if ctx.pool else relu_bwd(grad, a3)
+        if ctx.pool == 2:                     # two consumers of the c3 feature: their gradients add
+            parts = []
+            if grad is not None:
+                parts.append(relu_bwd(grad.contiguous(), a3))
+            if grad_pooled is not None:
+                parts.append(pool4_relu_bwd(grad_pooled.contiguous(), a3))
+            g3 = parts[0] if len(parts) == 1 else add(parts[0], parts[1])
+        else:
+            grad = grad.contiguous()
+            g3 = pool4_relu_bwd(grad, a3) if ctx.pool else relu_bwd(grad, a3)
         need = ctx.needs_input_grad
         dw3, db3 = conv_wgrad(a2, g3, d3) if (need[5] or need[6]) else (None, None)
         dw2 = db2 = dw1 = db1 = None

@@ -168,3 +168,40 @@ def test_bbox_training_step_against_oracle(dev):
     for (k, p), (_, q) in zip(list(model.space_map_cnn.named_parameters()) + list(model.box_merge.named_parameters()),
                               list(smr.named_parameters()) + list(rbr.named_parameters())):
         assert rel_err(p.grad, q.grad) < 5e-3, k     # fp32 torch CPU is the yardstick here (not fp64)
+
+
+def test_joint_model_equals_sum_of_heads(dev):
+    """Config 4 composition: the joint step's loss is the sum of the two single-head losses, and every gradient is
+    the sum of the two single-head gradients (shared encoder), on the same seeded inputs."""
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.joint import JointRoadMapBBox
+    from driving_dirty_amd import ops
+
+    hp = dict(unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500)
+    ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8))
+    joint = JointRoadMapBBox(Namespace(pretrained_ae=ae, **hp))
+    synth.fill_module(joint, seed=29)
+    joint = joint.to(dev)
+    enc = joint.ae.encoder
+    enc.fc1.drop_p = enc.fc2.drop_p = 0.0
+    views = synth.camera_batch(2, seed=29).to(dev)
+    road = synth.road_maps(2, seed=29).to(dev)
+    tgt = tuple({"bb_map": (synth.hash_uniform((800, 800), 100 + i, 0.0, 1.0) < 0.02).float().to(dev)} for i in range(2))
+    out = joint.training_step((tuple(views), tgt, tuple(road)), 0)
+    out["loss"].backward()
+    gj = {k: p.grad.clone() for k, p in joint.named_parameters()}
+    joint.zero_grad(set_to_none=True)
+    # head 1: roadmap only
+    z = enc.forward_nhwc4(ops.stitch6(views)[0])
+    l1 = ops.BceWithLogits.apply(ops.linear(z, joint.fc1.weight, joint.fc1.bias), road.float().reshape(2, -1))
+    l1.backward()
+    # head 2: boxes only
+    enc.c3_only = True
+    feat = enc.forward_nhwc4(ops.stitch6(views)[0])
+    enc.c3_only = False
+    boxes = joint.box_merge(feat, joint.space_map_cnn(views), road.float().unsqueeze(1)).squeeze(1)
+    l2 = ops.BceProbs.apply(boxes.reshape(2, -1), torch.stack([t["bb_map"] for t in tgt]).reshape(2, -1))
+    l2.backward()
+    assert abs(float(out["loss"].detach()) - float((l1 + l2).detach())) / float((l1 + l2).detach()) < 1e-6
+    for k, p in joint.named_parameters():
+        assert rel_err(gj[k], p.grad, floor=1e-12) < 2e-4, k
