@@ -35,6 +35,7 @@ SIGNATURES = {
     "dd_abi_version": (_i32, []),
     "dd_last_error": (C.c_char_p, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_nhwc_to_nchw": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_conv_packed_floats": (_i64, [_DP, _i32]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "dd_linear_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "dd_linear_dgrad": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "dd_linear_wgrad": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "dd_threat_score_workspace_bytes": (_i64, []),
+    "dd_threat_score": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 

@@ -171,6 +171,40 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restric
   if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
 }
 
+// Threat score tp / (sum a + sum b - tp) (reference src/utils/helper.py:74-77), optionally on round(b)
+// (roadmap_bce_v2.py:140): one pass, three sums.
+__global__ __launch_bounds__(256) void threat_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             double* __restrict__ partial, long n, int round_b) {
+  float tp = 0.f, sa = 0.f, sb = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float av = a[i];
+    const float bv = round_b ? rintf(b[i]) : b[i];      // torch.round = round half to even = rintf
+    tp += av * bv;
+    sa += av;
+    sb += bv;
+  }
+  const double t0 = block_sum(tp);
+  __syncthreads();
+  const double t1 = block_sum(sa);
+  __syncthreads();
+  const double t2 = block_sum(sb);
+  if (threadIdx.x == 0) {
+    partial[3L * blockIdx.x + 0] = t0;
+    partial[3L * blockIdx.x + 1] = t1;
+    partial[3L * blockIdx.x + 2] = t2;
+  }
+}
+
+__global__ __launch_bounds__(64) void threat_final_kernel(const double* __restrict__ partial, int nblocks,
+                                                          float* __restrict__ out) {
+  double s = 0.0;
+  const int k = threadIdx.x;
+  if (k < 3)
+    for (int b = 0; b < nblocks; ++b) s += partial[3L * b + k];
+  const double tp = __shfl(s, 0), sa = __shfl(s, 1), sb = __shfl(s, 2);
+  if (k == 0) out[0] = (float)(tp / (sa + sb - tp));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2_sqrt,
@@ -279,6 +313,19 @@ int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
                      1.0 / (double)n, loss_out);
   DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int64_t dd_threat_score_workspace_bytes(void) { return (int64_t)kLossBlocks * 3 * sizeof(double); }
+
+int dd_threat_score(const float* a, const float* b, float* out, int64_t n, int32_t round_b, void* workspace, void* stream) {
+  DD_REQUIRE(a && b && out && workspace && n > 0, DD_ERR_BAD_ARG, "threat_score: bad argument");
+  const int grid = (int)min((n + 255) / 256, (long)kLossBlocks);
+  hipLaunchKernelGGL(threat_partial_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, (double*)workspace, (long)n,
+                     round_b);
+  DD_LAUNCH_CHECK("threat_score");
+  hipLaunchKernelGGL(threat_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, grid, out);
+  DD_LAUNCH_CHECK("threat_score final");
   return 0;
 }
 

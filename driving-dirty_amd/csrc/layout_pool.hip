@@ -38,6 +38,22 @@ __global__ __launch_bounds__(256) void stitch6_kernel(const float* __restrict__ 
   }
 }
 
+// uint8 HWC camera frames (what a JPEG decoder emits) -> the same wide NHWC4 fp32 image: ToTensor's /255
+// (reference autoencoder.py:133 torchvision.transforms.ToTensor) fused with the gather; 3 bytes in, 16 bytes out.
+__global__ __launch_bounds__(256) void stitch6_u8_kernel(const unsigned char* __restrict__ frames, f32x4* __restrict__ wide4,
+                                                         int B, int H, int W) {
+  const long npx = (long)B * H * 6 * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(p % (6 * W));
+    const int yy = (int)((p / (6 * W)) % H);
+    const int b = (int)(p / ((long)6 * W * H));
+    const int slot = xw / W, xx = xw - slot * W;
+    const unsigned char* src = frames + ((((long)b * 6 + kViewOrder[slot]) * H + yy) * W + xx) * 3;
+    constexpr float s = 1.0f / 255.0f;
+    wide4[p] = f32x4{src[0] * s, src[1] * s, src[2] * s, 0.f};
+  }
+}
+
 // NCHW -> NHWC(Cs): one thread per (pixel, 4-channel group)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, f32x4* __restrict__ dst,
                                                            int B, int C, int H, int W, int Cs) {
@@ -185,6 +201,15 @@ int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* t
   hipLaunchKernelGGL(stitch6_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, views, (f32x4*)wide_nhwc4,
                      wide_nchw, target, batch, height, width, mask_slot);
   DD_LAUNCH_CHECK("stitch6");
+  return 0;
+}
+
+int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width, void* stream) {
+  DD_REQUIRE(frames && wide_nhwc4 && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "stitch6_u8: bad argument");
+  const long npx = (long)batch * height * 6 * width;
+  hipLaunchKernelGGL(stitch6_u8_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, frames, (f32x4*)wide_nhwc4,
+                     batch, height, width);
+  DD_LAUNCH_CHECK("stitch6_u8");
   return 0;
 }
 

@@ -57,6 +57,26 @@ def stitch6(views, mask_slot=-1, want_nhwc4=True, want_nchw=False, want_target=F
     return wide4, wide, tgt
 
 
+def stitch6_u8(frames):
+    """frames [B,6,H,W,3] uint8 -> wide NHWC4 fp32 in [0,1] (ToTensor's /255 fused with the 6-view gather)."""
+    b, n, h, w, c = frames.shape
+    if n != 6 or c != 3 or frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous():
+        raise _lib.HotpathError(f"stitch6_u8: expected contiguous uint8 [B,6,H,W,3] on the GPU, got {tuple(frames.shape)} {frames.dtype}")
+    out = torch.empty((b, h, 6 * w, 4), device=frames.device, dtype=torch.float32)
+    check(_lib.lib().dd_stitch6_u8(_p(frames), _p(out), b, h, w, _stream()), "dd_stitch6_u8")
+    return out
+
+
+def threat_score(a, b, round_b=False):
+    """compute_ts_road_map (helper.py:74-77) in one pass on the device."""
+    _dev(a, "a")
+    _dev(b, "b", a.shape)
+    out = torch.empty((), device=a.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().dd_threat_score_workspace_bytes(), device=a.device, dtype=torch.uint8)
+    check(_lib.lib().dd_threat_score(_p(a), _p(b), _p(out), a.numel(), int(round_b), _p(ws), _stream()), "dd_threat_score")
+    return out
+
+
 def nchw_to_nhwc(x, c_store):
     b, c, h, w = x.shape
     _dev(x, "x")

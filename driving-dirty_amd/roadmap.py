@@ -17,9 +17,8 @@ from .lightning import LightningModule, hparam
 
 
 def compute_ts_road_map(road_map1, road_map2):
-    """Threat score, reference src/utils/helper.py:74-77."""
-    tp = (road_map1 * road_map2).sum()
-    return tp * 1.0 / (road_map1.sum() + road_map2.sum() - tp)
+    """Threat score, reference src/utils/helper.py:74-77 (one fused pass on the device)."""
+    return ops.threat_score(road_map1.contiguous(), road_map2.contiguous())
 
 
 class RoadMapBCE(LightningModule):
@@ -80,7 +79,7 @@ class RoadMapBCE(LightningModule):
     def validation_step(self, batch, batch_idx):
         val_loss, target_rm, pred_rm, pred_logit_rm = self._run_step(batch, batch_idx, step_name="valid")
         val_ts = compute_ts_road_map(target_rm, pred_logit_rm)
-        val_ts_rounded = compute_ts_road_map(target_rm, pred_logit_rm.round())
+        val_ts_rounded = ops.threat_score(target_rm.contiguous(), pred_logit_rm.contiguous(), round_b=True)
         return {"val_loss": val_loss, "val_ts_rounded": val_ts_rounded, "val_ts": val_ts}
 
     def validation_epoch_end(self, outputs):
@@ -129,4 +128,4 @@ class RoadMap(RoadMapBCE):
     def validation_step(self, batch, batch_idx):
         val_loss, target_rm, pred_rm = self._run_step(batch, batch_idx, step_name="valid")
         return {"val_loss": val_loss, "val_ts": compute_ts_road_map(target_rm, pred_rm),
-                "val_ts_rounded": compute_ts_road_map(target_rm, pred_rm.round())}
+                "val_ts_rounded": ops.threat_score(target_rm.contiguous(), pred_rm.contiguous(), round_b=True)}

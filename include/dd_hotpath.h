@@ -67,6 +67,11 @@ const char* dd_last_error(void);
 int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* target,
                int32_t batch, int32_t height, int32_t width, int32_t mask_slot, void* stream);
 
+/* Input pipeline variant: frames [B,6,H,W,3] uint8 as a JPEG decoder emits them -> the same wide
+ * NHWC4 fp32 image, with torchvision ToTensor's /255 (reference autoencoder.py:133, data_helper.py:63-68) fused. */
+int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
+                  void* stream);
+
 /* NCHW [B,C,H,W] <-> NHWC [B,H,W,Cs] (Cs >= C; extra channels written as zero / ignored). */
 int dd_nchw_to_nhwc(const float* src, float* dst, int32_t batch, int32_t c, int32_t h, int32_t w,
                     int32_t c_store, void* stream);
@@ -216,6 +221,11 @@ int dd_linear_dgrad(const float* dy, const float* w, float* dx, int32_t m, int32
                     int64_t workspace_bytes, void* stream);
 int dd_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int32_t m, int32_t n, int32_t k,
                     void* stream);
+
+/* Threat score tp / (sum a + sum b - tp), tp = sum a*b (reference src/utils/helper.py:74-77); round_b != 0 scores
+ * round(b) (roadmap_bce_v2.py:140).  One pass, deterministic. */
+int64_t dd_threat_score_workspace_bytes(void);
+int dd_threat_score(const float* a, const float* b, float* out, int64_t n, int32_t round_b, void* workspace, void* stream);
 
 /* ---- optimizer -----------------------------------------------------------------------------
  * torch.optim.Adam step (autoencoder.py:119-120, roadmap_bce_v2.py:154-157; no weight decay,

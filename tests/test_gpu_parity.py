@@ -357,3 +357,34 @@ def test_adam_overlapped_with_backward_is_identical(dev):
     a, b = run(False), run(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_threat_score_and_validation_step(dev):
+    """compute_ts_road_map (helper.py:74-77) fused on the device, and RoadMapBCE.validation_step's outputs."""
+    from driving_dirty_amd import ops
+    from oracle import steps
+    t = (hu((3, 800, 800), "tst", 0.0, 1.0) < 0.3).float()
+    p = hu((3, 800, 800), "tsp", 0.0, 1.0)
+    assert abs(float(ops.threat_score(t.to(dev), p.to(dev))) - float(steps.threat_score(t.double(), p.double()))) < 1e-6
+    assert abs(float(ops.threat_score(t.to(dev), p.to(dev), round_b=True)) - float(steps.threat_score(t.double(), p.double().round()))) < 1e-6
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.roadmap import RoadMapBCE
+    ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132, output_height=16, output_width=22))
+    m = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500)).to(dev)
+    views = synth.camera_batch(3, 16, 22, seed=31).to(dev)
+    road = synth.road_maps(3, seed=31).to(dev)
+    out = m.validation_step((tuple(views), None, tuple(road)), 0)
+    agg = m.validation_epoch_end([out, out])
+    assert set(out) == {"val_loss", "val_ts_rounded", "val_ts"} and set(agg) == {"val_loss", "log"}
+    assert 0.0 <= float(out["val_ts"]) <= 1.0
+
+
+def test_stitch6_uint8_pipeline(dev):
+    """uint8 HWC frames -> wide NHWC4 float: equals ToTensor (/255) followed by the reference stitch."""
+    from driving_dirty_amd import ops
+    from oracle import steps
+    frames = (hu((2, 6, 9, 13, 3), "u8", 0.0, 256.0)).clamp(0, 255).to(torch.uint8)
+    ref = steps.wide_stitch(frames.permute(0, 1, 4, 2, 3).float() / 255.0)
+    out = ops.stitch6_u8(frames.to(dev))
+    assert torch.allclose(out[..., :3].permute(0, 3, 1, 2).cpu(), ref, rtol=0, atol=1e-7)
+    assert float(out[..., 3].abs().max()) == 0.0
