@@ -41,6 +41,8 @@ SIGNATURES = {
     "dd_conv_packed_floats": (_i64, [_DP, _i32]),
     "dd_conv_pack": (_i32, [_p, _p, _DP, _i32, _p]),
     "dd_conv_fwd": (_i32, [_p, _p, _p, _p, _p, _DP, _i32, _p]),
+    "dd_conv_fwd_relu_bits": (_i32, [_p, _p, _p, _p, _p, _DP, _p]),
+    "dd_conv_dgrad_relu_bits": (_i32, [_p, _p, _p, _p, _DP, _p]),
     "dd_conv_dgrad": (_i32, [_p, _p, _p, _p, _DP, _p]),
     "dd_conv_wgrad_workspace_bytes": (_i64, [_DP]),
     "dd_conv_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _DP, _p]),

@@ -27,6 +27,11 @@
 
 namespace {
 
+// internal epilogues on top of the public DD_EPI_* ones: the ReLU sign travels as ONE BIT per activation
+// (a uint32 per 32-channel pixel) instead of being re-read from the 128-byte fp32 pixel by the backward kernels
+constexpr int EPI_BIAS_RELU_BITS = 5;   // y = relu(conv + bias), bits[pixel] = mask of (y > 0) over the 32 channels
+constexpr int EPI_RELU_BITS = 6;        // y = conv * bit(channel) of bits[pixel]
+
 template <int CIN, int S>
 struct StripCfg {
   static constexpr int PXB = CIN * 4;        // bytes per pixel
@@ -109,7 +114,8 @@ template <int CIN, int S, int EPI, int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ msk, float* __restrict__ y,
-                                                           int B, int H, int W, int Ho, int Wo, int nstrips) {
+                                                           unsigned* __restrict__ bits_out, int B, int H, int W, int Ho,
+                                                           int Wo, int nstrips) {
   using C = StripCfg<CIN, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
   char* spill = ring + 3 * C::SLOTB;
   const char* wl = smem;
   const int h = lane >> 5, n = lane & 31;
-  const float bv = (EPI == DD_EPI_BIAS || EPI == DD_EPI_BIAS_RELU) ? bias[n] : 0.f;
+  const float bv = (EPI == DD_EPI_BIAS || EPI == DD_EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_BITS) ? bias[n] : 0.f;
 
   long idx, end;
   wave_range((long)B * nstrips * Ho, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
@@ -158,6 +164,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
         const __amdgpu_buffer_rsrc_t ms = rsrc(msk + orow, Wo * 128);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mreg[r] = bload1(ms, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4);
+      }
+      if (EPI == EPI_RELU_BITS) {   // one uint32 per pixel: 32x fewer mask bytes than the fp32 activation
+        const __amdgpu_buffer_rsrc_t ms = rsrc((const unsigned*)msk + (long)(b * Ho + yy) * Wo, Wo * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mreg[r] = bload1(ms, (x0 + dd_acc_row(r, lane)) * 4);
       }
       // keep the loads ABOVE the MFMA chain: left alone, hipcc sinks them to their first use (the ring store
       // behind the chain) and the wave then eats a full HBM round trip per row
@@ -216,9 +227,17 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
         if (EPI == DD_EPI_BIAS) v += bv;
-        if (EPI == DD_EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
+        if (EPI == DD_EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v + bv, 0.f);
         if (EPI == DD_EPI_RELU_MASK) v = (mreg[r] > 0.f) ? v : 0.f;
+        if (EPI == EPI_RELU_BITS) v = ((__builtin_bit_cast(unsigned, mreg[r]) >> n) & 1u) ? v : 0.f;
         bstore1(ys, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4, v);
+        if (EPI == EPI_BIAS_RELU_BITS) {
+          // lanes 0-31 hold the 32 channels of pixel i, lanes 32-63 those of pixel i+4: one ballot = two mask words
+          const unsigned long long m = __ballot(v > 0.f);
+          const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + (long)(b * Ho + yy) * Wo, Wo * 4);
+          const unsigned word = h ? (unsigned)(m >> 32) : (unsigned)m;
+          __builtin_amdgcn_raw_buffer_store_b32(word, bs, (n == 0) ? (x0 + dd_acc_row(r, lane)) * 4 : -16, 0, 0);
+        }
       }
     }
   }
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
 // (same along x), so a pair of output rows x 64 output pixels costs the same 144 MFMAs the forward
 // spends on 32 output pixels -- no multiplies by inserted zeros.
 // ------------------------------------------------------------------------------------------------
-template <int WPB, bool MASK>
+template <int WPB, int MASK>   // 0: none, 1: fp32 activation (> 0), 2: packed sign bits
 __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restrict__ dy, const float* __restrict__ wp,
                                                           const float* __restrict__ msk, float* __restrict__ dx,
                                                           int B, int H, int W, int Ho, int Wo, int nstrips) {
@@ -285,10 +304,16 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
     const long orow = ((long)(b * H + min(yi, H - 1)) * W) * 32;                                \
     const int obytes = (yi < H) ? W * 128 : 0;                                                  \
     float mreg[16];                                                                             \
-    if (MASK) {                                                                                 \
+    if (MASK == 1) {                                                                            \
       const __amdgpu_buffer_rsrc_t ms = rsrc(msk + orow, obytes);                               \
       _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                         \
         mreg[rr] = bload1(ms, ((2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 32 + n) * 4);         \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+    }                                                                                           \
+    if (MASK == 2) {                                                                            \
+      const __amdgpu_buffer_rsrc_t ms = rsrc((const unsigned*)msk + (long)(b * H + min(yi, H - 1)) * W, obytes / 32); \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                         \
+        mreg[rr] = bload1(ms, (2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 4);                    \
       __builtin_amdgcn_sched_barrier(0);                                                        \
     }                                                                                           \
     f32x16 acc;                                                                                 \
@@ -310,7 +335,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
     const __amdgpu_buffer_rsrc_t os = rsrc(dx + orow, obytes);                                  \
     _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                         \
       float v = acc[rr];                                                                        \
-      if (MASK) v = (mreg[rr] > 0.f) ? v : 0.f;                                                 \
+      if (MASK == 1) v = (mreg[rr] > 0.f) ? v : 0.f;                                            \
+      if (MASK == 2) v = ((__builtin_bit_cast(unsigned, mreg[rr]) >> n) & 1u) ? v : 0.f;        \
       bstore1(os, ((2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 32 + n) * 4, v);                  \
     }                                                                                           \
   }
@@ -556,7 +582,7 @@ int resident_grid(const dd_conv_desc* d, long row_tiles, int wpb, int per_cu) {
 
 template <int CIN, int S, int EPI, int WPB>
 int launch_fwd(const float* x, const float* wp, const float* bias, const float* msk, float* y, const dd_conv_desc* d,
-               hipStream_t st) {
+               hipStream_t st, unsigned* bits_out = nullptr) {
   using C = StripCfg<CIN, S>;
   const int Ho = dd_conv_out(d->height, S), Wo = dd_conv_out(d->width, S);
   const int nstrips = (Wo + 31) / 32;
@@ -565,8 +591,8 @@ int launch_fwd(const float* x, const float* wp, const float* bias, const float* 
   const int grid = resident_grid(d, (long)d->batch * nstrips * Ho, WPB, per_cu);
   auto k = conv_strip_fwd<CIN, S, EPI, WPB>;
   if (int rc = allow_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, wp, bias, msk, y, d->batch, d->height, d->width, Ho, Wo,
-                     nstrips);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, wp, bias, msk, y, bits_out, d->batch, d->height, d->width,
+                     Ho, Wo, nstrips);
   DD_LAUNCH_CHECK("conv_strip_fwd");
   return 0;
 }
@@ -614,16 +640,41 @@ int dd_conv_fwd(const float* x, const float* packed_fwd, const float* bias, cons
 #undef DD_DISPATCH
 }
 
+int dd_conv_fwd_relu_bits(const float* x, const float* packed_fwd, const float* bias, float* y, uint32_t* relu_bits,
+                          const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && packed_fwd && bias && y && relu_bits, DD_ERR_BAD_ARG, "conv_fwd_relu_bits: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->cin_store == 4) return launch_fwd<4, 1, EPI_BIAS_RELU_BITS, 8>(x, packed_fwd, bias, nullptr, y, d, st, relu_bits);
+  if (d->stride == 1) return launch_fwd<32, 1, EPI_BIAS_RELU_BITS, 8>(x, packed_fwd, bias, nullptr, y, d, st, relu_bits);
+  return launch_fwd<32, 2, EPI_BIAS_RELU_BITS, 4>(x, packed_fwd, bias, nullptr, y, d, st, relu_bits);
+}
+
+static int conv_dgrad_impl(const float* dy, const float* packed_dgrad, const float* relu_src, int mask_mode, float* dx,
+                           const dd_conv_desc* d, void* stream);
+
 int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_src, float* dx, const dd_conv_desc* d,
                   void* stream) {
+  return conv_dgrad_impl(dy, packed_dgrad, relu_src, relu_src ? 1 : 0, dx, d, stream);
+}
+
+int dd_conv_dgrad_relu_bits(const float* dy, const float* packed_dgrad, const uint32_t* relu_bits, float* dx,
+                            const dd_conv_desc* d, void* stream) {
+  DD_REQUIRE(relu_bits, DD_ERR_BAD_ARG, "conv_dgrad_relu_bits: NULL mask");
+  return conv_dgrad_impl(dy, packed_dgrad, (const float*)relu_bits, 2, dx, d, stream);
+}
+
+static int conv_dgrad_impl(const float* dy, const float* packed_dgrad, const float* relu_src, int mask_mode, float* dx,
+                           const dd_conv_desc* d, void* stream) {
   if (int rc = check_desc(d)) return rc;
   DD_REQUIRE(dy && packed_dgrad && dx, DD_ERR_BAD_ARG, "conv_dgrad: NULL pointer");
   DD_REQUIRE(d->cin_real == 32, DD_ERR_UNSUPPORTED, "conv_dgrad: Cin %d (the first layer has no data gradient)", d->cin_real);
   hipStream_t st = (hipStream_t)stream;
   if (d->stride == 1) {
     // a stride-1 k3 p1 data gradient IS a k3 p1 convolution of dy with the flipped / transposed weights
-    return relu_src ? launch_fwd<32, 1, DD_EPI_RELU_MASK, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st)
-                    : launch_fwd<32, 1, DD_EPI_NONE, 8>(dy, packed_dgrad, nullptr, nullptr, dx, d, st);
+    if (mask_mode == 2) return launch_fwd<32, 1, EPI_RELU_BITS, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st);
+    return mask_mode ? launch_fwd<32, 1, DD_EPI_RELU_MASK, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st)
+                     : launch_fwd<32, 1, DD_EPI_NONE, 8>(dy, packed_dgrad, nullptr, nullptr, dx, d, st);
   }
   using C = StripCfg<32, 1>;
   constexpr int WPB = 8;
@@ -632,13 +683,18 @@ int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_
   const int nstrips = (ns + 31) / 32;
   const size_t lds = C::WFLOATS * 4 + (size_t)WPB * C::WAVEB;
   const int grid = resident_grid(d, (long)d->batch * nstrips * nr, WPB, 1);
-  if (relu_src) {
-    auto k = conv_s2_dgrad<WPB, true>;
+  if (mask_mode == 2) {
+    auto k = conv_s2_dgrad<WPB, 2>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
+                       nstrips);
+  } else if (mask_mode == 1) {
+    auto k = conv_s2_dgrad<WPB, 1>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
                        nstrips);
   } else {
-    auto k = conv_s2_dgrad<WPB, false>;
+    auto k = conv_s2_dgrad<WPB, 0>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
                        nstrips);

@@ -129,6 +129,27 @@ def conv_fwd(x, packed, bias, desc, epilogue=EPI_BIAS_RELU, mask=None):
     return y
 
 
+def conv_fwd_bits(x, packed, bias, desc):
+    """relu(conv(x) + bias) plus the ReLU signs as one uint32 per pixel (bit c = channel c is positive)."""
+    ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
+    _dev(x, "x", (desc.batch, desc.height, desc.width, desc.cin_store))
+    _dev(bias, "bias", (32,))
+    y = torch.empty((desc.batch, ho, wo, 32), device=x.device, dtype=torch.float32)
+    bits = torch.empty((desc.batch, ho, wo), device=x.device, dtype=torch.int32)
+    check(_lib.lib().dd_conv_fwd_relu_bits(_p(x), _p(packed), _p(bias), _p(y), _p(bits), C.byref(desc), _stream()), "dd_conv_fwd_relu_bits")
+    return y, bits
+
+
+def conv_dgrad_bits(dy, packed_dgrad, bits, desc):
+    ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
+    _dev(dy, "dy", (desc.batch, ho, wo, 32))
+    if not (bits.is_cuda and bits.dtype == torch.int32 and bits.is_contiguous() and tuple(bits.shape) == (desc.batch, desc.height, desc.width)):
+        raise _lib.HotpathError("conv_dgrad_bits: relu_bits must be a contiguous int32 [B,H,W] device tensor")
+    dx = torch.empty((desc.batch, desc.height, desc.width, 32), device=dy.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_dgrad_relu_bits(_p(dy), _p(packed_dgrad), _p(bits), _p(dx), C.byref(desc), _stream()), "dd_conv_dgrad_relu_bits")
+    return dx
+
+
 def conv_dgrad(dy, packed_dgrad, relu_src, desc):
     ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
     _dev(dy, "dy", (desc.batch, ho, wo, 32))
@@ -208,10 +229,11 @@ class EncoderConvStack(torch.autograd.Function):
         d1 = conv_desc(b, h, w, 3, 1, rows_per_task)
         d2 = conv_desc(b, h, w, 32, 1, rows_per_task)
         d3 = conv_desc(b, h, w, 32, 2, rows_per_task)
-        a1 = conv_fwd(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
-        a2 = conv_fwd(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
+        # c1 / c2 also emit their ReLU signs as bit planes (60 MB instead of 1.9 GB to re-read in the backward)
+        a1, s1 = conv_fwd_bits(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
+        a2, s2 = conv_fwd_bits(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
         a3 = conv_fwd(a2, conv_pack(w3, d3, PACK_FWD), b3, d3)
-        ctx.save_for_backward(x4, a1, a2, a3, w2, w3)
+        ctx.save_for_backward(x4, a1, a2, a3, w2, w3, s1, s2)
         ctx.pool = int(pool)                  # 0: conv feature, 1: pooled vector, 2: both (joint roadmap + box model)
         ctx.rows_per_task = rows_per_task
         if ctx.pool == 2:
@@ -222,7 +244,7 @@ class EncoderConvStack(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad, grad_pooled=None):
-        x4, a1, a2, a3, w2, w3 = ctx.saved_tensors
+        x4, a1, a2, a3, w2, w3, s1, s2 = ctx.saved_tensors
         b, h, w, _ = x4.shape
         rpt = ctx.rows_per_task
         d1, d2, d3 = conv_desc(b, h, w, 3, 1, rpt), conv_desc(b, h, w, 32, 1, rpt), conv_desc(b, h, w, 32, 2, rpt)
@@ -240,14 +262,14 @@ class EncoderConvStack(torch.autograd.Function):
         dw3, db3 = conv_wgrad(a2, g3, d3) if (need[5] or need[6]) else (None, None)
         dw2 = db2 = dw1 = db1 = None
         if need[1] or need[2] or need[3] or need[4]:
-            g2 = conv_dgrad(g3, conv_pack(w3, d3, PACK_DGRAD_S2), a2, d3)
+            g2 = conv_dgrad_bits(g3, conv_pack(w3, d3, PACK_DGRAD_S2), s2, d3)
             del g3
             for hook in MFMA_PHASE_HOOKS:
                 hook()
             if need[3] or need[4]:
                 dw2, db2 = conv_wgrad(a1, g2, d2)
             if need[1] or need[2]:
-                g1 = conv_dgrad(g2, conv_pack(w2, d2, PACK_DGRAD_S1), a1, d2)
+                g1 = conv_dgrad_bits(g2, conv_pack(w2, d2, PACK_DGRAD_S1), s1, d2)
                 del g2
                 dw1, db1 = conv_wgrad(x4, g1, d1)
         return None, dw1, db1, dw2, db2, dw3, db3, None, None

@@ -96,6 +96,15 @@ int dd_conv_fwd(const float* x, const float* packed_fwd, const float* bias, cons
 int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_src, float* dx,
                   const dd_conv_desc* d, void* stream);
 
+/* The ReLU sign as ONE BIT per activation: dd_conv_fwd_relu_bits = dd_conv_fwd(DD_EPI_BIAS_RELU) that also writes
+ * relu_bits[B,Ho,Wo] (uint32: bit c = y[..., c] > 0); dd_conv_dgrad_relu_bits = dd_conv_dgrad whose fused ReLU mask
+ * is read from such a bit plane (4 bytes per pixel instead of 128): the HBM-bound stride-2 data gradient stops
+ * re-reading a 1.9 GB activation only for its signs. */
+int dd_conv_fwd_relu_bits(const float* x, const float* packed_fwd, const float* bias, float* y, uint32_t* relu_bits,
+                          const dd_conv_desc* d, void* stream);
+int dd_conv_dgrad_relu_bits(const float* dy, const float* packed_dgrad, const uint32_t* relu_bits, float* dx,
+                            const dd_conv_desc* d, void* stream);
+
 /* dw_oihw[32,cin_real,3,3], dbias[32] from x[B,H,W,cin_store] and dy[B,Ho,Wo,32]
  * (dy already multiplied by this layer's ReLU mask).  Deterministic: per-wave partial sums
  * in `workspace`, then a fixed-order reduction. */

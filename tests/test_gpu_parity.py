@@ -86,6 +86,15 @@ def test_conv_fwd_dgrad_wgrad(dev, b, h, w, cin, stride, rows):
         xm = (x.detach() - 0.5).float()
         dxm = ops.conv_dgrad(g, ops.conv_pack(wd, desc, kind), nhwc(xm).to(dev), desc)
         assert rel_err(dxm.permute(0, 3, 1, 2), x.grad * (xm > 0)) < KERNEL_TOL
+        # the same mask as a bit plane (one uint32 per pixel), as the forward's *_relu_bits variant writes it
+        bits = ((xm > 0).long() << torch.arange(32).view(1, 32, 1, 1)).sum(1)
+        bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32).to(dev)
+        dxb = ops.conv_dgrad_bits(g, ops.conv_pack(wd, desc, kind), bits, desc)
+        assert torch.equal(dxb, dxm)
+    yb, sb = ops.conv_fwd_bits(x_nhwc, ops.conv_pack(wd, desc, ops.PACK_FWD), bd, desc)
+    assert torch.equal(yb, y)
+    want = ((y > 0).long() << torch.arange(32, device=dev)).sum(-1)
+    assert torch.equal(sb.long() & 0xFFFFFFFF, want)
 
 
 def test_conv_refuses_unsupported(dev):
