@@ -63,19 +63,19 @@ class KernelTimer:
 
     def install(self):
         from driving_dirty_amd import ops
-        inner = ops.conv_fwd
+        inner = ops.conv_fwd_bits            # the encoder stack runs c1 / c2 through the *_relu_bits forward
 
-        def timed(x, packed, bias, desc, epilogue=ops.EPI_BIAS_RELU, mask=None):
-            hot = self.enabled and desc.cin_real == 32 and desc.stride == 1 and epilogue == ops.EPI_BIAS_RELU
+        def timed(x, packed, bias, desc):
+            hot = self.enabled and desc.cin_real == 32 and desc.stride == 1
             if not hot:
-                return inner(x, packed, bias, desc, epilogue, mask)
+                return inner(x, packed, bias, desc)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = inner(x, packed, bias, desc, epilogue, mask)
+            out = inner(x, packed, bias, desc)
             e.record()
             self.pairs.append((s, e))
-            return y
-        ops.conv_fwd = timed
+            return out
+        ops.conv_fwd_bits = timed
 
     def mean_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
@@ -219,6 +219,7 @@ def main():
         ms = dt / a.steps * 1e3
         value = world * BATCH * a.steps / dt
         k_ms = timer.mean_ms()
+        assert timer.pairs, "the dominant kernel was never launched through the timed entry point"
         achieved = C2_FLOP_PER_SCENE * BATCH / (k_ms * 1e-3) / 1e12
         line = {
             "metric": "6-view scenes/sec fwd+bwd, roadmap model bs=32",

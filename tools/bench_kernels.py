@@ -54,12 +54,13 @@ def main():
     d1, d2, d3 = (ops.conv_desc(b, h, w, 3, 1, a.rows), ops.conv_desc(b, h, w, 32, 1, a.rows),
                   ops.conv_desc(b, h, w, 32, 2, a.rows))
     px, pxo = b * h * w, b * ho * wo
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (b, h, w), device=dev, dtype=torch.int32)
     cases = [
         ("c1_fwd", lambda: ops.conv_fwd(x4, ops.conv_pack(w1, d1, 0), bias, d1), 2 * px * 32 * 27, px * (16 + 128)),
-        ("c2_fwd", lambda: ops.conv_fwd(a1, ops.conv_pack(w2, d2, 0), bias, d2), 2 * px * 32 * 288, px * 256),
+        ("c2_fwd", lambda: ops.conv_fwd_bits(a1, ops.conv_pack(w2, d2, 0), bias, d2), 2 * px * 32 * 288, px * 256),
         ("c3_fwd", lambda: ops.conv_fwd(a1, ops.conv_pack(w2, d3, 0), bias, d3), 2 * pxo * 32 * 288, px * 128 + pxo * 128),
-        ("c2_dgrad", lambda: ops.conv_dgrad(g, ops.conv_pack(w2, d2, 1), a1, d2), 2 * px * 32 * 288, px * 384),
-        ("c3_dgrad", lambda: ops.conv_dgrad(g3, ops.conv_pack(w2, d3, 2), a1, d3), 2 * pxo * 32 * 288, pxo * 128 + px * 256),
+        ("c2_dgrad", lambda: ops.conv_dgrad_bits(g, ops.conv_pack(w2, d2, 1), bits, d2), 2 * px * 32 * 288, px * 260),
+        ("c3_dgrad", lambda: ops.conv_dgrad_bits(g3, ops.conv_pack(w2, d3, 2), bits, d3), 2 * pxo * 32 * 288, pxo * 128 + px * 132),
         ("c1_wgrad", lambda: ops.conv_wgrad(x4, g, d1), 2 * px * 32 * 27, px * (16 + 128)),
         ("c2_wgrad", lambda: ops.conv_wgrad(a1, g, d2), 2 * px * 32 * 288, px * 256),
         ("c3_wgrad", lambda: ops.conv_wgrad(a1, g3, d3), 2 * pxo * 32 * 288, px * 128 + pxo * 128),

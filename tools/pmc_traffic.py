@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-KERNEL = "conv_strip_fwd<32, 1, 2, 8>"      # c2 forward (CIN=32, S=1, EPI=BIAS_RELU, 8 waves)
+KERNEL = "conv_strip_fwd<32, 1, 5, 8>"      # c2 forward (CIN=32, S=1, EPI=BIAS_RELU+sign bits, 8 waves)
 
 
 def per_launch(directory, counter):
