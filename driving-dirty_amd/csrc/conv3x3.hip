@@ -223,6 +223,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
       // epilogue: lane = output channel, register = pixel -> 128 contiguous bytes per pixel per store;
       // pixels right of the image fall outside the row descriptor and are dropped by the hardware
       const __amdgpu_buffer_rsrc_t ys = rsrc(y + orow, Wo * 128);
+      unsigned sign_word = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
@@ -232,12 +233,17 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
         if (EPI == EPI_RELU_BITS) v = ((__builtin_bit_cast(unsigned, mreg[r]) >> n) & 1u) ? v : 0.f;
         bstore1(ys, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4, v);
         if (EPI == EPI_BIAS_RELU_BITS) {
-          // lanes 0-31 hold the 32 channels of pixel i, lanes 32-63 those of pixel i+4: one ballot = two mask words
+          // lanes 0-31 hold the 32 channels of pixel i = (r&3)+8(r>>2), lanes 32-63 those of pixel i+4: one ballot =
+          // two mask words.  Lane p (< 32) keeps the word of strip pixel p, so the row's 32 words leave as ONE store.
           const unsigned long long m = __ballot(v > 0.f);
-          const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + (long)(b * Ho + yy) * Wo, Wo * 4);
-          const unsigned word = h ? (unsigned)(m >> 32) : (unsigned)m;
-          __builtin_amdgcn_raw_buffer_store_b32(word, bs, (n == 0) ? (x0 + dd_acc_row(r, lane)) * 4 : -16, 0, 0);
+          const int i0 = (r & 3) + 8 * (r >> 2);
+          if (n == i0) sign_word = (unsigned)m;
+          if (n == i0 + 4) sign_word = (unsigned)(m >> 32);
         }
+      }
+      if (EPI == EPI_BIAS_RELU_BITS) {
+        const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + (long)(b * Ho + yy) * Wo, Wo * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(sign_word, bs, (h == 0) ? (x0 + n) * 4 : -16, 0, 0);
       }
     }
   }
