@@ -147,10 +147,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
+    ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("DD_RESERVED_CUS", "16"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -172,6 +175,14 @@ def main():
     from driving_dirty_amd.ddp import GradSync
     from driving_dirty_amd.optim import HipAdam
     _lib.lib()                                            # fail loudly if the HIP library is missing
+    if world > 1:
+        # RCCL's all-reduce workgroups run for milliseconds beside the conv backward and need LDS the conv workgroups
+        # do not leave free: give them their own compute units (and cap RCCL at as many channels) so the conv grids
+        # stay one resident round.  DD_RESERVED_CUS overrides.
+        reserve = int(os.environ.get("DD_RESERVED_CUS", "16"))
+        _lib.check(_lib.lib().dd_set_cu_budget(256 - reserve), "dd_set_cu_budget")
+    if a.cu_budget:
+        _lib.check(_lib.lib().dd_set_cu_budget(a.cu_budget), "dd_set_cu_budget")
 
     model = build_model(dev)
     model.ae.encoder.rows_per_task = a.rows_per_task

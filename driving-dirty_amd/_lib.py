@@ -34,6 +34,8 @@ _GP = C.POINTER(GConvDesc)
 SIGNATURES = {
     "dd_abi_version": (_i32, []),
     "dd_last_error": (C.c_char_p, []),
+    "dd_set_cu_budget": (_i32, [_i32]),
+    "dd_get_cu_budget": (_i32, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

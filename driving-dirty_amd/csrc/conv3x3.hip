@@ -581,7 +581,7 @@ int check_desc(const dd_conv_desc* d) {
 // of the instantiation), fewer when the problem has fewer wave-sized pieces.  rows_per_task (a testing / tuning
 // knob, never changes results) asks for at least that many rows per wave, i.e. fewer and longer ranges.
 int resident_grid(const dd_conv_desc* d, long row_tiles, int wpb, int per_cu) {
-  long blocks = (long)DD_NUM_CU * per_cu;
+  long blocks = (long)dd_cu_budget_internal() * per_cu;
   if (d->rows_per_task > 0) blocks = min(blocks, max(1L, row_tiles / d->rows_per_task / wpb));
   return (int)max(1L, min(blocks, (row_tiles + wpb - 1) / wpb));
 }

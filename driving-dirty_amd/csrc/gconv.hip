@@ -454,7 +454,7 @@ WgradPlan wgrad_plan(const dd_gconv_desc* d) {
   p.njg = (p.nj + p.nb - 1) / p.nb;
   p.njobs = p.nto * p.njg;
   const long tiles = (long)d->batch * ((d->out_w + 31) / 32) * d->out_h;
-  const long waves = 2L * DD_NUM_CU * 4;   // two 4-wave workgroups per CU
+  const long waves = 2L * dd_cu_budget_internal() * 4;   // two 4-wave workgroups per CU
   p.nranges = (int)max(1L, min(tiles, waves / p.njobs));
   p.blocks = (p.nranges * p.njobs + 3) / 4;
   return p;
@@ -494,7 +494,7 @@ int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const f
   const int ng = groups_of(d), nt = (d->cout + 31) / 32;
   const bool div = d->div_h > 1 || d->div_w > 1;
   const long tiles = (long)d->batch * ((d->out_w + 31) / 32) * d->out_h;
-  const int grid = (int)max(1L, min((long)DD_NUM_CU, (tiles + 7) / 8));   // one 8-wave workgroup per CU, all resident
+  const int grid = (int)max(1L, min((long)dd_cu_budget_internal(), (tiles + 7) / 8));   // one 8-wave workgroup per CU, all resident
   const size_t lds = (size_t)2 * ng * sizeof(int2);
   DD_REQUIRE(lds <= 64 * 1024, DD_ERR_UNSUPPORTED, "gconv_fwd: tap table of %zu bytes", lds);
 #define DD_GF(NT, DIV) hipLaunchKernelGGL((gconv_fwd_kernel<NT, DIV>), dim3(grid), dim3(512), lds, st, x, packed, bias, mask, y, *d, ng, epilogue)

@@ -14,7 +14,18 @@ int dd_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+static int g_cu_budget = DD_NUM_CU;
+
+int dd_cu_budget_internal() { return g_cu_budget; }
+
 extern "C" {
 int dd_abi_version(void) { return DD_ABI_VERSION; }
+
+int dd_set_cu_budget(int32_t compute_units) {
+  DD_REQUIRE(compute_units >= 1 && compute_units <= DD_NUM_CU, DD_ERR_BAD_ARG, "set_cu_budget: %d not in 1..%d", compute_units, DD_NUM_CU);
+  g_cu_budget = compute_units;
+  return 0;
+}
+int dd_get_cu_budget(void) { return g_cu_budget; }
 const char* dd_last_error(void) { return g_err; }
 }

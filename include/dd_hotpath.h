@@ -57,6 +57,15 @@ typedef struct dd_conv_desc {
 int dd_abi_version(void);
 const char* dd_last_error(void);
 
+/* The conv kernels launch exactly as many workgroups as fit on the chip at once and give every wave an equal,
+ * contiguous share of the work.  When another kernel must run BESIDE them for milliseconds (the RCCL all-reduce
+ * of data-parallel training: its workgroups need LDS the conv workgroups do not leave free), hand it a few
+ * compute units: with fewer than 256 the conv grids shrink accordingly instead of spilling into a second round.
+ * Process-wide; 1..256 (default 256).  Never changes results (weight-gradient partial sums are reduced in a fixed
+ * order for any grid). */
+int dd_set_cu_budget(int32_t compute_units);
+int dd_get_cu_budget(void);
+
 /* ---- layout: 6-view gather (K4) --------------------------------------------------
  * views [B,6,3,H,W] fp32 -> wide NHWC4 image [B,H,6W,4] with the reference's view order
  * [0,1,2,5,4,3] (roadmap_bce_v2.py:58-62, autoencoder.py:55-57); channel 3 is zero.

@@ -397,3 +397,26 @@ def test_stitch6_uint8_pipeline(dev):
     out = ops.stitch6_u8(frames.to(dev))
     assert torch.allclose(out[..., :3].permute(0, 3, 1, 2).cpu(), ref, rtol=0, atol=1e-7)
     assert float(out[..., 3].abs().max()) == 0.0
+
+
+def test_cu_budget_never_changes_results(dev):
+    """dd_set_cu_budget shrinks the resident grids (room for RCCL beside the conv backward): same numbers."""
+    from driving_dirty_amd import _lib, ops
+    b, h, w = 2, 40, 300
+    d = ops.conv_desc(b, h, w, 32, 1)
+    x = hu((b, h, w, 32), "cux").to(dev)
+    wt = hu((32, 32, 3, 3), "cuw", -0.2, 0.2).to(dev)
+    bias = hu((32,), "cub").to(dev)
+    g = hu((b, h, w, 32), "cug").to(dev)
+    outs = []
+    try:
+        for budget in (256, 7):
+            _lib.check(_lib.lib().dd_set_cu_budget(budget), "budget")
+            y = ops.conv_fwd(x, ops.conv_pack(wt, d, 0), bias, d)
+            dx = ops.conv_dgrad(g, ops.conv_pack(wt, d, 1), x, d)
+            dw, db = ops.conv_wgrad(x, g, d)
+            outs.append((y, dx, dw, db))
+    finally:
+        _lib.lib().dd_set_cu_budget(256)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_err(outs[1][2], outs[0][2]) < 1e-5 and rel_err(outs[1][3], outs[0][3]) < 1e-5
