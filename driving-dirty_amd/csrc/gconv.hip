@@ -43,7 +43,7 @@ template <int NT, bool DIV>
 __global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ bias, const float* __restrict__ msk,
                                                         float* __restrict__ y, const dd_gconv_desc d, int ngroups,
-                                                        int epi) {
+                                                        int epi, int spt) {
   extern __shared__ __attribute__((aligned(16))) int2 tab[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,16 +103,45 @@ __global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict_
     acc[nt] = DD_MFMA(A[u].z, Bw[u][nt].z, acc[nt]);                                                 \
     acc[nt] = DD_MFMA(A[u].w, Bw[u][nt].w, acc[nt]);                                                 \
   }
-    DD_LOAD_SET(0, A0, B0)
-    for (int g = 0; g < ngroups; g += 2 * GU) {   // ngroups is a multiple of GU
-      const bool more1 = g + GU < ngroups, more2 = g + 2 * GU < ngroups;
-      if (more1) { DD_LOAD_SET(g + GU, A1, B1) }
-      __builtin_amdgcn_sched_barrier(0);          // set k+1 is requested before set k is multiplied
-      DD_COMPUTE_SET(A0, B0)
-      if (more2) { DD_LOAD_SET(g + 2 * GU, A0, B0) }
-      __builtin_amdgcn_sched_barrier(0);
-      if (more1) { DD_COMPUTE_SET(A1, B1) }
+    // Taps whose input row lies outside the image, or whose input columns lie outside it for ALL 32 pixels of the
+    // strip, contribute nothing: they are skipped for the whole wave (a flipped-tap transposed conv with
+    // pad = d(k-1) would otherwise spend (out/in)^2 - 1 = 26..36 % of its MFMAs on zeros).  Possible when a pipeline
+    // set (GU chunk pairs) never straddles two taps: spt = sets per tap.
+    int ky0 = 0, ky1 = d.kh - 1, kx0 = 0, kx1 = d.kw - 1;
+    if (!DIV && spt > 0) {
+      const int ry = yo * d.stride_h - d.pad_h;                       // input row of tap ky = ry + ky*dil_h
+      ky0 = ry >= 0 ? 0 : (-ry + d.dil_h - 1) / d.dil_h;
+      ky1 = min(d.kh - 1, (d.in_h - 1 - ry) >= 0 ? (d.in_h - 1 - ry) / d.dil_h : -1);
+      const int xlo = x0 * d.stride_w - d.pad_w;                      // leftmost / rightmost pixel of the strip
+      const int xhi = min(x0 + 31, d.out_w - 1) * d.stride_w - d.pad_w;
+      kx0 = xhi >= 0 ? 0 : (-xhi + d.dil_w - 1) / d.dil_w;
+      kx1 = min(d.kw - 1, (d.in_w - 1 - xlo) >= 0 ? (d.in_w - 1 - xlo) / d.dil_w : -1);
     }
+    const int nky = max(ky1 - ky0 + 1, 0), nkx = max(kx1 - kx0 + 1, 0);
+    const int per_tap = spt > 0 ? spt : (ngroups / GU);               // spt == 0: one "tap" = all sets, no skipping
+    const int nsets = spt > 0 ? nky * nkx * spt : per_tap;
+    // iterator over the valid sets: (ky, kx, cs) -> first group of the set
+    int it_ky = ky0, it_kx = kx0, it_cs = 0;
+#define DD_NEXT_SET(G)                                                                               \
+  {                                                                                                  \
+    G = (spt > 0 ? ((it_ky * d.kw + it_kx) * spt + it_cs) : it_cs) * GU;                             \
+    if (++it_cs == per_tap) { it_cs = 0; if (++it_kx > kx1) { it_kx = kx0; ++it_ky; } }              \
+  }
+    if (nsets > 0) {
+      int g;
+      DD_NEXT_SET(g)
+      DD_LOAD_SET(g, A0, B0)
+      for (int i = 0; i < nsets; i += 2) {
+        const bool more1 = i + 1 < nsets, more2 = i + 2 < nsets;
+        if (more1) { DD_NEXT_SET(g) DD_LOAD_SET(g, A1, B1) }
+        __builtin_amdgcn_sched_barrier(0);          // set k+1 is requested before set k is multiplied
+        DD_COMPUTE_SET(A0, B0)
+        if (more2) { DD_NEXT_SET(g) DD_LOAD_SET(g, A0, B0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) { DD_COMPUTE_SET(A1, B1) }
+      }
+    }
+#undef DD_NEXT_SET
 #undef DD_LOAD_SET
 #undef DD_COMPUTE_SET
 
@@ -153,17 +182,17 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, float* __restrict
 // ---------------------------------------------------------------------------------------------- weight gradient
 // One wave = one 32-channel slice of dy (A operand) x NB column tiles of the (tap, cin) space (B operand), over a
 // contiguous range of output row tiles; waves of a workgroup share the range so dy comes out of L1.
-template <int NB>
+template <int NO, int NB>
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ part, float* __restrict__ bpart,
-                                                          const dd_gconv_desc d, int njg, int nto, int nranges) {
+                                                          const dd_gconv_desc d, int njg, int nog, int nranges) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
-  const int njobs = nto * njg;
+  const int njobs = nog * njg;
   const int job = gw % njobs, range = gw / njobs;
   if (range >= nranges) return;
-  const int ot = job / njg, jg = job - ot * njg;
+  const int og = job / njg, jg = job - og * njg;
   const int h = lane >> 5, n = lane & 31;
   const int J = d.kh * d.kw * d.cin;
 
@@ -183,12 +212,16 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restric
       chan[k] = 0;
     }
   }
-  f32x16 acc[NB];
+  f32x16 acc[NO][NB];
 #pragma unroll
-  for (int k = 0; k < NB; ++k)
+  for (int a = 0; a < NO; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-  float bsum = 0.f;
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][k][r] = 0.f;
+  float bsum[NO];
+#pragma unroll
+  for (int a = 0; a < NO; ++a) bsum[a] = 0.f;
 
   const int nstrips = (d.out_w + 31) / 32;
   const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
@@ -202,12 +235,13 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restric
     const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)b * d.in_h * d.in_w * d.in_cstore, in_bytes);
     const __amdgpu_buffer_rsrc_t gs = dd_rsrc(dy + (long)b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {   // 8 pixel pairs at a time: 8 x (1 + NB) loads in flight, then 8 x NB MFMAs
-      float av[8], bw[8][NB];
+    for (int half = 0; half < 2; ++half) {   // 8 pixel pairs at a time: 8 x (NO + NB) loads in flight, then 8 x NO x NB MFMAs
+      float av[8][NO], bw[8][NB];
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int xo = x0 + 2 * (half * 8 + s) + h;
-        av[s] = dd_bload1(gs, out_offset(d, yo, xo, ot * 32 + n));
+#pragma unroll
+        for (int a = 0; a < NO; ++a) av[s][a] = dd_bload1(gs, out_offset(d, yo, xo, (og * NO + a) * 32 + n));
 #pragma unroll
         for (int k = 0; k < NB; ++k)
           bw[s][k] = dd_bload1(xs, gather_offset<false>(d, yo, xo, rowoff[k], coloff[k], chan[k]));   // av = 0 beyond out_w
@@ -215,25 +249,32 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restric
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        bsum += av[s];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) acc[k] = DD_MFMA(av[s], bw[s][k], acc[k]);
+        for (int a = 0; a < NO; ++a) {
+          bsum[a] += av[s][a];
+#pragma unroll
+          for (int k = 0; k < NB; ++k) acc[a][k] = DD_MFMA(av[s][a], bw[s][k], acc[a][k]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < NB; ++k)
+  for (int a = 0; a < NO; ++a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[((((long)range * njobs + job) * NB + k) * 16 + r) * 64 + lane] = acc[k][r];
-  if (jg == 0) bpart[((long)range * nto + ot) * 64 + lane] = bsum;
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        part[(((((long)range * njobs + job) * NO + a) * NB + k) * 16 + r) * 64 + lane] = acc[a][k][r];
+    if (jg == 0) bpart[((long)range * nog * NO + og * NO + a) * 64 + lane] = bsum[a];
+  }
 }
 
 // dw[w_off + o*sn + c*sc + tap'] (+)= sum over ranges; one thread per accumulator element.
 __global__ __launch_bounds__(256) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
-                                                          int nranges, int njobs, int nb, int njg, int T, int cin,
+                                                          int nranges, int njobs, int no, int nb, int njg, int T, int cin,
                                                           long w_off, long sn, long sc, int flip, int n_real, int c_real,
                                                           int accumulate) {
-  const long per = (long)njobs * nb * 1024;
+  const long per = (long)njobs * no * nb * 1024;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= per) return;
   float s0 = 0.f, s1 = 0.f;
@@ -246,9 +287,9 @@ __global__ __launch_bounds__(256) void gconv_wgrad_reduce(const float* __restric
   const float s = s0 + s1;
   const int lane = e & 63, reg = (e >> 6) & 15;
   const long jk = e >> 10;
-  const int k = (int)(jk % nb), job = (int)(jk / nb);
-  const int ot = job / njg, jg = job - ot * njg;
-  const int o = ot * 32 + dd_acc_row(reg, lane);
+  const int k = (int)(jk % nb), a = (int)((jk / nb) % no), job = (int)(jk / ((long)nb * no));
+  const int og = job / njg, jg = job - og * njg;
+  const int o = (og * no + a) * 32 + dd_acc_row(reg, lane);
   const int j = (jg * nb + k) * 32 + (lane & 31);
   if (j >= T * cin) return;
   const int tap = j / cin, c = j - tap * cin;
@@ -409,15 +450,15 @@ __global__ __launch_bounds__(256) void deconv2x2_c1_reduce(const float* __restri
   if (i < nvals - 1) dwt[i] = s; else db[0] = s;
 }
 
-int check_gdesc(const dd_gconv_desc* d) {
+int check_gdesc(const dd_gconv_desc* d, int max_cout = 64) {
   DD_REQUIRE(d != nullptr, DD_ERR_BAD_ARG, "gconv: NULL descriptor");
   DD_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->out_h > 0 && d->out_w > 0 && d->omem_h > 0 && d->omem_w > 0,
              DD_ERR_BAD_ARG, "gconv: non-positive size");
   DD_REQUIRE(d->cin > 0 && d->cin % 4 == 0 && d->in_coff % 4 == 0 && d->in_cstore % 4 == 0 && d->in_coff + d->cin <= d->in_cstore,
              DD_ERR_UNSUPPORTED, "gconv: input channel slice [%d,+%d) of %d must be 4-aligned", d->in_coff, d->cin, d->in_cstore);
   DD_REQUIRE(d->in_cstore < 1024, DD_ERR_UNSUPPORTED, "gconv: more than 1020 stored input channels");
-  DD_REQUIRE(d->cout > 0 && d->cout <= 64 && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_cstore, DD_ERR_UNSUPPORTED,
-             "gconv: output channel slice [%d,+%d) of %d (Cout <= 64)", d->out_coff, d->cout, d->out_cstore);
+  DD_REQUIRE(d->cout > 0 && d->cout <= max_cout && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_cstore, DD_ERR_UNSUPPORTED,
+             "gconv: output channel slice [%d,+%d) of %d (Cout <= %d)", d->out_coff, d->cout, d->out_cstore, max_cout);
   DD_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->div_h > 0 &&
                  d->div_w > 0 && d->ostride_h > 0 && d->ostride_w > 0 && d->ooff_h >= 0 && d->ooff_w >= 0,
              DD_ERR_BAD_ARG, "gconv: bad kernel geometry");
@@ -435,29 +476,57 @@ int groups_of(const dd_gconv_desc* d) {
   return (g + GU - 1) / GU * GU;
 }
 
-int pick_nb(int nj) {
+int pick_nb(int nj, int max_nb) {
   int best = 1, cost = nj;
-  for (int nb = 2; nb <= 4; ++nb) {
+  for (int nb = 2; nb <= max_nb; ++nb) {
     const int c = (nj + nb - 1) / nb * nb;
     if (c <= cost) { cost = c; best = nb; }
   }
   return best;
 }
 
-struct WgradPlan { int nto, nj, nb, njg, njobs, nranges, blocks; };
+// A wave owns NO dy channel tiles x NB (tap, cin) column tiles: NO + NB operand loads feed NO x NB MFMAs.
+struct WgradPlan { int nto, no, nog, nj, nb, njg, njobs, nranges, blocks; };
 
 WgradPlan wgrad_plan(const dd_gconv_desc* d) {
   WgradPlan p;
   p.nto = (d->cout + 31) / 32;
+  p.no = p.nto <= 3 ? p.nto : 2;
+  p.nog = (p.nto + p.no - 1) / p.no;
   p.nj = (d->kh * d->kw * d->cin + 31) / 32;
-  p.nb = pick_nb(p.nj);
+  p.nb = pick_nb(p.nj, p.no == 1 ? 4 : (p.no == 2 ? 3 : 2));
   p.njg = (p.nj + p.nb - 1) / p.nb;
-  p.njobs = p.nto * p.njg;
+  p.njobs = p.nog * p.njg;
   const long tiles = (long)d->batch * ((d->out_w + 31) / 32) * d->out_h;
   const long waves = 2L * dd_cu_budget_internal() * 4;   // two 4-wave workgroups per CU
   p.nranges = (int)max(1L, min(tiles, waves / p.njobs));
   p.blocks = (p.nranges * p.njobs + 3) / 4;
   return p;
+}
+
+// per-channel sum over the pixels of a dense NHWC buffer (bias gradient of a transposed conv whose weight
+// gradient is taken in the role-swapped, waste-free form)
+__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ buf, float* __restrict__ partial,
+                                                           long npix, int cstore, int coff, int cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  float s0 = 0.f, s1 = 0.f;
+  for (long p = gw; p < npix; p += nw) {
+    const float* px = buf + p * cstore + coff;
+    if (lane < cout) s0 += px[lane];
+    if (lane + 64 < cout) s1 += px[lane + 64];
+  }
+  partial[(long)gw * 128 + lane] = s0;
+  partial[(long)gw * 128 + 64 + lane] = s1;
+}
+
+__global__ __launch_bounds__(128) void channel_sum_final(const float* __restrict__ partial, float* __restrict__ out, int nw,
+                                                         int cout, int accumulate) {
+  const int c = threadIdx.x;
+  if (c >= cout) return;
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += partial[(long)w * 128 + c];
+  out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace
@@ -497,7 +566,10 @@ int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const f
   const int grid = (int)max(1L, min((long)dd_cu_budget_internal(), (tiles + 7) / 8));   // one 8-wave workgroup per CU, all resident
   const size_t lds = (size_t)2 * ng * sizeof(int2);
   DD_REQUIRE(lds <= 64 * 1024, DD_ERR_UNSUPPORTED, "gconv_fwd: tap table of %zu bytes", lds);
-#define DD_GF(NT, DIV) hipLaunchKernelGGL((gconv_fwd_kernel<NT, DIV>), dim3(grid), dim3(512), lds, st, x, packed, bias, mask, y, *d, ng, epilogue)
+  // sets (GU chunk pairs) per tap when a set never straddles taps, else 0 = no tap skipping
+  const int pairs_per_tap = d->cin / 8;
+  const int spt = (d->cin % 8 == 0 && pairs_per_tap % GU == 0) ? pairs_per_tap / GU : 0;
+#define DD_GF(NT, DIV) hipLaunchKernelGGL((gconv_fwd_kernel<NT, DIV>), dim3(grid), dim3(512), lds, st, x, packed, bias, mask, y, *d, ng, epilogue, spt)
   if (nt == 1) { if (div) DD_GF(1, true); else DD_GF(1, false); }
   else { if (div) DD_GF(2, true); else DD_GF(2, false); }
 #undef DD_GF
@@ -506,15 +578,15 @@ int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const f
 }
 
 int64_t dd_gconv_wgrad_workspace_bytes(const dd_gconv_desc* d) {
-  if (check_gdesc(d)) return -1;
+  if (check_gdesc(d, 96)) return -1;
   const WgradPlan p = wgrad_plan(d);
-  return ((int64_t)p.nranges * p.njobs * p.nb * 1024 + (int64_t)p.nranges * p.nto * 64) * 4;
+  return ((int64_t)p.nranges * p.njobs * p.no * p.nb * 1024 + (int64_t)p.nranges * p.nog * p.no * 64) * 4;
 }
 
 int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dd_gconv_desc* d, int64_t w_off, int64_t sn,
                    int64_t sc, int32_t flip, int32_t n_real, int32_t c_real, int32_t accumulate, void* workspace,
                    int64_t workspace_bytes, void* stream) {
-  if (int rc = check_gdesc(d)) return rc;
+  if (int rc = check_gdesc(d, 96)) return rc;
   DD_REQUIRE(x && dy && dw && workspace, DD_ERR_BAD_ARG, "gconv_wgrad: NULL pointer");
   DD_REQUIRE(d->div_h == 1 && d->div_w == 1, DD_ERR_UNSUPPORTED, "gconv_wgrad: divisibility mode has no weight gradient");
   DD_REQUIRE(workspace_bytes >= dd_gconv_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "gconv_wgrad: workspace too small");
@@ -522,24 +594,46 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = wgrad_plan(d);
   float* part = (float*)workspace;
-  float* bpart = part + (size_t)p.nranges * p.njobs * p.nb * 1024;
-#define DD_GW(NB) hipLaunchKernelGGL((gconv_wgrad_kernel<NB>), dim3(p.blocks), dim3(256), 0, st, x, dy, part, bpart, *d, p.njg, p.nto, p.nranges)
-  switch (p.nb) {
-    case 1: DD_GW(1); break;
-    case 2: DD_GW(2); break;
-    case 3: DD_GW(3); break;
-    default: DD_GW(4); break;
+  float* bpart = part + (size_t)p.nranges * p.njobs * p.no * p.nb * 1024;
+#define DD_GW(NO, NB) hipLaunchKernelGGL((gconv_wgrad_kernel<NO, NB>), dim3(p.blocks), dim3(256), 0, st, x, dy, part, bpart, *d, p.njg, p.nog, p.nranges)
+  switch (p.no * 10 + p.nb) {
+    case 11: DD_GW(1, 1); break;
+    case 12: DD_GW(1, 2); break;
+    case 13: DD_GW(1, 3); break;
+    case 14: DD_GW(1, 4); break;
+    case 21: DD_GW(2, 1); break;
+    case 22: DD_GW(2, 2); break;
+    case 23: DD_GW(2, 3); break;
+    case 31: DD_GW(3, 1); break;
+    default: DD_GW(3, 2); break;
   }
 #undef DD_GW
   DD_LAUNCH_CHECK("gconv_wgrad");
-  const long per = (long)p.njobs * p.nb * 1024;
-  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, dw, p.nranges, p.njobs, p.nb,
-                     p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
+  const long per = (long)p.njobs * p.no * p.nb * 1024;
+  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, dw, p.nranges, p.njobs, p.no,
+                     p.nb, p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
   DD_LAUNCH_CHECK("gconv_wgrad_reduce");
   if (dbias) {
-    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(256), 0, st, bpart, dbias, p.nranges, p.nto, n_real, accumulate & 2);
+    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(256), 0, st, bpart, dbias, p.nranges, p.nog * p.no, n_real, accumulate & 2);
     DD_LAUNCH_CHECK("gconv_bias_reduce");
   }
+  return 0;
+}
+
+int64_t dd_channel_sum_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 4 * 128 * 4; }
+
+int dd_channel_sum(const float* buf, float* out, int64_t npix, int32_t cstore, int32_t coff, int32_t cout, int32_t accumulate,
+                   void* workspace, void* stream) {
+  DD_REQUIRE(buf && out && workspace && npix > 0 && cstore > 0 && coff >= 0 && cout > 0 && coff + cout <= cstore, DD_ERR_BAD_ARG,
+             "channel_sum: bad argument");
+  DD_REQUIRE(cout <= 128, DD_ERR_UNSUPPORTED, "channel_sum: more than 128 channels");
+  const int grid = (int)min((npix + 3) / 4, (long)DD_NUM_CU);
+  hipLaunchKernelGGL(channel_sum_partial, dim3(grid), dim3(256), 0, (hipStream_t)stream, buf, (float*)workspace, (long)npix, cstore,
+                     coff, cout);
+  DD_LAUNCH_CHECK("channel_sum");
+  hipLaunchKernelGGL(channel_sum_final, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)workspace, out, grid * 4, cout,
+                     accumulate);
+  DD_LAUNCH_CHECK("channel_sum final");
   return 0;
 }
 

@@ -178,10 +178,28 @@ class Layer:
             for ph in range(4):
                 d = _desc(b, src, ddst, cs, self.cout, (1, 1), out_hw=(ih, iw), ostride=(2, 2), ooff=(ph // 2, ph % 2))
                 _wgrad(src.buf, ddst.buf, dw, db, d, ph, 4, self.cout * 4, False, self.cout, self.cin, 2 if ph > 0 else 0)
+        elif self.cin <= 96 and self.cout % 4 == 0 and ddst.off_h == 0 and ddst.off_w == 0:
+            # stride-1 transposed conv, role-swapped: dWt[c][o][t] = sum over INPUT pixels p of x[p][c] * dy[p + t*d - pad][o]
+            # is the weight gradient of the plain conv  dx = conv(dy, Wt)  with x in the role of its output gradient.
+            # Every tap of every pixel is inside dy there, whereas the flipped-tap form spends (out/in)^2 - 1 of its
+            # MFMAs on the zero border.  The bias gradient (sum of dy) then needs its own per-channel sum.
+            d = _desc(b, ddst, src, self.cout, self.cin, self.k, (1, 1), self.dil, self.pad)
+            _wgrad(ddst.buf, src.buf, dw, None, d, 0, self.cout * self.T, self.T, False, self.cin, self.cout, 0)
+            if want_bias:
+                channel_sum(ddst, db)
         else:
             d = _desc(b, src, ddst, cs, self.cout, self.k, (1, 1), self.dil, self._flip_pad())
             _wgrad(src.buf, ddst.buf, dw, db, d, 0, self.T, self.cout * self.T, True, self.cout, self.cin, 0)
         return dw, db
+
+
+def channel_sum(view, out, accumulate=False):
+    """out[c] = sum over all pixels of view.buf[..., view.coff + c] (dense buffers only)."""
+    b, mh, mw, cs = view.buf.shape
+    assert view.off_h == 0 and view.off_w == 0 and view.h == mh and view.w == mw
+    ws = torch.empty(_lib.lib().dd_channel_sum_workspace_bytes(), device=view.buf.device, dtype=torch.uint8)
+    check(_lib.lib().dd_channel_sum(_p(view.buf), _p(out), b * mh * mw, cs, view.coff, view.chans, int(accumulate), _p(ws),
+                                    _stream()), "dd_channel_sum")
 
 
 def view_to_nhwc4(views, view, transform):

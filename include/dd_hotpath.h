@@ -163,7 +163,7 @@ int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n
 /* ---- generic NHWC convolution (K1/K2/K3/K5 of SURVEY 2.3: every other Conv2d / ConvTranspose2d of the path) ---
  * One implicit-GEMM kernel family for the decoder (components.py:70-73,89-92) and the spatial bounding-box
  * heads (spatial_bb/components.py:18-26,129-139): any kernel size, stride, dilation and padding, Cin a multiple
- * of 4 channels taken from a channel slice of the input buffer, Cout <= 64 written into a channel slice and a
+ * of 4 channels taken from a channel slice of the input buffer, Cout <= 64 (<= 96 for the weight gradient) written into a channel slice and a
  * strided / offset pixel lattice of the output buffer.  The same forward kernel also runs
  *   - ConvTranspose2d stride 1 (dilated): a convolution with flipped taps and pad = dil*(k-1) - pad;
  *   - ConvTranspose2d k2 s2: four 1x1 convolutions, one per output phase (ostride 2, ooff = phase);
@@ -202,6 +202,12 @@ int64_t dd_gconv_wgrad_workspace_bytes(const dd_gconv_desc* d);
 int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dd_gconv_desc* d, int64_t w_off,
                    int64_t sn, int64_t sc, int32_t flip, int32_t n_real, int32_t c_real, int32_t accumulate,
                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out[c] (+)= sum over the npix pixels of buf[p, coff + c], c < cout <= 128 (bias gradient of a transposed conv whose
+ * weight gradient is taken in the role-swapped form, see gconv.py). */
+int64_t dd_channel_sum_workspace_bytes(void);
+int dd_channel_sum(const float* buf, float* out, int64_t npix, int32_t cstore, int32_t coff, int32_t cout, int32_t accumulate,
+                   void* workspace, void* stream);
 
 /* Last layer of the box heads, ConvTranspose2d(8 -> 1, k2 s2) + sigmoid (spatial_bb/components.py:139,168):
  * x [B,h,w,8] NHWC, wt [8,1,2,2] (IOHW), probs [B,2h,2w].  The backward takes dL/dprobs, applies the sigmoid's
