@@ -14,6 +14,8 @@
 // table turns the chunk index into (row offset, column offset, channel) so the inner loop has no integer
 // division.  Loads run one 4-group set ahead of the MFMAs (register ping-pong).
 // Zero padding, ragged edges, divisibility holes of transposed gathers: out-of-range buffer offsets.
+#include <stdlib.h>
+
 #include "dd_common.h"
 
 namespace {
@@ -37,6 +39,62 @@ __device__ __forceinline__ int out_offset(const dd_gconv_desc& d, int yo, int xo
   const bool ok = (xo < d.out_w) && (chan < d.cout);
   return ok ? (((yo * d.ostride_h + d.ooff_h) * d.omem_w + xo * d.ostride_w + d.ooff_w) * d.out_cstore + d.out_coff + chan) * 4
             : -16;
+}
+
+// Valid tap rows of output row yo / valid tap columns of the 32-pixel strip at x0 (taps that touch the image).
+__device__ __forceinline__ void tap_rows(const dd_gconv_desc& d, int yo, int& k0, int& k1) {
+  const int ry = yo * d.stride_h - d.pad_h;                         // input row of tap ky = ry + ky*dil_h
+  k0 = ry >= 0 ? 0 : (-ry + d.dil_h - 1) / d.dil_h;
+  k1 = min(d.kh - 1, (d.in_h - 1 - ry) >= 0 ? (d.in_h - 1 - ry) / d.dil_h : -1);
+}
+__device__ __forceinline__ void tap_cols(const dd_gconv_desc& d, int x0, int& k0, int& k1) {
+  const int xlo = x0 * d.stride_w - d.pad_w;                        // leftmost / rightmost pixel of the strip
+  const int xhi = min(x0 + 31, d.out_w - 1) * d.stride_w - d.pad_w;
+  k0 = xhi >= 0 ? 0 : (-xhi + d.dil_w - 1) / d.dil_w;
+  k1 = min(d.kw - 1, (d.in_w - 1 - xlo) >= 0 ? (d.in_w - 1 - xlo) / d.dil_w : -1);
+}
+
+// First row-tile index of piece `i` of `n` equal-cost pieces; cost(tile) = 1 + valid tap rows x valid tap columns
+// (the 1 stands for the epilogue, so that all-padding tiles are still spread).  Wave-uniform scalar walk, once per wave.
+__device__ __forceinline__ long cost_cut(const dd_gconv_desc& d, int nstrips, int i, int n) {
+  long rows_cost = 0;      // sum over rows of nky
+  for (int yo = 0; yo < d.out_h; ++yo) {
+    int a, b;
+    tap_rows(d, yo, a, b);
+    rows_cost += max(b - a + 1, 0);
+  }
+  long img_cost = 0;
+  for (int s = 0; s < nstrips; ++s) {
+    int a, b;
+    tap_cols(d, s * 32, a, b);
+    img_cost += (long)max(b - a + 1, 0) * rows_cost + d.out_h;
+  }
+  const long total = img_cost * d.batch;
+  if (i >= n) return (long)d.batch * nstrips * d.out_h;
+  long target = (total * i) / n;
+  const long bimg = target / img_cost;
+  target -= bimg * img_cost;
+  long idx = bimg * nstrips * d.out_h;
+  for (int s = 0; s < nstrips; ++s) {
+    int a, b;
+    tap_cols(d, s * 32, a, b);
+    const long nkx = max(b - a + 1, 0);
+    const long col_cost = nkx * rows_cost + d.out_h;
+    if (target >= col_cost) {
+      target -= col_cost;
+      idx += d.out_h;
+      continue;
+    }
+    for (int yo = 0; yo < d.out_h; ++yo) {
+      int c, e;
+      tap_rows(d, yo, c, e);
+      const long tc = nkx * max(e - c + 1, 0) + 1;
+      if (target < tc) return idx + yo;
+      target -= tc;
+    }
+    return idx + d.out_h;
+  }
+  return idx;
 }
 
 template <int NT, bool DIV>
@@ -74,7 +132,17 @@ __global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict_
                  ? bias[nt * 32 + n] : 0.f;
 
   long idx, end;
-  dd_range((long)d.batch * nstrips * d.out_h, blockIdx.x * (blockDim.x >> 6) + wave, gridDim.x * (blockDim.x >> 6), idx, end);
+  {
+    const int gw = blockIdx.x * (blockDim.x >> 6) + wave, nw = gridDim.x * (blockDim.x >> 6);
+    if (!DIV && spt > 0) {
+      // Row tiles at the image border skip most taps (below), so equal COUNTS would leave the interior waves with
+      // all the work: cut the (image, strip, row) sequence into pieces of equal COST = valid tap rows x valid tap columns.
+      idx = cost_cut(d, nstrips, gw, nw);
+      end = cost_cut(d, nstrips, gw + 1, nw);
+    } else {
+      dd_range((long)d.batch * nstrips * d.out_h, gw, nw, idx, end);
+    }
+  }
   for (; idx < end; ++idx) {
     const long col = idx / d.out_h;
     const int yo = (int)(idx - col * d.out_h);
@@ -109,13 +177,8 @@ __global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict_
     // set (GU chunk pairs) never straddles two taps: spt = sets per tap.
     int ky0 = 0, ky1 = d.kh - 1, kx0 = 0, kx1 = d.kw - 1;
     if (!DIV && spt > 0) {
-      const int ry = yo * d.stride_h - d.pad_h;                       // input row of tap ky = ry + ky*dil_h
-      ky0 = ry >= 0 ? 0 : (-ry + d.dil_h - 1) / d.dil_h;
-      ky1 = min(d.kh - 1, (d.in_h - 1 - ry) >= 0 ? (d.in_h - 1 - ry) / d.dil_h : -1);
-      const int xlo = x0 * d.stride_w - d.pad_w;                      // leftmost / rightmost pixel of the strip
-      const int xhi = min(x0 + 31, d.out_w - 1) * d.stride_w - d.pad_w;
-      kx0 = xhi >= 0 ? 0 : (-xhi + d.dil_w - 1) / d.dil_w;
-      kx1 = min(d.kw - 1, (d.in_w - 1 - xlo) >= 0 ? (d.in_w - 1 - xlo) / d.dil_w : -1);
+      tap_rows(d, yo, ky0, ky1);
+      tap_cols(d, x0, kx0, kx1);
     }
     const int nky = max(ky1 - ky0 + 1, 0), nkx = max(kx1 - kx0 + 1, 0);
     const int per_tap = spt > 0 ? spt : (ngroups / GU);               // spt == 0: one "tap" = all sets, no skipping
@@ -476,11 +539,15 @@ int groups_of(const dd_gconv_desc* d) {
   return (g + GU - 1) / GU * GU;
 }
 
-int pick_nb(int nj, int max_nb) {
-  int best = 1, cost = nj;
-  for (int nb = 2; nb <= max_nb; ++nb) {
-    const int c = (nj + nb - 1) / nb * nb;
-    if (c <= cost) { cost = c; best = nb; }
+// Column tiles per wave: padded MFMA work x (1 + half the operand loads per MFMA) -- wider register tiles reuse the dy
+// operand, too wide ones multiply zero columns.
+int pick_nb(int nj, int no, int max_nb) {
+  int best = 1;
+  float best_score = 1e30f;
+  for (int nb = 1; nb <= max_nb; ++nb) {
+    const int padded = (nj + nb - 1) / nb * nb;
+    const float score = padded * (1.f + 0.5f * (no + nb) / (float)(no * nb));
+    if (score < best_score) { best_score = score; best = nb; }
   }
   return best;
 }
@@ -494,7 +561,7 @@ WgradPlan wgrad_plan(const dd_gconv_desc* d) {
   p.no = p.nto <= 3 ? p.nto : 2;
   p.nog = (p.nto + p.no - 1) / p.no;
   p.nj = (d->kh * d->kw * d->cin + 31) / 32;
-  p.nb = pick_nb(p.nj, p.no == 1 ? 4 : (p.no == 2 ? 3 : 2));
+  p.nb = pick_nb(p.nj, p.no, p.no == 1 ? 4 : (p.no == 2 ? 3 : 2));
   p.njg = (p.nj + p.nb - 1) / p.nb;
   p.njobs = p.nog * p.njg;
   const long tiles = (long)d->batch * ((d->out_w + 31) / 32) * d->out_h;
@@ -568,7 +635,8 @@ int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const f
   DD_REQUIRE(lds <= 64 * 1024, DD_ERR_UNSUPPORTED, "gconv_fwd: tap table of %zu bytes", lds);
   // sets (GU chunk pairs) per tap when a set never straddles taps, else 0 = no tap skipping
   const int pairs_per_tap = d->cin / 8;
-  const int spt = (d->cin % 8 == 0 && pairs_per_tap % GU == 0) ? pairs_per_tap / GU : 0;
+  static const bool noskip = getenv("DD_GCONV_NOSKIP") != nullptr;   // A/B knob for the tap-skipping path
+  const int spt = (!noskip && d->cin % 8 == 0 && pairs_per_tap % GU == 0) ? pairs_per_tap / GU : 0;
 #define DD_GF(NT, DIV) hipLaunchKernelGGL((gconv_fwd_kernel<NT, DIV>), dim3(grid), dim3(512), lds, st, x, packed, bias, mask, y, *d, ng, epilogue, spt)
   if (nt == 1) { if (div) DD_GF(1, true); else DD_GF(1, false); }
   else { if (div) DD_GF(2, true); else DD_GF(2, false); }
