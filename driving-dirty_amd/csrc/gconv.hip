@@ -333,22 +333,31 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restric
 }
 
 // dw[w_off + o*sn + c*sc + tap'] (+)= sum over ranges; one thread per accumulator element.
-__global__ __launch_bounds__(256) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
-                                                          int nranges, int njobs, int no, int nb, int njg, int T, int cin,
-                                                          long w_off, long sn, long sc, int flip, int n_real, int c_real,
-                                                          int accumulate) {
+__global__ __launch_bounds__(1024) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int nranges, int njobs, int no, int nb, int njg, int T, int cin,
+                                                           long w_off, long sn, long sc, int flip, int n_real, int c_real,
+                                                           int accumulate) {
+  // one block = 64 consecutive accumulator elements (one register row of one tile) x 16 groups of ranges
+  __shared__ float red[16][64];
   const long per = (long)njobs * no * nb * 1024;
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per) return;
-  float s0 = 0.f, s1 = 0.f;
-  int r = 0;
-  for (; r + 2 <= nranges; r += 2) {
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = g;
+  for (; r + 48 < nranges; r += 64) {
     s0 += part[(long)r * per + e];
-    s1 += part[(long)(r + 1) * per + e];
+    s1 += part[(long)(r + 16) * per + e];
+    s2 += part[(long)(r + 32) * per + e];
+    s3 += part[(long)(r + 48) * per + e];
   }
-  if (r < nranges) s0 += part[(long)r * per + e];
-  const float s = s0 + s1;
-  const int lane = e & 63, reg = (e >> 6) & 15;
+  for (; r < nranges; r += 16) s0 += part[(long)r * per + e];
+  red[g][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += red[i][lane];
+  const int reg = (int)((e >> 6) & 15);
   const long jk = e >> 10;
   const int k = (int)(jk % nb), a = (int)((jk / nb) % no), job = (int)(jk / ((long)nb * no));
   const int og = job / njg, jg = job - og * njg;
@@ -361,16 +370,18 @@ __global__ __launch_bounds__(256) void gconv_wgrad_reduce(const float* __restric
   dw[wi] = accumulate ? dw[wi] + s : s;
 }
 
-__global__ __launch_bounds__(256) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
-                                                         int nranges, int nto, int n_real, int accumulate) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
+                                                          int nranges, int nto, int n_real, int accumulate) {
+  __shared__ float red[16][64];
   const int ot = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   float s = 0.f;
-  for (int r = g; r < nranges; r += 4) s += bpart[((long)r * nto + ot) * 64 + lane];
+  for (int r = g; r < nranges; r += 16) s += bpart[((long)r * nto + ot) * 64 + lane];
   red[g][lane] = s;
   __syncthreads();
   if (g != 0) return;
-  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += red[i][lane];
   s += __shfl_xor(s, 32);
   const int o = ot * 32 + lane;
   if (lane < 32 && o < n_real) db[o] = accumulate ? db[o] + s : s;
@@ -575,24 +586,42 @@ WgradPlan wgrad_plan(const dd_gconv_desc* d) {
 // gradient is taken in the role-swapped, waste-free form)
 __global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ buf, float* __restrict__ partial,
                                                            long npix, int cstore, int coff, int cout) {
+  __shared__ float red[4][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-  float s0 = 0.f, s1 = 0.f;
-  for (long p = gw; p < npix; p += nw) {
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+  long p = gw;
+  for (; p + nw < npix; p += 2L * nw) {          // two pixels in flight per lane
+    const float* px = buf + p * cstore + coff;
+    const float* qx = px + (long)nw * cstore;
+    if (lane < cout) { s0 += px[lane]; t0 += qx[lane]; }
+    if (lane + 64 < cout) { s1 += px[lane + 64]; t1 += qx[lane + 64]; }
+  }
+  for (; p < npix; p += nw) {
     const float* px = buf + p * cstore + coff;
     if (lane < cout) s0 += px[lane];
     if (lane + 64 < cout) s1 += px[lane + 64];
   }
-  partial[(long)gw * 128 + lane] = s0;
-  partial[(long)gw * 128 + 64 + lane] = s1;
+  red[wave][lane] = s0 + t0;
+  red[wave][64 + lane] = s1 + t1;
+  __syncthreads();
+  if (threadIdx.x < 128)
+    partial[(long)blockIdx.x * 128 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(128) void channel_sum_final(const float* __restrict__ partial, float* __restrict__ out, int nw,
-                                                         int cout, int accumulate) {
-  const int c = threadIdx.x;
-  if (c >= cout) return;
+__global__ __launch_bounds__(1024) void channel_sum_final(const float* __restrict__ partial, float* __restrict__ out, int nrows,
+                                                          int cout, int accumulate) {
+  __shared__ float red[8][128];
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   float s = 0.f;
-  for (int w = 0; w < nw; ++w) s += partial[(long)w * 128 + c];
+  for (int w = g; w < nrows; w += 8) s += partial[(long)w * 128 + c];
+  red[g][c] = s;
+  __syncthreads();
+  if (g != 0 || c >= cout) return;
+  s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += red[i][c];
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -678,28 +707,28 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
 #undef DD_GW
   DD_LAUNCH_CHECK("gconv_wgrad");
   const long per = (long)p.njobs * p.no * p.nb * 1024;
-  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, dw, p.nranges, p.njobs, p.no,
+  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)(per / 64)), dim3(1024), 0, st, part, dw, p.nranges, p.njobs, p.no,
                      p.nb, p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
   DD_LAUNCH_CHECK("gconv_wgrad_reduce");
   if (dbias) {
-    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(256), 0, st, bpart, dbias, p.nranges, p.nog * p.no, n_real, accumulate & 2);
+    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(1024), 0, st, bpart, dbias, p.nranges, p.nog * p.no, n_real, accumulate & 2);
     DD_LAUNCH_CHECK("gconv_bias_reduce");
   }
   return 0;
 }
 
-int64_t dd_channel_sum_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 4 * 128 * 4; }
+int64_t dd_channel_sum_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 4 * 128 * 4; }   // one 128-channel row per block
 
 int dd_channel_sum(const float* buf, float* out, int64_t npix, int32_t cstore, int32_t coff, int32_t cout, int32_t accumulate,
                    void* workspace, void* stream) {
   DD_REQUIRE(buf && out && workspace && npix > 0 && cstore > 0 && coff >= 0 && cout > 0 && coff + cout <= cstore, DD_ERR_BAD_ARG,
              "channel_sum: bad argument");
   DD_REQUIRE(cout <= 128, DD_ERR_UNSUPPORTED, "channel_sum: more than 128 channels");
-  const int grid = (int)min((npix + 3) / 4, (long)DD_NUM_CU);
+  const int grid = (int)min((npix + 3) / 4, (long)DD_NUM_CU * 4);
   hipLaunchKernelGGL(channel_sum_partial, dim3(grid), dim3(256), 0, (hipStream_t)stream, buf, (float*)workspace, (long)npix, cstore,
                      coff, cout);
   DD_LAUNCH_CHECK("channel_sum");
-  hipLaunchKernelGGL(channel_sum_final, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)workspace, out, grid * 4, cout,
+  hipLaunchKernelGGL(channel_sum_final, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, out, grid, cout,
                      accumulate);
   DD_LAUNCH_CHECK("channel_sum final");
   return 0;
