@@ -45,6 +45,16 @@ SIGNATURES = {
     "dd_conv_fwd": (_i32, [_p, _p, _p, _p, _p, _DP, _i32, _p]),
     "dd_conv_fwd_relu_bits": (_i32, [_p, _p, _p, _p, _p, _DP, _p]),
     "dd_conv_dgrad_relu_bits": (_i32, [_p, _p, _p, _p, _DP, _p]),
+    "dd_conv_stats_floats": (_i64, []),
+    "dd_conv_fwd_stats": (_i32, [_p, _p, _p, _p, _p, _p, _DP, _p]),
+    "dd_bn2d_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _i32, _p, _p, _p, _p]),
+    "dd_bn2d_apply_relu": (_i32, [_p, _p, _p, _i64, _p]),
+    "dd_bn2d_workspace_bytes": (_i64, []),
+    "dd_bn2d_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "dd_conv_dgrad_bn": (_i32, [_p, _p, _p, _p, _p, _DP, _p]),
+    "dd_conv_wgrad_bn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _DP, _p]),
+    "dd_pool4_bn_fwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "dd_pool4_bn_bwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_conv_dgrad": (_i32, [_p, _p, _p, _p, _DP, _p]),
     "dd_conv_wgrad_workspace_bytes": (_i64, [_DP]),
     "dd_conv_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _DP, _p]),

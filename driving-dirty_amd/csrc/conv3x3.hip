@@ -31,6 +31,13 @@ namespace {
 // (a uint32 per 32-channel pixel) instead of being re-read from the 128-byte fp32 pixel by the backward kernels
 constexpr int EPI_BIAS_RELU_BITS = 5;   // y = relu(conv + bias), bits[pixel] = mask of (y > 0) over the 32 channels
 constexpr int EPI_RELU_BITS = 6;        // y = conv * bit(channel) of bits[pixel]
+// Conv -> BatchNorm2d -> ReLU variant (reference components_v2.py:43-46): the conv writes the PRE-normalisation value
+// and gathers the batch statistics in its epilogue; the normalise + ReLU is applied by whoever READS the tensor
+// (next conv's row loader, pool, mask tests) from a per-channel (scale, shift), so the activation is never rewritten.
+constexpr int EPI_BIAS_STATS = 7;       // u = conv + bias; per-lane sum / sum of squares of u -> stats[wave][lane][2]
+constexpr int EPI_RELU_MASK_AFF = 8;    // y = conv * (mask*m_scale[c] + m_shift[c] > 0)
+
+// per-channel affine tables handed to the kernels: [0:32) input scale, [32:64) input shift, [64:96) mask scale, [96:128) mask shift
 
 template <int CIN, int S>
 struct StripCfg {
@@ -100,6 +107,29 @@ __device__ __forceinline__ void store_row(char* slot, char* spill, int lane,
   }
 }
 
+// Same, for a tensor stored PRE-BatchNorm: in-image pixels become relu(v * scale + shift) on their way into the ring;
+// padding stays zero (it pads the normalised activation).  A lane's chunks all cover channels 4*(lane&7)..+3
+// (64*i is a multiple of the 8 chunks per pixel), so it carries one (scale, shift) quad.
+template <int S, bool SWZ>
+__device__ __forceinline__ void store_row_aff(char* slot, char* spill, int lane, const f32x4 (&r)[StripCfg<32, S>::NLOAD],
+                                              bool rowok, int gx0, int W, f32x4 sc, f32x4 sh) {
+  using C = StripCfg<32, S>;
+#pragma unroll
+  for (int i = 0; i < C::NLOAD; ++i) {
+    const int c = lane + 64 * i;
+    const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
+    char* dst = slot + q * C::PXB + ((ch ^ (SWZ ? swz<32>(q) : 0)) << 4);
+    if (64 * (i + 1) > C::NCH) dst = (c < C::NCH) ? dst : spill + (c - C::NCH) * 16;
+    const bool in = rowok && (gx0 + q >= 0) && (gx0 + q < W);
+    f32x4 v = r[i];
+    v.x = in ? fmaxf(v.x * sc.x + sh.x, 0.f) : 0.f;
+    v.y = in ? fmaxf(v.y * sc.y + sh.y, 0.f) : 0.f;
+    v.z = in ? fmaxf(v.z * sc.z + sh.z, 0.f) : 0.f;
+    v.w = in ? fmaxf(v.w * sc.w + sh.w, 0.f) : 0.f;
+    *(f32x4*)dst = v;
+  }
+}
+
 // The contiguous range of row tiles owned by global wave gw; idx = column * rows + row.
 __device__ __forceinline__ void wave_range(long total, int gw, int nw, long& idx, long& end) {
   const long per = (total + nw - 1) / nw;
@@ -110,12 +140,13 @@ __device__ __forceinline__ void wave_range(long total, int gw, int nw, long& idx
 // ------------------------------------------------------------------------------------------------
 // forward / stride-1 dgrad
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int S, int EPI, int WPB>
+template <int CIN, int S, int EPI, int WPB, bool AFF = false>
 __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ msk, float* __restrict__ y,
                                                            unsigned* __restrict__ bits_out, int B, int H, int W, int Ho,
-                                                           int Wo, int nstrips) {
+                                                           int Wo, int nstrips, const float* __restrict__ aff = nullptr,
+                                                           float* __restrict__ stats = nullptr) {
   using C = StripCfg<CIN, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -131,7 +162,14 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
   char* spill = ring + 3 * C::SLOTB;
   const char* wl = smem;
   const int h = lane >> 5, n = lane & 31;
-  const float bv = (EPI == DD_EPI_BIAS || EPI == DD_EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_BITS) ? bias[n] : 0.f;
+  const float bv = (EPI == DD_EPI_BIAS || EPI == DD_EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_BITS || EPI == EPI_BIAS_STATS) ? bias[n] : 0.f;
+  f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+  if (AFF) {
+    asc = *(const f32x4*)(aff + 4 * (lane & 7));
+    ash = *(const f32x4*)(aff + 32 + 4 * (lane & 7));
+  }
+  const float msc = (EPI == EPI_RELU_MASK_AFF) ? aff[64 + n] : 1.f, msh = (EPI == EPI_RELU_MASK_AFF) ? aff[96 + n] : 0.f;
+  float st_sum = 0.f, st_sq = 0.f;
 
   long idx, end;
   wave_range((long)B * nstrips * Ho, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
@@ -149,7 +187,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
       f32x4 t[C::NLOAD];
       const int iy = S * y0 - 1 + d;
       load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
-      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
+      if constexpr (AFF) store_row_aff<S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t, iy >= 0 && iy < H, gx0, W, asc, ash);
+      else store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
     }
 
     for (int yy = y0; yy < y1; ++yy) {
@@ -160,7 +199,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
 
       const long orow = ((long)(b * Ho + yy) * Wo) * 32;
       float mreg[16];
-      if (EPI == DD_EPI_RELU_MASK) {
+      if (EPI == DD_EPI_RELU_MASK || EPI == EPI_RELU_MASK_AFF) {
         const __amdgpu_buffer_rsrc_t ms = rsrc(msk + orow, Wo * 128);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mreg[r] = bload1(ms, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4);
@@ -217,7 +256,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const int iy = S * yy + 2 + s;
-        store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
+        if constexpr (AFF) store_row_aff<S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s], iy >= 0 && iy < H, gx0, W, asc, ash);
+        else store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
       }
 
       // epilogue: lane = output channel, register = pixel -> 128 contiguous bytes per pixel per store;
@@ -227,9 +267,14 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
-        if (EPI == DD_EPI_BIAS) v += bv;
+        if (EPI == DD_EPI_BIAS || EPI == EPI_BIAS_STATS) v += bv;
+        if (EPI == EPI_BIAS_STATS && x0 + dd_acc_row(r, lane) < Wo) {   // batch statistics: lane = channel, no shuffles needed
+          st_sum += v;
+          st_sq += v * v;
+        }
         if (EPI == DD_EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v + bv, 0.f);
         if (EPI == DD_EPI_RELU_MASK) v = (mreg[r] > 0.f) ? v : 0.f;
+        if (EPI == EPI_RELU_MASK_AFF) v = (mreg[r] * msc + msh > 0.f) ? v : 0.f;
         if (EPI == EPI_RELU_BITS) v = ((__builtin_bit_cast(unsigned, mreg[r]) >> n) & 1u) ? v : 0.f;
         bstore1(ys, ((x0 + dd_acc_row(r, lane)) * 32 + n) * 4, v);
         if (EPI == EPI_BIAS_RELU_BITS) {
@@ -247,6 +292,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
       }
     }
   }
+  if (EPI == EPI_BIAS_STATS) {   // one partial per wave-lane; waves without work still write their zeros
+    const long gwl = ((long)(blockIdx.x * WPB + wave) * 64 + lane) * 2;
+    stats[gwl] = st_sum;
+    stats[gwl + 1] = st_sq;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,10 +305,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_strip_fwd(const float* __restri
 // (same along x), so a pair of output rows x 64 output pixels costs the same 144 MFMAs the forward
 // spends on 32 output pixels -- no multiplies by inserted zeros.
 // ------------------------------------------------------------------------------------------------
-template <int WPB, int MASK>   // 0: none, 1: fp32 activation (> 0), 2: packed sign bits
+template <int WPB, int MASK>   // 0: none, 1: fp32 activation (> 0), 2: packed sign bits, 3: pre-BN tensor with (scale, shift)
 __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restrict__ dy, const float* __restrict__ wp,
                                                           const float* __restrict__ msk, float* __restrict__ dx,
-                                                          int B, int H, int W, int Ho, int Wo, int nstrips) {
+                                                          int B, int H, int W, int Ho, int Wo, int nstrips,
+                                                          const float* __restrict__ aff = nullptr) {
   using C = StripCfg<32, 1>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -271,6 +322,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
   }
   __syncthreads();
   const int nr = (H + 1) / 2;   // output row pairs per column
+  const float msc = (MASK == 3) ? aff[64 + (lane & 31)] : 1.f, msh = (MASK == 3) ? aff[96 + (lane & 31)] : 0.f;
   char* ring = smem + C::WFLOATS * 4 + wave * C::WAVEB;
   char* spill = ring + 3 * C::SLOTB;
   const char* wl = smem;
@@ -310,7 +362,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
     const long orow = ((long)(b * H + min(yi, H - 1)) * W) * 32;                                \
     const int obytes = (yi < H) ? W * 128 : 0;                                                  \
     float mreg[16];                                                                             \
-    if (MASK == 1) {                                                                            \
+    if (MASK == 1 || MASK == 3) {                                                               \
       const __amdgpu_buffer_rsrc_t ms = rsrc(msk + orow, obytes);                               \
       _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                         \
         mreg[rr] = bload1(ms, ((2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 32 + n) * 4);         \
@@ -342,6 +394,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
     _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                         \
       float v = acc[rr];                                                                        \
       if (MASK == 1) v = (mreg[rr] > 0.f) ? v : 0.f;                                            \
+      if (MASK == 3) v = (mreg[rr] * msc + msh > 0.f) ? v : 0.f;                                \
       if (MASK == 2) v = ((__builtin_bit_cast(unsigned, mreg[rr]) >> n) & 1u) ? v : 0.f;        \
       bstore1(os, ((2 * (s0 + dd_acc_row(rr, lane)) + (PX)) * 32 + n) * 4, v);                  \
     }                                                                                           \
@@ -362,10 +415,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_s2_dgrad(const float* __restric
 // wave-load), B = x rows from the LDS ring (ds_read_b32, 32 consecutive dwords per half-wave).
 // Each wave accumulates over its whole range and writes ONE partial.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int S, int WPB>
+template <int CIN, int S, int WPB, bool AFF = false>
 __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ part, float* __restrict__ bpart, int B,
-                                                       int H, int W, int Ho, int Wo, int nstrips) {
+                                                       int H, int W, int Ho, int Wo, int nstrips,
+                                                       const float* __restrict__ aff = nullptr) {
   using C = StripCfg<CIN, S>;
   constexpr int NT = (CIN == 32) ? 9 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -376,6 +430,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__
   char* spill = ring + 3 * C::SLOTB;
   const int h = lane >> 5, n = lane & 31;
   const int gw = blockIdx.x * WPB + wave;
+  f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+  if (AFF) {
+    asc = *(const f32x4*)(aff + 4 * (lane & 7));
+    ash = *(const f32x4*)(aff + 32 + 4 * (lane & 7));
+  }
 
   f32x16 acc[NT];
 #pragma unroll
@@ -406,7 +465,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__
       f32x4 t[C::NLOAD];
       const int iy = S * y0 - 1 + d;
       load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
-      store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
+      if constexpr (AFF) store_row_aff<S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t, iy >= 0 && iy < H, gx0, W, asc, ash);
+      else store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
     }
     float areg[16];
     {
@@ -457,7 +517,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_wgrad(const float* __restrict__
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const int iy = S * yy + 2 + s;
-        store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
+        if constexpr (AFF) store_row_aff<S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s], iy >= 0 && iy < H, gx0, W, asc, ash);
+        else store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
       }
 #pragma unroll
       for (int pp = 0; pp < 16; ++pp) areg[pp] = anext[pp];
@@ -555,11 +616,11 @@ __global__ void relu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __res
 
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {
-  static thread_local const void* done[16];
+  static thread_local const void* done[48];
   static thread_local int ndone = 0;
   for (int i = 0; i < ndone; ++i)
     if (done[i] == (const void*)kernel) return 0;
-  if (ndone < 16) done[ndone++] = (const void*)kernel;
+  if (ndone < 48) done[ndone++] = (const void*)kernel;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return e == hipSuccess ? 0 : dd_fail(DD_ERR_LAUNCH, "hipFuncSetAttribute(%zu bytes LDS): %s", bytes, hipGetErrorString(e));
 }
@@ -586,19 +647,19 @@ int resident_grid(const dd_conv_desc* d, long row_tiles, int wpb, int per_cu) {
   return (int)max(1L, min(blocks, (row_tiles + wpb - 1) / wpb));
 }
 
-template <int CIN, int S, int EPI, int WPB>
+template <int CIN, int S, int EPI, int WPB, bool AFF = false>
 int launch_fwd(const float* x, const float* wp, const float* bias, const float* msk, float* y, const dd_conv_desc* d,
-               hipStream_t st, unsigned* bits_out = nullptr) {
+               hipStream_t st, unsigned* bits_out = nullptr, const float* aff = nullptr, float* stats = nullptr) {
   using C = StripCfg<CIN, S>;
   const int Ho = dd_conv_out(d->height, S), Wo = dd_conv_out(d->width, S);
   const int nstrips = (Wo + 31) / 32;
   const size_t lds = C::WFLOATS * 4 + (size_t)WPB * C::WAVEB;
   const int per_cu = (int)max((size_t)1, min((size_t)2, (size_t)(160 * 1024) / lds));
   const int grid = resident_grid(d, (long)d->batch * nstrips * Ho, WPB, per_cu);
-  auto k = conv_strip_fwd<CIN, S, EPI, WPB>;
+  auto k = conv_strip_fwd<CIN, S, EPI, WPB, AFF>;
   if (int rc = allow_lds(k, lds)) return rc;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, wp, bias, msk, y, bits_out, d->batch, d->height, d->width,
-                     Ho, Wo, nstrips);
+                     Ho, Wo, nstrips, aff, stats);
   DD_LAUNCH_CHECK("conv_strip_fwd");
   return 0;
 }
@@ -657,7 +718,7 @@ int dd_conv_fwd_relu_bits(const float* x, const float* packed_fwd, const float* 
 }
 
 static int conv_dgrad_impl(const float* dy, const float* packed_dgrad, const float* relu_src, int mask_mode, float* dx,
-                           const dd_conv_desc* d, void* stream);
+                           const dd_conv_desc* d, void* stream, const float* aff = nullptr);
 
 int dd_conv_dgrad(const float* dy, const float* packed_dgrad, const float* relu_src, float* dx, const dd_conv_desc* d,
                   void* stream) {
@@ -670,14 +731,21 @@ int dd_conv_dgrad_relu_bits(const float* dy, const float* packed_dgrad, const ui
   return conv_dgrad_impl(dy, packed_dgrad, (const float*)relu_bits, 2, dx, d, stream);
 }
 
+int dd_conv_dgrad_bn(const float* dy, const float* packed_dgrad, const float* pre_bn, const float* affine, float* dx,
+                     const dd_conv_desc* d, void* stream) {
+  DD_REQUIRE(pre_bn && affine, DD_ERR_BAD_ARG, "conv_dgrad_bn: NULL mask / affine");
+  return conv_dgrad_impl(dy, packed_dgrad, pre_bn, 3, dx, d, stream, affine);
+}
+
 static int conv_dgrad_impl(const float* dy, const float* packed_dgrad, const float* relu_src, int mask_mode, float* dx,
-                           const dd_conv_desc* d, void* stream) {
+                           const dd_conv_desc* d, void* stream, const float* aff) {
   if (int rc = check_desc(d)) return rc;
   DD_REQUIRE(dy && packed_dgrad && dx, DD_ERR_BAD_ARG, "conv_dgrad: NULL pointer");
   DD_REQUIRE(d->cin_real == 32, DD_ERR_UNSUPPORTED, "conv_dgrad: Cin %d (the first layer has no data gradient)", d->cin_real);
   hipStream_t st = (hipStream_t)stream;
   if (d->stride == 1) {
     // a stride-1 k3 p1 data gradient IS a k3 p1 convolution of dy with the flipped / transposed weights
+    if (mask_mode == 3) return launch_fwd<32, 1, EPI_RELU_MASK_AFF, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st, nullptr, aff);
     if (mask_mode == 2) return launch_fwd<32, 1, EPI_RELU_BITS, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st);
     return mask_mode ? launch_fwd<32, 1, DD_EPI_RELU_MASK, 8>(dy, packed_dgrad, nullptr, relu_src, dx, d, st)
                      : launch_fwd<32, 1, DD_EPI_NONE, 8>(dy, packed_dgrad, nullptr, nullptr, dx, d, st);
@@ -689,21 +757,26 @@ static int conv_dgrad_impl(const float* dy, const float* packed_dgrad, const flo
   const int nstrips = (ns + 31) / 32;
   const size_t lds = C::WFLOATS * 4 + (size_t)WPB * C::WAVEB;
   const int grid = resident_grid(d, (long)d->batch * nstrips * nr, WPB, 1);
-  if (mask_mode == 2) {
+  if (mask_mode == 3) {
+    auto k = conv_s2_dgrad<WPB, 3>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
+                       nstrips, aff);
+  } else if (mask_mode == 2) {
     auto k = conv_s2_dgrad<WPB, 2>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
-                       nstrips);
+                       nstrips, aff);
   } else if (mask_mode == 1) {
     auto k = conv_s2_dgrad<WPB, 1>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
-                       nstrips);
+                       nstrips, aff);
   } else {
     auto k = conv_s2_dgrad<WPB, 0>;
     if (int rc = allow_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, dy, packed_dgrad, relu_src, dx, d->batch, H, W, Ho, Wo,
-                       nstrips);
+                       nstrips, aff);
   }
   DD_LAUNCH_CHECK("conv_s2_dgrad");
   return 0;
@@ -716,8 +789,41 @@ int64_t dd_conv_wgrad_workspace_bytes(const dd_conv_desc* d) {
   return waves * ((int64_t)nt * 1024 + 64) * 4;
 }
 
+static int conv_wgrad_impl(const float* x, const float* aff, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                           int64_t workspace_bytes, const dd_conv_desc* d, void* stream);
+
 int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
                   int64_t workspace_bytes, const dd_conv_desc* d, void* stream) {
+  return conv_wgrad_impl(x, nullptr, dy, dw_oihw, dbias, workspace, workspace_bytes, d, stream);
+}
+
+int dd_conv_wgrad_bn(const float* pre_bn, const float* affine, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                     int64_t workspace_bytes, const dd_conv_desc* d, void* stream) {
+  DD_REQUIRE(affine, DD_ERR_BAD_ARG, "conv_wgrad_bn: NULL affine");
+  DD_REQUIRE(d && d->cin_real == 32, DD_ERR_UNSUPPORTED, "conv_wgrad_bn: the input of a BN'd layer has 32 channels");
+  return conv_wgrad_impl(pre_bn, affine, dy, dw_oihw, dbias, workspace, workspace_bytes, d, stream);
+}
+
+int64_t dd_conv_stats_floats(void) { return (int64_t)DD_NUM_CU * 2 * 8 * 64 * 2; }
+
+int dd_conv_fwd_stats(const float* x, const float* packed_fwd, const float* bias, const float* in_affine, float* u,
+                      float* stats, const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && packed_fwd && bias && u && stats, DD_ERR_BAD_ARG, "conv_fwd_stats: NULL pointer");
+  DD_REQUIRE(!(in_affine && d->cin_store == 4), DD_ERR_UNSUPPORTED, "conv_fwd_stats: the image layer has no BN'd input");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(stats, 0, dd_conv_stats_floats() * sizeof(float), st) != hipSuccess)
+    return dd_fail(DD_ERR_LAUNCH, "conv_fwd_stats: hipMemsetAsync failed");
+  if (d->cin_store == 4) return launch_fwd<4, 1, EPI_BIAS_STATS, 8>(x, packed_fwd, bias, nullptr, u, d, st, nullptr, nullptr, stats);
+  if (d->stride == 1)
+    return in_affine ? launch_fwd<32, 1, EPI_BIAS_STATS, 8, true>(x, packed_fwd, bias, nullptr, u, d, st, nullptr, in_affine, stats)
+                     : launch_fwd<32, 1, EPI_BIAS_STATS, 8, false>(x, packed_fwd, bias, nullptr, u, d, st, nullptr, nullptr, stats);
+  return in_affine ? launch_fwd<32, 2, EPI_BIAS_STATS, 4, true>(x, packed_fwd, bias, nullptr, u, d, st, nullptr, in_affine, stats)
+                   : launch_fwd<32, 2, EPI_BIAS_STATS, 4, false>(x, packed_fwd, bias, nullptr, u, d, st, nullptr, nullptr, stats);
+}
+
+static int conv_wgrad_impl(const float* x, const float* aff, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                           int64_t workspace_bytes, const dd_conv_desc* d, void* stream) {
   if (int rc = check_desc(d)) return rc;
   DD_REQUIRE(x && dy && dw_oihw && dbias && workspace, DD_ERR_BAD_ARG, "conv_wgrad: NULL pointer");
   DD_REQUIRE(workspace_bytes >= dd_conv_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wgrad: workspace %ld < %ld bytes",
@@ -732,16 +838,19 @@ int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias,
   const int nw = grid * WPB;
   float* part = (float*)workspace;
   float* bpart = part + (size_t)nw * nt * 1024;
-#define DD_WG(CIN, SS)                                                                                              \
+#define DD_WG(CIN, SS, AFF)                                                                                         \
   {                                                                                                                 \
-    auto k = conv_wgrad<CIN, SS, WPB>;                                                                              \
-    const size_t lds = (size_t)WPB * StripCfg<CIN, SS>::WAVEB;                                                  \
+    auto k = conv_wgrad<CIN, SS, WPB, AFF>;                                                                         \
+    const size_t lds = (size_t)WPB * StripCfg<CIN, SS>::WAVEB;                                                      \
     if (int rc = allow_lds(k, lds)) return rc;                                                                      \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, H, W, Ho, Wo, nstrips); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, H, W, Ho, Wo, nstrips, \
+                       aff);                                                                                        \
   }
-  if (d->cin_store == 4) DD_WG(4, 1)
-  else if (S == 1) DD_WG(32, 1)
-  else DD_WG(32, 2)
+  if (d->cin_store == 4) DD_WG(4, 1, false)
+  else if (S == 1 && aff) DD_WG(32, 1, true)
+  else if (S == 1) DD_WG(32, 1, false)
+  else if (aff) DD_WG(32, 2, true)
+  else DD_WG(32, 2, false)
 #undef DD_WG
   DD_LAUNCH_CHECK("conv_wgrad");
   if (d->cin_store == 4)

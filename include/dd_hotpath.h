@@ -114,6 +114,36 @@ int dd_conv_fwd_relu_bits(const float* x, const float* packed_fwd, const float* 
 int dd_conv_dgrad_relu_bits(const float* dy, const float* packed_dgrad, const uint32_t* relu_bits, float* dx,
                             const dd_conv_desc* d, void* stream);
 
+/* ---- Conv -> BatchNorm2d -> ReLU variant (reference src/autoencoder/components_v2.py:19-24,43-46) -----------------
+ * The conv writes the PRE-normalisation tensor u = conv(x) + bias and gathers the batch statistics in its epilogue
+ * (`stats`: dd_conv_stats_floats() floats, zeroed by the call).  dd_bn2d_finalize turns them into batch mean / inv-std,
+ * updates the running statistics like torch.nn.BatchNorm2d (momentum, unbiased variance) and writes `affine`[128]:
+ * [0:32) scale, [32:64) shift (as INPUT transform of the next layer) and the same pair at [64:128) (as MASK transform).
+ * Whoever reads u applies y = relu(u*scale + shift) on the fly: the next conv (`in_affine`), the pool, the ReLU mask
+ * of the data gradient, the weight gradient's input -- the normalised activation is never written to memory. */
+int64_t dd_conv_stats_floats(void);
+int dd_conv_fwd_stats(const float* x, const float* packed_fwd, const float* bias, const float* in_affine, float* u,
+                      float* stats, const dd_conv_desc* d, void* stream);
+int dd_bn2d_finalize(const float* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int32_t training, float* affine, float* save_mean,
+                     float* save_invstd, void* stream);
+/* y = relu(u*scale + shift), u/y [npix, 32] (only when a caller wants the activation itself, e.g. the c3_only exit) */
+int dd_bn2d_apply_relu(const float* u, const float* affine, float* y, int64_t npix, void* stream);
+/* BatchNorm2d backward on g = dL/d(BN output) (already ReLU-masked): dgamma, dbeta (wavefront-shuffle reduction) and
+ * du = gamma*invstd * (g - dbeta/N - xhat*dgamma/N)  (training) or gamma*invstd*g (eval). */
+int64_t dd_bn2d_workspace_bytes(void);
+int dd_bn2d_bwd(const float* g, const float* u, const float* gamma, const float* save_mean, const float* save_invstd,
+                float* du, float* dgamma, float* dbeta, int64_t npix, int32_t training, void* workspace, void* stream);
+/* conv data / weight gradients whose ReLU mask / input is a pre-BN tensor seen through `affine` */
+int dd_conv_dgrad_bn(const float* dy, const float* packed_dgrad, const float* pre_bn, const float* affine, float* dx,
+                     const dd_conv_desc* d, void* stream);
+int dd_conv_wgrad_bn(const float* pre_bn, const float* affine, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                     int64_t workspace_bytes, const dd_conv_desc* d, void* stream);
+/* NCHW-order max_pool1d(4) over relu(u*scale+shift) and its backward (gradient w.r.t. the BN output), C = 32, H*W % 4 == 0 */
+int dd_pool4_bn_fwd(const float* u, const float* affine, float* pooled, int32_t batch, int32_t h, int32_t w, void* stream);
+int dd_pool4_bn_bwd(const float* dpooled, const float* u, const float* affine, float* dfeat, int32_t batch, int32_t h, int32_t w,
+                    void* stream);
+
 /* dw_oihw[32,cin_real,3,3], dbias[32] from x[B,H,W,cin_store] and dy[B,Ho,Wo,32]
  * (dy already multiplied by this layer's ReLU mask).  Deterministic: per-wave partial sums
  * in `workspace`, then a fixed-order reduction. */

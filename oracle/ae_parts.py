@@ -125,3 +125,39 @@ class DecoderNet(nn.Module):
         h = F.relu(F.conv_transpose2d(h, self.dc2.weight, self.dc2.bias, padding=1))
         h = F.relu(F.conv_transpose2d(h, self.dc3.weight, self.dc3.bias, stride=2))
         return F.conv_transpose2d(h, self.dc4.weight, self.dc4.bias)      # no activation (components.py:92)
+
+
+class EncoderNetV2(nn.Module):
+    """Conv -> BatchNorm2d -> ReLU variant, reference src/autoencoder/components_v2.py:6-57.
+
+    That class cannot be constructed (``self.bn3 = nn.Conv2d(32)``, components_v2.py:24, raises TypeError), so there is
+    nothing to import: this is a hand-composed F.conv2d -> F.batch_norm -> relu chain with ``bn3 = BatchNorm2d(32)`` as
+    the evident intent.  PARITY UNPINNED for this variant: no reference run exists to capture fixtures from.
+    """
+
+    def __init__(self, hidden_dim, latent_dim, in_channels, input_height, input_width):
+        super().__init__()
+        self.c1 = nn.Conv2d(in_channels, CONV_CH, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(CONV_CH)
+        self.c2 = nn.Conv2d(CONV_CH, CONV_CH, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(CONV_CH)
+        self.c3 = nn.Conv2d(CONV_CH, CONV_CH, 3, stride=2, padding=1)
+        self.bn3 = nn.BatchNorm2d(CONV_CH)
+        torch.rand(1, in_channels, input_height, input_width)
+        self.fc1 = FcBlock(pooled_len(input_height, input_width), hidden_dim)
+        self.fc2 = FcBlock(hidden_dim, hidden_dim)
+        self.fc_z_out = nn.Linear(hidden_dim, latent_dim)
+        self.c3_only = False
+
+    def _bn(self, bn, x):
+        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, 0.1 if bn.momentum is None else bn.momentum, bn.eps)
+
+    def forward(self, x, masks=(None, None)):
+        x = F.relu(self._bn(self.bn1, F.conv2d(x, self.c1.weight, self.c1.bias, padding=1)))
+        x = F.relu(self._bn(self.bn2, F.conv2d(x, self.c2.weight, self.c2.bias, padding=1)))
+        x = F.relu(self._bn(self.bn3, F.conv2d(x, self.c3.weight, self.c3.bias, stride=2, padding=1)))
+        if self.c3_only:
+            return x
+        flat = x.reshape(x.size(0), 1, -1)
+        h = self.fc1(F.max_pool1d(flat, POOL).squeeze(1), masks[0])
+        return self.fc_z_out(self.fc2(h, masks[1]))

@@ -205,3 +205,48 @@ def test_joint_model_equals_sum_of_heads(dev):
     assert abs(float(out["loss"].detach()) - float((l1 + l2).detach())) / float((l1 + l2).detach()) < 1e-6
     for k, p in joint.named_parameters():
         assert rel_err(gj[k], p.grad, floor=1e-12) < 2e-4, k
+
+
+@pytest.mark.parametrize("hw", [(16, 22), (12, 70)])
+def test_encoder_v2_conv_bn_relu_against_oracle(dev, hw):
+    """components_v2 variant (Conv -> BN2d -> ReLU, stats in the conv epilogue, normalise-on-read) vs the hand-composed
+    fp64 oracle: latent exit, c3_only exit, all gradients, running statistics, eval mode."""
+    from driving_dirty_amd.components_v2 import Encoder
+    from oracle import ae_parts
+    h, w = hw
+    enc = synth.fill_module(Encoder(16, 8, 3, h, w), seed=41)
+    ref = ae_parts.EncoderNetV2(16, 8, 3, h, w).double()
+    ref.load_state_dict(enc.state_dict())
+    enc = enc.to(dev)
+    for m in (enc.fc1, enc.fc2, ref.fc1, ref.fc2):
+        m.drop_p = 0.0
+    x = synth.hash_uniform((4, 3, h, w), synth.key_salt("v2x"), 0.0, 1.0)
+    wz = synth.hash_uniform((4, 8), synth.key_salt("v2w"))
+    enc.train(); ref.train()
+    z = enc(x.to(dev))
+    (z * wz.to(dev)).sum().backward()
+    zr = ref(x.double())
+    (zr * wz.double()).sum().backward()
+    assert rel_err(z, zr) < CHAIN_TOL
+    refp = dict(ref.named_parameters())
+    for k, p in enc.named_parameters():
+        floor = 1e-30
+        if k.endswith("bias") and (k.startswith("c") or k.endswith(".fc1.bias")):      # a bias in front of a BatchNorm: zero gradient
+            floor = float(refp[k[:-4] + "weight"].grad.abs().max())
+        assert rel_err(p.grad, refp[k].grad, floor=floor) < CHAIN_TOL, k
+    refb = dict(ref.named_buffers())
+    for k, b in enc.named_buffers():
+        assert rel_err(b.double(), refb[k].double()) < CHAIN_TOL, k
+    # feature exit
+    enc.zero_grad(); ref.zero_grad()
+    enc.c3_only = ref.c3_only = True
+    f = enc(x.to(dev)); fr = ref(x.double())
+    wf = synth.hash_uniform(tuple(fr.shape), synth.key_salt("v2f"))
+    (f * wf.to(dev)).sum().backward()
+    (fr * wf.double()).sum().backward()
+    assert rel_err(f, fr) < CHAIN_TOL
+    for k in ("c1.weight", "bn1.weight", "bn1.bias", "c2.weight", "bn2.weight", "bn2.bias", "c3.weight", "bn3.weight", "bn3.bias"):
+        assert rel_err(dict(enc.named_parameters())[k].grad, refp[k].grad) < CHAIN_TOL, k
+    enc.c3_only = ref.c3_only = False
+    enc.eval(); ref.eval()
+    assert rel_err(enc(x.to(dev)), ref(x.double())) < CHAIN_TOL
