@@ -150,7 +150,7 @@ class EncoderNetV2(nn.Module):
         self.c3_only = False
 
     def _bn(self, bn, x):
-        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, 0.1 if bn.momentum is None else bn.momentum, bn.eps)
+        return bn(x)      # nn.BatchNorm2d: batch statistics + running-stat update in train mode, running stats in eval
 
     def forward(self, x, masks=(None, None)):
         x = F.relu(self._bn(self.bn1, F.conv2d(x, self.c1.weight, self.c1.bias, padding=1)))

@@ -207,7 +207,7 @@ def test_joint_model_equals_sum_of_heads(dev):
         assert rel_err(gj[k], p.grad, floor=1e-12) < 2e-4, k
 
 
-@pytest.mark.parametrize("hw", [(16, 22), (12, 70)])
+@pytest.mark.parametrize("hw", [(16, 22), (16, 70)])
 def test_encoder_v2_conv_bn_relu_against_oracle(dev, hw):
     """components_v2 variant (Conv -> BN2d -> ReLU, stats in the conv epilogue, normalise-on-read) vs the hand-composed
     fp64 oracle: latent exit, c3_only exit, all gradients, running statistics, eval mode."""
