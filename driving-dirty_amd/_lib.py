@@ -37,6 +37,7 @@ SIGNATURES = {
     "dd_set_cu_budget": (_i32, [_i32]),
     "dd_get_cu_budget": (_i32, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_stitch6_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_nhwc_to_nchw": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -65,6 +66,8 @@ SIGNATURES = {
     "dd_bn_relu_drop_bwd": (_i32, [_p] * 12 + [_i32, _i32, _f32, _f32, _i32, _p]),
     "dd_loss_workspace_bytes": (_i64, [_i64]),
     "dd_bce_logits": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
+    "dd_bce_logits_u8": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
+    "dd_sigmoid": (_i32, [_p, _p, _i64, _p]),
     "dd_mse": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_gconv_packed_floats": (_i64, [_GP]),
     "dd_gconv_pack": (_i32, [_p, _p, _GP, _i64, _i64, _i64, _i32, _i32, _i32, _p]),

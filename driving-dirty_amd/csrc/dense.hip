@@ -95,13 +95,25 @@ __device__ __forceinline__ double block_sum(float v) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ t,
+// TT = float (0/1 values) or unsigned char (bool masks exactly as the dataset hands them over: road_image, data_helper.py)
+template <typename TT>
+__device__ __forceinline__ f32x4 load_target4(const TT* t, long i);
+template <>
+__device__ __forceinline__ f32x4 load_target4<float>(const float* t, long i) { return ((const f32x4*)t)[i]; }
+template <>
+__device__ __forceinline__ f32x4 load_target4<unsigned char>(const unsigned char* t, long i) {
+  const unsigned w = ((const unsigned*)t)[i];
+  return f32x4{(float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24)};
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const TT* __restrict__ t,
                                                          float* __restrict__ dz, float* __restrict__ probs,
                                                          double* __restrict__ partial, long n, float gscale) {
   float s = 0.f;
   const long n4 = n / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 zv = ((const f32x4*)z)[i], tv = ((const f32x4*)t)[i];
+    const f32x4 zv = ((const f32x4*)z)[i], tv = load_target4<TT>(t, i);
     f32x4 g, p;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -116,14 +128,27 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {   // tail (n % 4 elements)
     const long i = 4 * n4 + threadIdx.x;
-    const float e = expf(-fabsf(z[i]));
-    s += fmaxf(z[i], 0.f) - z[i] * t[i] + log1pf(e);
+    const float e = expf(-fabsf(z[i])), ti = (float)t[i];
+    s += fmaxf(z[i], 0.f) - z[i] * ti + log1pf(e);
     const float sig = z[i] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-    if (dz) dz[i] = (sig - t[i]) * gscale;
+    if (dz) dz[i] = (sig - ti) * gscale;
     if (probs) probs[i] = sig;
   }
   const double tot = block_sum(s);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const f32x4* __restrict__ z, f32x4* __restrict__ p, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = z[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float e = expf(-fabsf(v[k]));
+      o[k] = v[k] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    }
+    p[i] = o;
+  }
 }
 
 // BCE on probabilities with torch's clamp of the logs at -100 (F.binary_cross_entropy, spatial_w_rm.py:131).
@@ -281,12 +306,36 @@ int dd_bce_logits(const float* logits, const float* target, float* loss_out, flo
   DD_REQUIRE(((uintptr_t)logits | (uintptr_t)target | (uintptr_t)dlogits | (uintptr_t)probs) % 16 == 0, DD_ERR_BAD_ARG,
              "bce_logits: buffers must be 16-byte aligned");
   const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)kLossBlocks);
-  hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits, probs,
+  hipLaunchKernelGGL(bce_logits_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits, probs,
                      (double*)workspace, (long)n, grad_scale / (float)n);
   DD_LAUNCH_CHECK("bce_logits");
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
                      1.0 / (double)n, loss_out);
   DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_bce_logits_u8(const float* logits, const unsigned char* target, float* loss_out, float* dlogits, float* probs, int64_t n,
+                     float grad_scale, void* workspace, void* stream) {
+  DD_REQUIRE(logits && target && loss_out && workspace && n > 0, DD_ERR_BAD_ARG, "bce_logits_u8: bad argument");
+  DD_REQUIRE(((uintptr_t)logits | (uintptr_t)dlogits | (uintptr_t)probs) % 16 == 0 && (uintptr_t)target % 4 == 0, DD_ERR_BAD_ARG,
+             "bce_logits_u8: misaligned buffer");
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)kLossBlocks);
+  hipLaunchKernelGGL(bce_logits_kernel<unsigned char>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits, probs,
+                     (double*)workspace, (long)n, grad_scale / (float)n);
+  DD_LAUNCH_CHECK("bce_logits_u8");
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
+                     1.0 / (double)n, loss_out);
+  DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_sigmoid(const float* z, float* p, int64_t n, void* stream) {
+  DD_REQUIRE(z && p && n > 0 && n % 4 == 0, DD_ERR_BAD_ARG, "sigmoid: bad argument (n must be a multiple of 4)");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)kLossBlocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)z, (f32x4*)p, n4);
+  DD_LAUNCH_CHECK("sigmoid");
   return 0;
 }
 

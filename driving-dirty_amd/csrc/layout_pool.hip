@@ -38,6 +38,26 @@ __global__ __launch_bounds__(256) void stitch6_kernel(const float* __restrict__ 
   }
 }
 
+// The reference hands the batch over as a TUPLE of per-sample tensors (collate_fn = tuple(zip(*batch)), helper.py:22-23)
+// and stacks them first (roadmap_bce_v2.py:55).  Reading through a table of per-sample base pointers skips that copy.
+struct SamplePtrs {
+  const float* p[64];      // passed by value in the kernel arguments: no device-side table, no extra copy
+};
+
+__global__ __launch_bounds__(256) void stitch6_ptrs_kernel(const SamplePtrs samples, f32x4* __restrict__ wide4,
+                                                           int B, int H, int W) {
+  const long npx = (long)B * H * 6 * W;
+  const long plane = (long)H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(p % (6 * W));
+    const int yy = (int)((p / (6 * W)) % H);
+    const int b = (int)(p / ((long)6 * W * H));
+    const int slot = xw / W, xx = xw - slot * W;
+    const float* src = samples.p[b] + ((long)kViewOrder[slot] * 3) * plane + (long)yy * W + xx;
+    wide4[p] = f32x4{src[0], src[plane], src[2 * plane], 0.f};
+  }
+}
+
 // uint8 HWC camera frames (what a JPEG decoder emits) -> the same wide NHWC4 fp32 image: ToTensor's /255
 // (reference autoencoder.py:133 torchvision.transforms.ToTensor) fused with the gather; 3 bytes in, 16 bytes out.
 __global__ __launch_bounds__(256) void stitch6_u8_kernel(const unsigned char* __restrict__ frames, f32x4* __restrict__ wide4,
@@ -201,6 +221,22 @@ int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* t
   hipLaunchKernelGGL(stitch6_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, views, (f32x4*)wide_nhwc4,
                      wide_nchw, target, batch, height, width, mask_slot);
   DD_LAUNCH_CHECK("stitch6");
+  return 0;
+}
+
+int dd_stitch6_ptrs(const float* const* sample_ptrs, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
+                    void* stream) {
+  DD_REQUIRE(sample_ptrs && wide_nhwc4 && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "stitch6_ptrs: bad argument");
+  for (int b0 = 0; b0 < batch; b0 += 64) {
+    const int nb = min(64, batch - b0);
+    SamplePtrs tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < nb ? sample_ptrs[b0 + i] : nullptr;
+    for (int i = 0; i < nb; ++i) DD_REQUIRE(tab.p[i] != nullptr, DD_ERR_BAD_ARG, "stitch6_ptrs: null sample pointer");
+    const long npx = (long)nb * height * 6 * width;
+    hipLaunchKernelGGL(stitch6_ptrs_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, tab,
+                       (f32x4*)wide_nhwc4 + (long)b0 * height * 6 * width, nb, height, width);
+    DD_LAUNCH_CHECK("stitch6_ptrs");
+  }
   return 0;
 }
 

@@ -57,6 +57,21 @@ def stitch6(views, mask_slot=-1, want_nhwc4=True, want_nchw=False, want_target=F
     return wide4, wide, tgt
 
 
+def stitch6_samples(samples):
+    """Tuple of B per-sample [6,3,H,W] tensors (the reference's collate, helper.py:22-23) -> wide NHWC4, no stack copy."""
+    import ctypes
+    b = len(samples)
+    n, c, h, w = samples[0].shape
+    for t in samples:
+        _dev(t, "sample", (6, 3, h, w))
+    if n != 6 or c != 3:
+        raise _lib.HotpathError(f"stitch6_samples: expected samples of [6,3,H,W], got {tuple(samples[0].shape)}")
+    table = (ctypes.c_void_p * b)(*[t.data_ptr() for t in samples])
+    wide4 = torch.empty((b, h, 6 * w, 4), device=samples[0].device, dtype=torch.float32)
+    check(_lib.lib().dd_stitch6_ptrs(table, _p(wide4), b, h, w, _stream()), "dd_stitch6_ptrs")
+    return wide4
+
+
 def stitch6_u8(frames):
     """frames [B,6,H,W,3] uint8 -> wide NHWC4 fp32 in [0,1] (ToTensor's /255 fused with the 6-view gather)."""
     b, n, h, w, c = frames.shape
@@ -371,12 +386,18 @@ class BceWithLogits(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
         _dev(logits, "logits")
-        _dev(target, "target", logits.shape)
         n = logits.numel()
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         dz = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
-        check(_lib.lib().dd_bce_logits(_p(logits), _p(target), _p(loss), _p(dz), None, n, 1.0, _p(_loss_ws(n, logits.device)),
-                                       _stream()), "dd_bce_logits")
+        if target.dtype in (torch.bool, torch.uint8):      # the dataset's bool road masks, read as bytes
+            if not target.is_cuda or not target.is_contiguous() or target.shape != logits.shape:
+                raise _lib.HotpathError(f"bce: target must be a contiguous GPU tensor of shape {tuple(logits.shape)}")
+            check(_lib.lib().dd_bce_logits_u8(_p(logits), _p(target), _p(loss), _p(dz), None, n, 1.0,
+                                              _p(_loss_ws(n, logits.device)), _stream()), "dd_bce_logits_u8")
+        else:
+            _dev(target, "target", logits.shape)
+            check(_lib.lib().dd_bce_logits(_p(logits), _p(target), _p(loss), _p(dz), None, n, 1.0,
+                                           _p(_loss_ws(n, logits.device)), _stream()), "dd_bce_logits")
         ctx.save_for_backward(dz)
         return loss
 
@@ -425,6 +446,16 @@ class BceProbs(torch.autograd.Function):
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
         return dp * g, None
+
+
+def sigmoid(z):
+    """sigmoid(logits) outside autograd (the reference's second forward output, roadmap_bce_v2.py:81)."""
+    _dev(z, "z")
+    if z.numel() % 4:
+        raise _lib.HotpathError("sigmoid: element count must be a multiple of 4")
+    p = torch.empty_like(z)
+    check(_lib.lib().dd_sigmoid(_p(z), _p(p), z.numel(), _stream()), "dd_sigmoid")
+    return p
 
 
 def sigmoid_and_loss(logits, target):

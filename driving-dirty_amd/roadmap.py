@@ -41,8 +41,10 @@ class RoadMapBCE(LightningModule):
         return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
 
     def _encode(self, sample, keeps=(None, None)):
-        x = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-        wide4 = ops.stitch6(x.contiguous())[0]          # gather + NHWC in one pass, no NCHW intermediate
+        if isinstance(sample, (tuple, list)):           # the collate's tuple: gather straight from the samples
+            wide4 = ops.stitch6_samples([t.contiguous() for t in sample])
+        else:
+            wide4 = ops.stitch6(sample.contiguous())[0]  # gather + NHWC in one pass, no NCHW intermediate
         return self.ae.encoder.forward_nhwc4(wide4, keeps)
 
     def forward(self, x, keeps=(None, None)):
@@ -50,16 +52,20 @@ class RoadMapBCE(LightningModule):
         representations = self._encode(x, keeps)
         y = ops.linear(representations, self.fc1.weight, self.fc1.bias)
         y = y.reshape(y.size(0), 800, 800)
-        return y, torch.sigmoid(y)
+        return y, ops.sigmoid(y.detach())
 
     def _run_step(self, batch, batch_idx, step_name, keeps=(None, None)):
         sample, target, road_image = batch
-        target_rm = torch.stack(tuple(road_image), dim=0).float()
+        masks = torch.stack(tuple(road_image), dim=0)     # bool as the dataset hands them over (data_helper.py:137-139)
         pred_rm, pred_logit_rm = self(sample, keeps)     # (logits, probabilities) -- names as in the reference
-        if self.logger is not None and batch_idx % self.hparams.output_img_freq == 0:
+        logging = self.logger is not None and batch_idx % self.hparams.output_img_freq == 0
+        # the loss reads the bool masks as bytes; the fp32 copy (roadmap_bce_v2.py:87) is only made where it is looked at
+        target_rm = masks.float() if (logging or step_name != "train" or masks.dtype.is_floating_point) else masks
+        if logging:
             self._log_rm_images(self.wide_stitch_six_images(sample), target_rm, pred_logit_rm, step_name)
-        batch_size = target_rm.size(0)
-        loss = ops.BceWithLogits.apply(pred_rm.reshape(batch_size, -1), target_rm.reshape(batch_size, -1))
+        batch_size = masks.size(0)
+        loss_target = masks if masks.dtype in (torch.bool, torch.uint8) else target_rm
+        loss = ops.BceWithLogits.apply(pred_rm.reshape(batch_size, -1), loss_target.reshape(batch_size, -1).contiguous())
         return loss, target_rm, pred_rm, pred_logit_rm
 
     def _log_rm_images(self, x, target_rm, pred_rm, step_name, limit=1):

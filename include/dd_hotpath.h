@@ -76,6 +76,13 @@ int dd_get_cu_budget(void);
 int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* target,
                int32_t batch, int32_t height, int32_t width, int32_t mask_slot, void* stream);
 
+/* The same gather from a HOST array of `batch` per-sample DEVICE base pointers (each [6,3,H,W] contiguous; the table
+ * travels in the kernel arguments, 64 samples per launch): the reference
+ * receives the batch as a tuple of tensors (helper.py:22-23) and torch.stack()s it first (roadmap_bce_v2.py:55);
+ * this skips that copy. */
+int dd_stitch6_ptrs(const float* const* sample_ptrs, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
+                    void* stream);
+
 /* Input pipeline variant: frames [B,6,H,W,3] uint8 as a JPEG decoder emits them -> the same wide
  * NHWC4 fp32 image, with torchvision ToTensor's /255 (reference autoencoder.py:133, data_helper.py:63-68) fused. */
 int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
@@ -186,6 +193,12 @@ int dd_bn_relu_drop_bwd(const float* dy, const float* x, const float* y, const f
 int64_t dd_loss_workspace_bytes(int64_t n);
 int dd_bce_logits(const float* logits, const float* target, float* loss_out, float* dlogits,
                   float* probs, int64_t n, float grad_scale, void* workspace, void* stream);
+/* The same with the target as bytes 0/1 (the dataset's bool road_image, data_helper.py:137-139; n % 4 == 0 or tail
+ * handled): skips the .float() pass of roadmap_bce_v2.py:87. */
+int dd_bce_logits_u8(const float* logits, const unsigned char* target, float* loss_out, float* dlogits, float* probs,
+                     int64_t n, float grad_scale, void* workspace, void* stream);
+/* probs = sigmoid(logits) (roadmap_bce_v2.py:81), n % 4 == 0 */
+int dd_sigmoid(const float* z, float* p, int64_t n, void* stream);
 /* Mean squared error mean((a-b)^2) with optional da = 2(a-b)*grad_scale/n (autoencoder.py:91). */
 int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n, float grad_scale,
            void* workspace, void* stream);

@@ -118,6 +118,9 @@ def test_stitch6(dev, b, h, w, slot):
     assert torch.equal(wide.cpu(), ref)
     assert torch.equal(wide4[..., :3].permute(0, 3, 1, 2).cpu(), ref)
     assert float(wide4[..., 3].abs().max()) == 0.0
+    if slot < 0:      # the collate's tuple of per-sample tensors, gathered without the stack copy
+        samples = [v[i].clone().to(dev) for i in range(b)]
+        assert torch.equal(ops.stitch6_samples(samples), wide4)
 
 
 @pytest.mark.parametrize("b,c,h,w", [(2, 32, 8, 11), (2, 32, 16, 15), (3, 32, 5, 7), (1, 32, 3, 3)])
@@ -212,6 +215,13 @@ def test_losses(dev, n):
     assert rel_err(zd.grad, 2.0 * z.grad) < KERNEL_TOL
     l2, probs = ops.sigmoid_and_loss(zd.detach(), t.float().to(dev))
     assert rel_err(probs, torch.sigmoid(z)) < KERNEL_TOL
+    # bool masks read as bytes: the same arithmetic, so the same bits
+    zb = z.detach().float().to(dev).requires_grad_(True)
+    lb = ops.BceWithLogits.apply(zb, t.bool().to(dev))
+    (lb * 2.0).backward()
+    assert torch.equal(lb.detach(), loss.detach()) and torch.equal(zb.grad, zd.grad)
+    if n % 4 == 0:
+        assert torch.equal(ops.sigmoid(zd.detach()), probs)
     a = hu((n,), "a").double().requires_grad_(True)
     refm = F.mse_loss(t, a)
     refm.backward()
