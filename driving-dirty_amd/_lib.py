@@ -38,6 +38,7 @@ SIGNATURES = {
     "dd_get_cu_budget": (_i32, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_stitch6_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "dd_boxes_to_binary_map": (_i32, [_p, _i32, _p, _p, _i32, _p]),
     "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_nhwc_to_nchw": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -13,7 +13,7 @@ from torch import nn
 from . import ops
 from .autoencoder import BasicAE
 from .lightning import LightningModule, hparam
-from .spatial import RoadMapBoxesMergingCNN, SpatialMappingCNN
+from .spatial import RoadMapBoxesMergingCNN, SpatialMappingCNN, bb_coord_to_map
 
 
 class JointRoadMapBBox(LightningModule):
@@ -40,7 +40,7 @@ class JointRoadMapBBox(LightningModule):
         sample, target, road_image = batch
         sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
         target_rm = torch.stack(tuple(road_image), dim=0).float()
-        target_bb = torch.stack([t["bb_map"] for t in target], dim=0).to(sample.device).float()
+        target_bb = bb_coord_to_map(target, sample.device).to(sample.device).float()
         logits, boxes = self(sample, target_rm.unsqueeze(1))
         b = target_rm.size(0)
         loss_rm = ops.BceWithLogits.apply(logits.reshape(b, -1), target_rm.reshape(b, -1))

@@ -72,6 +72,32 @@ def stitch6_samples(samples):
     return wide4
 
 
+def boxes_to_binary_map(box_sets, device=None):
+    """List of per-sample [n,2,4] corner tensors (f64 as the dataset holds them, or f32) -> [B,800,800] fp32 0/1 maps:
+    boxes_to_binary_map (bb_to_img.py:5-20) for the whole batch in one launch, bit-identical to the Pillow fill."""
+    import ctypes
+    b = len(box_sets)
+    if b == 0:
+        raise _lib.HotpathError("boxes_to_binary_map: empty batch")
+    dtype = box_sets[0].dtype
+    if dtype not in (torch.float64, torch.float32) or any(t.dtype != dtype for t in box_sets):
+        raise _lib.HotpathError("boxes_to_binary_map: boxes must all be float64 or all float32")
+    for t in box_sets:
+        if t.dim() != 3 or tuple(t.shape[1:]) != (2, 4):
+            raise _lib.HotpathError(f"boxes_to_binary_map: expected [n,2,4] boxes, got {tuple(t.shape)}")
+    if device is None:
+        device = next((t.device for t in box_sets if t.is_cuda), None)
+    if device is None or torch.device(device).type != "cuda":
+        raise _lib.HotpathError("boxes_to_binary_map: no GPU device given (the rasteriser has no CPU fallback)")
+    counts = [int(t.shape[0]) for t in box_sets]
+    offsets = (ctypes.c_int32 * (b + 1))(0, *[sum(counts[:i + 1]) for i in range(b)])
+    flat = torch.cat([t.reshape(-1, 8) for t in box_sets], dim=0).to(device).contiguous()
+    maps = torch.empty((b, 800, 800), device=device, dtype=torch.float32)
+    check(_lib.lib().dd_boxes_to_binary_map(_p(flat) if flat.numel() else None, 0 if dtype == torch.float64 else 1, offsets,
+                                            _p(maps), b, _stream()), "dd_boxes_to_binary_map")
+    return maps
+
+
 def stitch6_u8(frames):
     """frames [B,6,H,W,3] uint8 -> wide NHWC4 fp32 in [0,1] (ToTensor's /255 fused with the 6-view gather)."""
     b, n, h, w, c = frames.shape

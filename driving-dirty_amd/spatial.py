@@ -95,10 +95,20 @@ class RoadMapBoxesMergingCNN(_Merging):
         return self._run(ssr, spatial_map, rm)
 
 
+def bb_coord_to_map(target, device=None, rasterizer=None):
+    """Targets -> [b,800,800] maps: pre-rasterised ``'bb_map'`` entries are taken as they are, a caller-supplied
+    ``rasterizer`` is honoured, everything else goes through the HIP rasteriser in one launch."""
+    if all("bb_map" in t for t in target):
+        return torch.stack([t["bb_map"] for t in target], dim=0)
+    if rasterizer is not None:
+        return torch.stack([torch.as_tensor(rasterizer(t["bounding_box"])) for t in target], dim=0)
+    return ops.boxes_to_binary_map([t["bounding_box"] for t in target], device)
+
+
 class BBSpatialRoadMap(LightningModule):
-    """spatial_w_rm.py:25-167.  ``bb_coord_to_map`` (PIL polygon rasteriser, src/utils/bb_to_img.py) is host-side
-    target preparation outside the hot path: batches may carry a pre-rasterised ``'bb_map'`` [800,800] tensor in each
-    target dict (what the bench and tests use); otherwise a rasteriser must be supplied as ``hparams.rasterizer``."""
+    """spatial_w_rm.py:25-167.  ``bb_coord_to_map`` (the per-sample PIL polygon loop of src/utils/bb_to_img.py) runs
+    as one launch of the HIP rasteriser over the batch's ``'bounding_box'`` tensors; batches may instead carry a
+    pre-rasterised ``'bb_map'`` [800,800] tensor in each target dict, or name their own ``hparams.rasterizer``."""
 
     def __init__(self, hparams):
         super().__init__()
@@ -123,22 +133,14 @@ class BBSpatialRoadMap(LightningModule):
         yhat = self.box_merge(ssr, space_rep, rm)
         return yhat.squeeze(1)
 
-    def bb_coord_to_map(self, target):
-        maps = []
-        for sample in target:
-            if "bb_map" in sample:
-                maps.append(sample["bb_map"])
-            else:
-                raster = hparam(self.hparams, "rasterizer", None)
-                if raster is None:
-                    raise RuntimeError("targets carry no pre-rasterised 'bb_map' and no hparams.rasterizer was given")
-                maps.append(torch.as_tensor(raster(sample["bounding_box"])))
-        return torch.stack(maps, dim=0)
+    def bb_coord_to_map(self, target, device=None):
+        """tuple of b target dicts -> [b,800,800].  spatial_w_rm.py:85-95."""
+        return bb_coord_to_map(target, device, hparam(self.hparams, "rasterizer", None))
 
     def _run_step(self, batch, batch_idx, step_name):
         sample, target, road_image = batch
         sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-        target_bb_img = self.bb_coord_to_map(target).to(sample.device).type_as(sample)
+        target_bb_img = self.bb_coord_to_map(target, sample.device).to(sample.device).type_as(sample)
         rm = torch.stack(tuple(road_image), dim=0).float().unsqueeze(1)
         pred_bb_img = self(sample, rm)
         batch_size = target_bb_img.size(0)

@@ -75,3 +75,29 @@ def camera_batch(batch, height=256, width=306, seed=1, views=6, channels=3):
 def road_maps(batch, seed=1, size=800, density=0.3):
     """[B,size,size] bool road masks (reference data_helper.py road_image)."""
     return hash_uniform((batch, size, size), key_salt("road", seed), 0.0, 1.0) < density
+
+
+def car_boxes(n_boxes, seed=1):
+    """[n,2,4] float64 car-like rotated rectangles in metres (corner order fl, fr, bl, br; rows x then y), as the
+    dataset's ``target['bounding_box']`` holds them (reference data_helper.py:118-129).  Half are nearly axis-aligned
+    (lane traffic), some poke out of the +-40 m map."""
+    u = hash_uniform((n_boxes, 6), key_salt("cars", seed), 0.0, 1.0, dtype=torch.float64).numpy()
+    cx, cy = u[:, 0] * 84.0 - 42.0, u[:, 1] * 84.0 - 42.0
+    length, width = 3.5 + 2.5 * u[:, 2], 1.6 + 0.8 * u[:, 3]
+    theta = np.where(u[:, 4] < 0.5, np.round(u[:, 5] * 4.0) * (np.pi / 2) + (u[:, 4] - 0.25) * 0.2, u[:, 5] * 2.0 * np.pi)
+    c, s = np.cos(theta), np.sin(theta)
+    local = np.array([[0.5, 0.5], [0.5, -0.5], [-0.5, 0.5], [-0.5, -0.5]])              # fl fr bl br
+    lx, ly = local[None, :, 0] * length[:, None], local[None, :, 1] * width[:, None]
+    xs = cx[:, None] + lx * c[:, None] - ly * s[:, None]
+    ys = cy[:, None] + lx * s[:, None] + ly * c[:, None]
+    return torch.from_numpy(np.stack([xs, ys], axis=1))
+
+
+def wild_quads(n_boxes, seed=1):
+    """[n,2,4] float64 arbitrary quadrilaterals (self-intersecting, slivers, far outside the map): rasteriser edge cases."""
+    u = hash_uniform((n_boxes, 2, 4), key_salt("quads", seed), 0.0, 1.0, dtype=torch.float64).numpy()
+    big = u * 96.0 - 48.0
+    c = hash_uniform((n_boxes, 2, 1), key_salt("quadc", seed), -41.0, 41.0, dtype=torch.float64).numpy()
+    small = c + (u - 0.5) * 3.0
+    pick = (np.arange(n_boxes) % 3 == 0)[:, None, None]
+    return torch.from_numpy(np.where(pick, big, small))

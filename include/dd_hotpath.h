@@ -83,6 +83,15 @@ int dd_stitch6(const float* views, float* wide_nhwc4, float* wide_nchw, float* t
 int dd_stitch6_ptrs(const float* const* sample_ptrs, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
                     void* stream);
 
+/* Box rasteriser for a whole batch: boxes_to_binary_map (src/utils/bb_to_img.py:5-20) as called per sample by
+ * bb_coord_to_map (src/bounding_box_model/spatial_bb/spatial_w_rm.py:85-95).  `boxes` = the samples' [n,2,4] corner
+ * tensors concatenated on the DEVICE (boxes_dtype 0 = f64 as the dataset holds them, data_helper.py:129; 1 = f32);
+ * `sample_offsets` = HOST array of batch+1 box indices (sample s owns boxes [off[s], off[s+1]); empty samples give an
+ * all-zero map).  maps = [batch,800,800] fp32 0/1 with the vertical flip applied, bit-identical to
+ * Pillow 12.2's ImageDraw.polygon fill. */
+int dd_boxes_to_binary_map(const void* boxes, int32_t boxes_dtype, const int32_t* sample_offsets, float* maps,
+                           int32_t batch, void* stream);
+
 /* Input pipeline variant: frames [B,6,H,W,3] uint8 as a JPEG decoder emits them -> the same wide
  * NHWC4 fp32 image, with torchvision ToTensor's /255 (reference autoencoder.py:133, data_helper.py:63-68) fused. */
 int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,

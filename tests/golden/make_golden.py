@@ -8,6 +8,7 @@ Runs only in the build container (needs /root/reference on disk; the GPU box nev
 It imports the two torch-only reference files
     src/autoencoder/components.py                       (Encoder, Decoder, DenseBlock)
     src/bounding_box_model/spatial_bb/components.py     (SpatialMappingCNN, BoxesMergingCNN, RoadMapBoxesMergingCNN)
+and, for the box rasteriser, src/utils/bb_to_img.py (numpy + Pillow),
 fills their parameters and inputs from the closed-form generator in
 ``driving_dirty_amd.synth`` (so every consumer can rebuild the same tensors without the
 reference), runs forward + backward in fp32 and fp64 and stores outputs / gradients.
@@ -203,12 +204,36 @@ def spatial_heads(out):
     np.savez_compressed(out, **res)
 
 
+def box_raster(out):
+    """Reference boxes_to_binary_map (src/utils/bb_to_img.py:5-20, Pillow underneath) on synthetic car boxes and on
+    arbitrary quadrilaterals.  Inputs are stored too (their construction goes through libm's sin/cos)."""
+    import PIL
+    import importlib.util
+    # the file itself needs only numpy + Pillow; its package __init__ pulls in torchvision, which this image lacks,
+    # so the module is loaded by path
+    spec = importlib.util.spec_from_file_location("ref_bb_to_img", "/root/reference/src/utils/bb_to_img.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    boxes_to_binary_map = mod.boxes_to_binary_map  # reference
+    res = {"pillow_version": np.array(PIL.__version__)}
+    sets = {"cars_a": synth.car_boxes(24, 1), "cars_b": synth.car_boxes(40, 2), "cars_f32": synth.car_boxes(16, 3).float(),
+            "quads_a": synth.wild_quads(36, 1), "quads_b": synth.wild_quads(60, 2), "empty": torch.zeros(0, 2, 4, dtype=torch.float64)}
+    for name, boxes in sets.items():
+        m = np.ascontiguousarray(boxes_to_binary_map(boxes))
+        assert m.shape == (800, 800) and set(np.unique(m)) <= {0.0, 1.0}
+        res[f"{name}_boxes"] = _np(boxes)
+        res[f"{name}_map_bits"] = np.packbits(m.astype(np.uint8), axis=1)
+        res[f"{name}_ones"] = np.array(int(m.sum()))
+    np.savez_compressed(out, **res)
+
+
 CASES = {
     "tiny_encoder": tiny_encoder,
     "tiny_decoder": tiny_decoder,
     "default_init": default_init,
     "full_roadmap": full_roadmap,
     "spatial_heads": spatial_heads,
+    "box_raster": box_raster,
 }
 
 if __name__ == "__main__":
