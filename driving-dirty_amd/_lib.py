@@ -89,6 +89,17 @@ SIGNATURES = {
     "dd_linear_wgrad": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_threat_score_workspace_bytes": (_i64, []),
     "dd_threat_score": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
+    "dd_stitch6_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "dd_conv_bf16_packed_elems": (_i64, [_p]),
+    "dd_conv_bf16_pack": (_i32, [_p, _p, _i32, _p, _p]),
+    "dd_conv_bf16_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _p]),
+    "dd_conv_bf16_dgrad": (_i32, [_p, _p, _p, _p, _p, _p]),
+    "dd_conv_bf16_wgrad_workspace_bytes": (_i64, [_p]),
+    "dd_conv_bf16_wgrad": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _p]),
+    "dd_pool4_bf16_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_pool4_relu_bf16_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
+    "dd_bf16_to_f32": (_i32, [_p, _p, _i64, _p]),
     "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 

@@ -309,6 +309,35 @@ int dd_threat_score(const float* a, const float* b, float* out, int64_t n, int32
 int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, void* stream);
 
+/* ---- bf16 mixed precision (BASELINE config 5: 6x3x512x612 inputs, bf16) ---------------------------------
+ * The encoder conv stack (components.py:19-21,41-43) with bf16 operands on the bf16 matrix cores and fp32
+ * accumulation: activations and activation gradients are NHWC bf16 (raw uint16 bit patterns in this ABI), rounded
+ * to nearest even exactly once where they are written; weights, biases and their gradients stay fp32.  The FC tail,
+ * BatchNorm, losses and Adam are the fp32 entry points above.  The reference has no mixed-precision mode: the
+ * contract is "torch autocast equivalent" -- a conv evaluated on bf16-rounded inputs and weights with fp32
+ * accumulation, its output rounded to bf16 (oracle: oracle/bf16_parts.py). */
+int dd_stitch6_bf16(const float* views, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width, void* stream);
+int64_t dd_conv_bf16_packed_elems(const dd_conv_desc* d);                 /* uint16 elements of an operand image */
+/* kind as dd_conv_pack: 0 forward, 1 stride-1 data gradient, 2 stride-2 data gradient */
+int dd_conv_bf16_pack(const float* weight, const dd_conv_desc* d, int32_t kind, uint16_t* packed, void* stream);
+/* y = bf16(relu(conv(x) + bias)); relu_bits (nullable) [B,Ho,Wo] uint32 = mask of (y > 0) over the 32 channels */
+int dd_conv_bf16_fwd(const uint16_t* x, const uint16_t* packed, const float* bias, uint16_t* y, uint32_t* relu_bits,
+                     const dd_conv_desc* d, void* stream);
+/* dx = bf16(dgrad(dy) * bit(channel) of relu_bits[pixel]) with relu_bits [B,H,W] of the conv's INPUT activation */
+int dd_conv_bf16_dgrad(const uint16_t* dy, const uint16_t* packed, const uint32_t* relu_bits, uint16_t* dx,
+                       const dd_conv_desc* d, void* stream);
+int64_t dd_conv_bf16_wgrad_workspace_bytes(const dd_conv_desc* d);
+/* dweight [32,Cin,3,3], dbias [32] fp32 from bf16 x and dy, fp32 accumulation, deterministic two-stage reduction */
+int dd_conv_bf16_wgrad(const uint16_t* x, const uint16_t* dy, float* dweight, float* dbias, const dd_conv_desc* d,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+/* max_pool1d(4) over the NCHW-flattened feature (components.py:46-47) from NHWC bf16; H*W % 4 == 0, C % 4 == 0 */
+int dd_pool4_bf16_fwd(const uint16_t* feat, float* pooled, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* its backward with the ReLU in front of the pool fused (feat > 0), gradient written in bf16 */
+int dd_pool4_relu_bf16_bwd(const float* dpooled, const uint16_t* feat, uint16_t* dfeat, int32_t batch, int32_t h,
+                           int32_t w, int32_t c, void* stream);
+int dd_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);     /* n % 4 == 0, round to nearest even */
+int dd_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
