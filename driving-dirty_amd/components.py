@@ -101,9 +101,20 @@ class Encoder(nn.Module):
         self.fc_z_out = nn.Linear(hidden_dim, latent_dim)
         self.c3_only = False
         self.rows_per_task = 0     # kernel tuning knob (never changes results)
+        # "fp32" (the reference's arithmetic) or "bf16": conv stack on the bf16 matrix cores with fp32 accumulation,
+        # activations stored in bf16 (BASELINE config 5); the FC tail and every parameter stay fp32 either way
+        self.precision = "fp32"
 
     def forward_nhwc4(self, x4, keeps=(None, None)):
-        """x4: [B,H,W,4] NHWC image (channel 3 zero), e.g. straight from ``ops.stitch6``."""
+        """x4: [B,H,W,4] NHWC image (channel 3 zero), e.g. straight from ``ops.stitch6`` (fp32) or
+        ``ops_bf16.stitch6_bf16`` (bf16: selects the mixed-precision conv stack)."""
+        if x4.dtype == torch.bfloat16:
+            if self.c3_only:
+                raise NotImplementedError("the bf16 conv stack feeds the pooled exit only (c3_only is fp32)")
+            from . import ops_bf16
+            pooled = ops_bf16.encoder_conv_stack(x4, self.c1, self.c2, self.c3)
+            h = self.fc2(self.fc1(pooled, keeps[0]), keeps[1])
+            return ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
         if self.c3_only:
             feat = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, False, self.rows_per_task)
             return feat.permute(0, 3, 1, 2)         # NCHW-shaped view of the NHWC buffer
@@ -121,4 +132,8 @@ class Encoder(nn.Module):
 
     def forward(self, x, keeps=(None, None)):
         _require_gpu(x, "Encoder")
-        return self.forward_nhwc4(ops.nchw_to_nhwc(x.contiguous(), 4), keeps)
+        x4 = ops.nchw_to_nhwc(x.contiguous(), 4)
+        if self.precision == "bf16":
+            from . import ops_bf16
+            x4 = ops_bf16.to_bf16(x4)
+        return self.forward_nhwc4(x4, keeps)

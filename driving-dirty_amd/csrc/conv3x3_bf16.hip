@@ -110,21 +110,54 @@ __device__ __forceinline__ void wave_range(long total, int gw, int nw, long& idx
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // accumulator row -> channel
 
-// The accumulator (16 channels of one pixel per lane) -> 4 packed 8-byte stores; `pix_off` = byte offset of the pixel.
-__device__ __forceinline__ void store_pixel16(__amdgpu_buffer_rsrc_t rs, int pix_off, int h, const float (&v)[16]) {
+// Output staging.  The accumulator holds 16 channels of ONE pixel per lane; written straight to HBM that is 8-byte
+// pieces scattered at a 64-byte pitch (4 partial requests per pixel -- measured: the store path, not HBM, then bounds
+// the kernel).  Instead the tile goes through a per-wave LDS image (64-byte pixels, 16-byte chunks XOR-swizzled so
+// that the four 8-byte writes of a wave are conflict-free) and leaves lane-linear: every store instruction writes
+// 1 KB of contiguous memory, exactly like the loads.
+__device__ __forceinline__ int stage_swz(int pix) { return (pix >> 1) & 3; }
+
+__device__ __forceinline__ void stage_pixel16(char* tile, int pix, int h, const float (&v)[16]) {
+  const int sw = stage_swz(pix);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     u32x2 w;
     w.x = pack_bf16(v[4 * g], v[4 * g + 1]);
     w.y = pack_bf16(v[4 * g + 2], v[4 * g + 3]);
-    bstore2(rs, pix_off + (8 * g + 4 * h) * 2, w);
+    *(u32x2*)(tile + pix * 64 + ((g ^ sw) << 4) + h * 8) = w;
+  }
+}
+
+// NPIX staged pixels -> row bytes [base_off, base_off + 64*NPIX) of the descriptor (out-of-row pixels are dropped)
+template <int NPIX>
+__device__ __forceinline__ void flush_tile(const char* tile, __amdgpu_buffer_rsrc_t rs, int base_off, int lane) {
+#pragma unroll
+  for (int k = 0; k < NPIX / 16; ++k) {
+    const int c = 64 * k + lane;
+    const int pix = c >> 2, q = c & 3;
+    const u32x4 v = *(const u32x4*)(tile + pix * 64 + ((q ^ stage_swz(pix)) << 4));
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, base_off + c * 16, 0, 0);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward (EPI 0: y = bf16(relu(conv + bias)) + optional sign bits) and stride-1 data gradient
-// (EPI 1: y = bf16(conv * bit(channel) of bits_in[pixel]))
+// (EPI 1: y = bf16(conv * bit(channel) of bits_in[pixel])).
+//
+// Memory pipeline.  vmcnt counts loads AND stores in issue order, and at 0.3 us of MFMA work per row there is no long
+// compute phase for a store acknowledgement to hide behind: a wait that is even one operation too strict makes every
+// row pay the full HBM write latency (measured: 2.4 us per row, 4x the roofline time).  So the loop is written for
+// EXACT counted waits: two register slots (A, B) hold the rows in flight two iterations ahead, every iteration issues
+// the same vector-memory sequence with no conditional operation in it (absent outputs and rows past the range go to a
+// zero-size descriptor: the hardware drops them but still counts them), and the prologue issues the same sequence
+// with dummy stores, so that the state at the loop header is identical from both predecessors.
 // ------------------------------------------------------------------------------------------------
+template <int CIN, int S>
+struct InFlight {          // what one iteration prefetches: the new input rows of an output row + that row's sign word
+  typename RowRegs<CIN>::T rows[S][BCfg<CIN, S>::NLOAD];
+  unsigned mword;
+};
+
 template <int CIN, int S, int EPI, int WPB>
 __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* __restrict__ x, const bf16x8* __restrict__ wp,
                                                          const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
@@ -135,16 +168,20 @@ __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* _
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* ring = smem + wave * C::WAVEB;
+  constexpr int WAVEB = C::WAVEB + 2048;                  // ring + landing zone + output staging tile
+  float* bias_lds = (float*)smem;                         // 32 floats (128 B) in front of the waves' regions
+  char* ring = smem + 128 + wave * WAVEB;
   char* spill = ring + 3 * C::SLOTB;
+  char* tile = ring + C::WAVEB;
   const int h = lane >> 5, n = lane & 31;
+  if (EPI == 0) {
+    if (threadIdx.x < 32) bias_lds[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+  }
 
   bf16x8 wreg[C::NW];
 #pragma unroll
   for (int i = 0; i < C::NW; ++i) wreg[i] = wp[i * 64 + lane];
-  float bv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = (EPI == 0) ? bias[chan_of(r, h)] : 0.f;
 
   long idx, end;
   wave_range((long)B * nstrips * Ho, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
@@ -157,86 +194,133 @@ __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* _
     const unsigned short* xb = x + (long)b * H * W * CIN;
     const int gx0 = S * x0 - 1;
 
+    // group(t): the input rows output row t+1 adds to the window, and the sign word of output row t
+    auto issue = [&](int t, InFlight<CIN, S>& f) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      R t[C::NLOAD];
-      const int iy = S * y0 - 1 + d;
-      load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
-      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
-    }
-
-    for (int yy = y0; yy < y1; ++yy) {
-      R pre[S][C::NLOAD];
-#pragma unroll
-      for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
-      unsigned mword = 0;
+      for (int s2 = 0; s2 < S; ++s2) load_row<CIN, S>(xb, H, W, S * t + 2 + s2, gx0, lane, f.rows[s2]);
       if (EPI == 1) {
-        const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * Ho + yy) * Wo, Wo * 4);
-        mword = bload1(ms, (x0 + n) * 4);
+        const bool ok = t < y1;
+        const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * Ho + (ok ? t : 0)) * Wo, ok ? Wo * 4 : 0);
+        f.mword = bload1(ms, (x0 + n) * 4);
       }
+    };
+    // one output row: compute from the ring, retire `cur` (rows for the next output row), write row t
+    auto step = [&](int t, InFlight<CIN, S>& cur, InFlight<CIN, S>& nxt) {
+      issue(t + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);      // loads stay above the MFMA chain
 
       f32x16 acc;
+      if (EPI == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bq = *(const f32x4*)(bias_lds + 8 * g + 4 * h);
+          acc[4 * g] = bq.x; acc[4 * g + 1] = bq.y; acc[4 * g + 2] = bq.z; acc[4 * g + 3] = bq.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
       if constexpr (CIN == 32) {
+        // operand reads run three taps ahead of the MFMAs that consume them (an LDS read is ~4 MFMAs of latency)
+        const char* rowp[3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const char* rowb = ring + ((S * yy + dy) % 3) * C::SLOTB;
+        for (int dy = 0; dy < 3; ++dy) rowp[dy] = ring + ((S * t + dy) % 3) * C::SLOTB;
+        bf16x8 op[9][2];
+        auto rd = [&](int tap) {
+          const int q = S * n + tap % 3;
+          const char* pa = rowp[tap / 3] + q * 64;
+          const int sw = swz(q);
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int q = S * n + dx;
-            const char* pa = rowb + q * 64;
-            const int sw = swz(q);
+          for (int m = 0; m < 2; ++m) op[tap][m] = __builtin_bit_cast(bf16x8, *(const u32x4*)(pa + (((2 * m + h) ^ sw) << 4)));
+        };
+        rd(0); rd(1); rd(2);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const bf16x8 px = __builtin_bit_cast(bf16x8, *(const u32x4*)(pa + (((2 * m + h) ^ sw) << 4)));
-              acc = BF_MFMA(wreg[(dy * 3 + dx) * 2 + m], px, acc);
-            }
-          }
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap + 3 < 9) rd(tap + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          acc = BF_MFMA(wreg[tap * 2], op[tap][0], acc);
+          acc = BF_MFMA(wreg[tap * 2 + 1], op[tap][1], acc);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {   // k16 step = the 4 channels of pixels n + 2h, n + 2h + 1 (dx = 2h, 2h+1; dx = 3 has zero weights)
+        bf16x8 op[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          const char* pa = ring + ((S * yy + dy) % 3) * C::SLOTB + (n + 2 * h) * 8;
+          const char* pa = ring + ((S * t + dy) % 3) * C::SLOTB + (n + 2 * h) * 8;
           u32x4 v;
           const u32x2 lo = *(const u32x2*)pa, hi = *(const u32x2*)(pa + 8);
           v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
-          acc = BF_MFMA(wreg[dy], __builtin_bit_cast(bf16x8, v), acc);
+          op[dy] = __builtin_bit_cast(bf16x8, v);
         }
-      }
-
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const int iy = S * yy + 2 + s;
-        store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, pre[s]);
+        for (int dy = 0; dy < 3; ++dy) acc = BF_MFMA(wreg[dy], op[dy], acc);
       }
 
-      const long opix = (long)(b * Ho + yy) * Wo;
-      const __amdgpu_buffer_rsrc_t ys = rsrc(y + opix * 32, Wo * 64);
+      // retire the rows output row t+1 needs into the ring slots row t no longer uses
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) {
+        const int iy = S * t + 2 + s2;
+        store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, cur.rows[s2]);
+      }
+
+      const bool live = t < y1;                 // the second half of the last pair may be a dummy row: stores dropped
+      const long opix = (long)(b * Ho + (live ? t : 0)) * Wo;
+      const __amdgpu_buffer_rsrc_t ys = rsrc(y + opix * 32, live ? Wo * 64 : 0);
       float v[16];
       unsigned mine = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (EPI == 0) {
-          v[r] = fmaxf(acc[r] + bv[r], 0.f);
+          v[r] = fmaxf(acc[r], 0.f);
           mine |= (v[r] > 0.f ? 1u : 0u) << chan_of(r, h);
         } else {
-          v[r] = ((mword >> chan_of(r, h)) & 1u) ? acc[r] : 0.f;
+          v[r] = ((cur.mword >> chan_of(r, h)) & 1u) ? acc[r] : 0.f;
         }
       }
-      store_pixel16(ys, (x0 + n) * 64, h, v);
-      if (EPI == 0 && bits_out != nullptr) {   // the two half-waves hold the two 16-channel halves of pixel n's word
+      stage_pixel16(tile, n, h, v);
+      flush_tile<32>(tile, ys, x0 * 64, lane);
+      if (EPI == 0) {   // the two half-waves hold the two 16-channel halves of pixel n's word
         const unsigned word = mine | (unsigned)__shfl_xor((int)mine, 32);
-        const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + opix, Wo * 4);
+        const bool want = live && bits_out != nullptr;
+        const __amdgpu_buffer_rsrc_t bs = rsrc(want ? bits_out + opix : (unsigned*)y, want ? Wo * 4 : 0);
         bstore1(bs, (h == 0) ? (x0 + n) * 4 : -16, word);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      R t3[C::NLOAD];
+      const int iy = S * y0 - 1 + d;
+      load_row<CIN, S>(xb, H, W, iy, gx0, lane, t3);
+      store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t3);
     }
+    InFlight<CIN, S> fa, fb;
+    fa.mword = 0; fb.mword = 0;
+    issue(y0, fa);
+    asm volatile("" ::: "memory");            // keep the loads in front of the mirror stores at IR level too
+    __builtin_amdgcn_sched_barrier(0);
+    {   // mirror the loop body's stores so that the loop header sees the same queue from both predecessors
+      const __amdgpu_buffer_rsrc_t none = rsrc(y, 0);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      __builtin_amdgcn_raw_buffer_store_b128(z, none, lane * 16, 0, 0);          // distinct offsets: two stores, not one
+      __builtin_amdgcn_raw_buffer_store_b128(z, none, 1024 + lane * 16, 0, 0);
+      if (EPI == 0) bstore1(none, lane * 4, 0u);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    int t = y0;               // y0 < y1 always: a do-while keeps prologue and first iteration in one straight line
+    do {
+      step(t, fa, fb);
+      step(t + 1, fb, fa);
+      t += 2;
+    } while (t < y1);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// stride-2 data gradient by output parity class (tap lists as in conv3x3.hip's conv_s2_dgrad)
+// stride-2 data gradient by output parity class (tap lists as in conv3x3.hip's conv_s2_dgrad).  The two column
+// parities of an output row are staged into ONE 64-pixel image so the row leaves as contiguous 4 KB.
 // ------------------------------------------------------------------------------------------------
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void bf_s2_dgrad(const unsigned short* __restrict__ dy, const bf16x8* __restrict__ wp,
@@ -246,8 +330,10 @@ __global__ __launch_bounds__(WPB * 64) void bf_s2_dgrad(const unsigned short* __
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* ring = smem + wave * C::WAVEB;
+  constexpr int WAVEB = C::WAVEB + 4096;
+  char* ring = smem + wave * WAVEB;
   char* spill = ring + 3 * C::SLOTB;
+  char* tile = ring + C::WAVEB;
   const int h = lane >> 5, n = lane & 31;
   const int nr = (H + 1) / 2;
 
@@ -281,9 +367,8 @@ __global__ __launch_bounds__(WPB * 64) void bf_s2_dgrad(const unsigned short* __
       for (int py = 0; py < 2; ++py) {
         const int yi = 2 * r + py;
         const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * H + min(yi, H - 1)) * W, (yi < H) ? W * 4 : 0);
-        const u32x2 two = bload2(ms, 2 * (s0 + n) * 4);      // W odd: the last pair's second word is range-checked away
-        mw[py][0] = two.x;
-        mw[py][1] = (2 * (s0 + n) + 1 < W) ? two.y : 0u;
+        mw[py][0] = bload1(ms, (2 * (s0 + n)) * 4);
+        mw[py][1] = bload1(ms, (2 * (s0 + n) + 1) * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
 
@@ -292,7 +377,6 @@ __global__ __launch_bounds__(WPB * 64) void bf_s2_dgrad(const unsigned short* __
 #define BF_TILE(PY, PX, NTAP, ...)                                                                     \
   {                                                                                                    \
     constexpr int taps[NTAP][3] = {__VA_ARGS__};                                                       \
-    const int yi = 2 * r + (PY);                                                                       \
     f32x16 acc;                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                       \
     _Pragma("unroll") for (int t = 0; t < NTAP; ++t) {                                                 \
@@ -305,18 +389,26 @@ __global__ __launch_bounds__(WPB * 64) void bf_s2_dgrad(const unsigned short* __
         acc = BF_MFMA(wreg[taps[t][2] * 2 + m], px, acc);                                              \
       }                                                                                                \
     }                                                                                                  \
-    const __amdgpu_buffer_rsrc_t os = rsrc(dx + ((long)(b * H + min(yi, H - 1)) * W) * 32, (yi < H) ? W * 64 : 0); \
     float v[16];                                                                                       \
     _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                                  \
       v[rr] = ((mw[PY][PX] >> chan_of(rr, h)) & 1u) ? acc[rr] : 0.f;                                   \
-    store_pixel16(os, (2 * (s0 + n) + (PX)) * 64, h, v);                                               \
+    stage_pixel16(tile, 2 * n + (PX), h, v);                                                           \
+  }
+#define BF_FLUSH(PY)                                                                                   \
+  {                                                                                                    \
+    const int yi = 2 * r + (PY);                                                                       \
+    const __amdgpu_buffer_rsrc_t os = rsrc(dx + ((long)(b * H + min(yi, H - 1)) * W) * 32, (yi < H) ? W * 64 : 0); \
+    flush_tile<64>(tile, os, 2 * s0 * 64, lane);                                                       \
   }
       BF_TILE(1, 1, 4, {1, 1, 0}, {1, 0, 2}, {0, 1, 6}, {0, 0, 8})
       store_row<32, 1, true>(ring + ((r + 2) % 3) * C::SLOTB, spill, lane, pre);
-      BF_TILE(0, 1, 2, {0, 1, 3}, {0, 0, 5})
       BF_TILE(1, 0, 2, {1, 0, 1}, {0, 0, 7})
+      BF_FLUSH(1)
+      BF_TILE(0, 1, 2, {0, 1, 3}, {0, 0, 5})
       BF_TILE(0, 0, 1, {0, 0, 4})
+      BF_FLUSH(0)
 #undef BF_TILE
+#undef BF_FLUSH
     }
   }
 }
@@ -697,7 +789,7 @@ template <int CIN, int S, int EPI>
 int launch_strip(const unsigned short* x, const unsigned short* wp, const float* bias, const unsigned* bits_in, unsigned short* y,
                  unsigned* bits_out, const Geo& g, hipStream_t st) {
   auto kern = bf_strip_fwd<CIN, S, EPI, kWPB>;
-  const size_t lds = (size_t)kWPB * BCfg<CIN, S>::WAVEB;
+  const size_t lds = 128 + (size_t)kWPB * (BCfg<CIN, S>::WAVEB + 2048);
   if (int rc = allow_lds(kern, lds)) return rc;
   int grid = 0;
   if (int rc = resident_blocks(kern, kWPB * 64, lds, &grid)) return rc;
@@ -785,7 +877,7 @@ int dd_conv_bf16_dgrad(const uint16_t* dy, const uint16_t* packed, const uint32_
   hipStream_t st = (hipStream_t)stream;
   if (d->stride == 1) return launch_strip<32, 1, 1>(dy, packed, nullptr, relu_bits, dx, nullptr, g, st);
   auto kern = bf_s2_dgrad<kWPB>;
-  const size_t lds = (size_t)kWPB * BCfg<32, 1>::WAVEB;
+  const size_t lds = (size_t)kWPB * (BCfg<32, 1>::WAVEB + 4096);
   int grid = 0;
   if (int rc = resident_blocks(kern, kWPB * 64, lds, &grid)) return rc;
   const long tiles = (long)g.B * g.nstrips * ((g.H + 1) / 2);

@@ -33,6 +33,9 @@ class RoadMapBCE(LightningModule):
         self.frozen = True
         self.ae.freeze()
         self.ae.decoder = None
+        self.ae.encoder.precision = str(hparam(hparams, "precision", self.ae.encoder.precision))
+        if self.ae.encoder.precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.ae.encoder.precision!r}")
         self.fc1 = nn.Linear(self.ae.latent_dim, self.output_dim)
 
     def wide_stitch_six_images(self, sample):
@@ -41,7 +44,11 @@ class RoadMapBCE(LightningModule):
         return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
 
     def _encode(self, sample, keeps=(None, None)):
-        if isinstance(sample, (tuple, list)):           # the collate's tuple: gather straight from the samples
+        if self.ae.encoder.precision == "bf16":         # hparams.precision = "bf16" (BASELINE config 5)
+            from . import ops_bf16
+            x = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+            wide4 = ops_bf16.stitch6_bf16(x.contiguous())
+        elif isinstance(sample, (tuple, list)):         # the collate's tuple: gather straight from the samples
             wide4 = ops.stitch6_samples([t.contiguous() for t in sample])
         else:
             wide4 = ops.stitch6(sample.contiguous())[0]  # gather + NHWC in one pass, no NCHW intermediate

@@ -44,3 +44,11 @@ def conv_stack_pooled(x, c1, c2, c3):
     a2 = _ConvReluBf16.apply(a1, c2.weight.double(), c2.bias, 1)
     a3 = _ConvReluBf16.apply(a2, c3.weight.double(), c3.bias, 2)
     return F.max_pool1d(a3.reshape(a3.size(0), 1, -1), 4).squeeze(1), (a1, a2, a3)
+
+
+def encoder_latent(enc, wide, masks=(None, None)):
+    """``oracle.ae_parts.EncoderNet`` with its conv stack evaluated in the mixed-precision contract above and the FC
+    tail in the container dtype of ``enc`` (double it for an fp64 tail)."""
+    pooled, _ = conv_stack_pooled(wide, enc.c1, enc.c2, enc.c3)
+    pooled = pooled.to(enc.fc_z_out.weight.dtype)
+    return enc.fc_z_out(enc.fc2(enc.fc1(pooled, masks[0]), masks[1]))

@@ -150,3 +150,50 @@ def test_conv_stack_against_oracle(dev):
     for name, g, r in zip(["c1.w", "c1.b", "c2.w", "c2.b", "c3.w", "c3.b"], got, ref_grads):
         err = float((g.cpu().double() - r.double()).abs().max() / r.double().abs().max())
         assert err < 4e-3, (name, err)
+
+
+def test_roadmap_step_in_bf16_against_oracle(dev):
+    """RoadMapBCE(precision='bf16').training_step vs the oracle: conv stack in the mixed-precision contract, FC tail,
+    head and loss in fp64.  Also: the bf16 step stays within bf16's resolution of the fp32 step."""
+    from argparse import Namespace
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.roadmap import RoadMapBCE
+    from oracle import ae_parts, bf16_parts, steps
+    hp = dict(hidden_dim=16, latent_dim=8, input_height=16, input_width=132, output_height=16, output_width=22)
+    ae = BasicAE(Namespace(**hp))
+    model = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9))
+    synth.fill_module(model, seed=23)
+    for blk in (model.ae.encoder.fc1, model.ae.encoder.fc2):
+        blk.drop_p = 0.0
+    enc = ae_parts.EncoderNet(16, 8, 3, 16, 132).double()
+    enc.load_state_dict(model.ae.encoder.state_dict())
+    enc.fc1.drop_p = enc.fc2.drop_p = 0.0
+    head = torch.nn.Linear(8, 640000).double()
+    head.load_state_dict(model.fc1.state_dict())
+    model = model.to(dev)
+    views = synth.camera_batch(3, 16, 22, seed=23)
+    road = synth.road_maps(3, seed=23)
+    out = model.training_step((tuple(views.to(dev)), None, tuple(road.to(dev))), 0)
+    out["loss"].backward()
+
+    z = bf16_parts.encoder_latent(enc, bf16r(steps.wide_stitch(views)))
+    logits = head(z)
+    ref = F.binary_cross_entropy_with_logits(logits.reshape(3, -1), road.double().reshape(3, -1))
+    ref.backward()
+    assert abs(float(out["loss"].detach()) - float(ref.detach())) / float(ref.detach()) < 1e-4
+    refs = dict(list(("ae.encoder." + k, p) for k, p in enc.named_parameters()) + [("fc1." + k, p) for k, p in head.named_parameters()])
+    for k, p in model.named_parameters():
+        r = refs[k].grad.double()
+        floor = 1e-30
+        if k.endswith("fc1.bias") and "encoder" in k:       # zero by construction in front of BatchNorm
+            floor = float(refs[k[:-4] + "weight"].grad.abs().max())
+        err = float((p.grad.cpu().double() - r).abs().max() / max(float(r.abs().max()), floor))
+        # one-ulp rounding flips (4e-3 relative each) in three stacked bf16 layers, amplified by BatchNorm over a batch
+        # of 3: the conv gradients agree to ~5e-3 of peak whichever way the fp32 sums are ordered
+        assert err < 1e-2, (k, err)
+
+    # the same model in fp32: bf16 changes the loss by no more than bf16 resolution
+    model.zero_grad()
+    model.ae.encoder.precision = "fp32"
+    l32 = model.training_step((tuple(views.to(dev)), None, tuple(road.to(dev))), 0)["loss"]
+    assert abs(float(l32.detach()) - float(out["loss"].detach())) / float(l32.detach()) < 1e-2

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Config 5 (bf16, 6x3x512x612, bs 16 per GPU) diagnostics: per-kernel time and achieved HBM GB/s of the bf16 conv
+stack (these kernels are HBM-bound: bytes = the tensors each one must read and write once), and the RoadMapBCE step
+in fp32 vs bf16.   python tools/bench_bf16.py [--batch 16 --h 512 --w 612 --iters 5 --only fwd,step]"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from driving_dirty_amd import ops, ops_bf16 as ob  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--h", type=int, default=512)
+    ap.add_argument("--w", type=int, default=612)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    b, h, w = a.batch, a.h, 6 * a.w
+    ho, wo = ops.conv_out(h, 2), ops.conv_out(w, 2)
+    px, pxo = b * h * w, b * ho * wo
+    want = lambda n: not a.only or any(s in n for s in a.only.split(","))
+    res = {}
+
+    def rec(name, ms, nbytes, flops):
+        res[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "frac_hbm_8TBs": round(nbytes / ms / 1e6 / 8000, 3),
+                     "TF": round(flops / ms / 1e9, 1)}
+        print(name, res[name], flush=True)
+
+    if want("kern"):
+        d1, d2, d3 = ops.conv_desc(b, h, w, 3, 1), ops.conv_desc(b, h, w, 32, 1), ops.conv_desc(b, h, w, 32, 2)
+        w1 = torch.randn(32, 3, 3, 3, device=dev) * 0.2
+        w2 = torch.randn(32, 32, 3, 3, device=dev) * 0.06
+        bias = torch.zeros(32, device=dev)
+        x4 = torch.rand(b, h, w, 4, device=dev).to(torch.bfloat16)
+        x4[..., 3] = 0
+        p1, p2, p3 = ob.conv_pack(w1, d1, 0), ob.conv_pack(w2, d2, 0), ob.conv_pack(w2, d3, 0)
+        a1, s1 = ob.conv_fwd(x4, p1, bias, d1)
+        a2, s2 = ob.conv_fwd(a1, p2, bias, d2)
+        a3, _ = ob.conv_fwd(a2, p3, bias, d3, want_bits=False)
+        g3 = (torch.randn(b, ho, wo, 32, device=dev) * 0.1).to(torch.bfloat16)
+        g2 = (torch.randn(b, h, w, 32, device=dev) * 0.1).to(torch.bfloat16)
+        pd2, pd3 = ob.conv_pack(w2, d2, 1), ob.conv_pack(w2, d3, 2)
+        rec("c1_fwd", timeit(lambda: ob.conv_fwd(x4, p1, bias, d1), a.iters), px * (8 + 64 + 4), px * 2 * 27 * 32)
+        rec("c2_fwd", timeit(lambda: ob.conv_fwd(a1, p2, bias, d2), a.iters), px * (64 + 64 + 4), px * 2 * 288 * 32)
+        rec("c3_fwd", timeit(lambda: ob.conv_fwd(a2, p3, bias, d3, want_bits=False), a.iters), px * 64 + pxo * 64, pxo * 2 * 288 * 32)
+        rec("c3_dgrad", timeit(lambda: ob.conv_dgrad(g3, pd3, s2, d3), a.iters), pxo * 64 + px * (64 + 4), pxo * 2 * 288 * 32)
+        rec("c2_dgrad", timeit(lambda: ob.conv_dgrad(g2, pd2, s1, d2), a.iters), px * (64 + 64 + 4), px * 2 * 288 * 32)
+        rec("c3_wgrad", timeit(lambda: ob.conv_wgrad(a2, g3, d3), a.iters), px * 64 + pxo * 64, pxo * 2 * 288 * 32)
+        rec("c2_wgrad", timeit(lambda: ob.conv_wgrad(a1, g2, d2), a.iters), px * 128, px * 2 * 288 * 32)
+        rec("c1_wgrad", timeit(lambda: ob.conv_wgrad(x4, g2, d1), a.iters), px * 72, px * 2 * 27 * 32)
+        pooled = ob.pool4_fwd(a3)
+        rec("pool_fwd", timeit(lambda: ob.pool4_fwd(a3), a.iters), pxo * (64 + 32), 0)
+        rec("pool_bwd", timeit(lambda: ob.pool4_relu_bwd(pooled, a3), a.iters), pxo * (64 + 32 + 64), 0)
+        views = torch.rand(b, 6, 3, a.h, a.w, device=dev)
+        rec("stitch_bf16", timeit(lambda: ob.stitch6_bf16(views), a.iters), px * (12 + 8), 0)
+        del a1, a2, a3, g2, g3, x4, pooled, views
+        torch.cuda.empty_cache()
+
+    if want("step"):
+        from driving_dirty_amd.autoencoder import BasicAE
+        from driving_dirty_amd.optim import HipAdam
+        from driving_dirty_amd.roadmap import RoadMapBCE
+        for prec in ("bf16", "fp32"):
+            torch.manual_seed(20200505)
+            ae = BasicAE(Namespace(hidden_dim=128, latent_dim=64, input_height=a.h, input_width=6 * a.w, output_height=a.h, output_width=a.w))
+            m = RoadMapBCE(Namespace(pretrained_ae=ae, precision=prec, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
+            g = torch.Generator(device="cpu").manual_seed(1)
+            batch = (tuple(torch.rand(b, 6, 3, a.h, a.w, generator=g).to(dev)), None, tuple((torch.rand(b, 800, 800, generator=g) < 0.3).to(dev)))
+            m.training_step(batch, 0)["loss"].backward()
+            m.zero_grad(set_to_none=True)
+            opt = HipAdam(m.parameters(), lr=1e-3)
+            opt.overlap_with_backward(grad_scale=1.0, grad_sync=None)
+
+            def step():
+                m.zero_grad(set_to_none=True)
+                out = m.training_step(batch, 1)
+                out["loss"].backward()
+                opt.step()
+                return out["loss"]
+            for _ in range(2):
+                loss = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.iters):
+                loss = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.iters
+            res["step_" + prec] = {"ms_per_step": round(dt * 1e3, 3), "scenes_per_s": round(b / dt, 1), "batch": b, "loss": round(float(loss), 6)}
+            print("step_" + prec, res["step_" + prec], flush=True)
+            del m, ae, opt, batch
+            torch.cuda.empty_cache()
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
