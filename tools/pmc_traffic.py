@@ -11,11 +11,11 @@ import glob
 import json
 import sys
 
-KERNEL = "conv_strip_fwd<32, 1, 5, 8>"      # c2 forward (CIN=32, S=1, EPI=BIAS_RELU+sign bits, 8 waves)
+KERNEL = "conv_strip_fwd<32, 1, 5, 8"       # c2 forward (CIN=32, S=1, EPI=BIAS_RELU+sign bits, 8 waves)
 
 
 def per_launch(directory, counter):
-    f = glob.glob(directory + "/*/*counter_collection.csv")[0]
+    f = glob.glob(directory + "/**/*counter_collection.csv", recursive=True)[0]
     per = {}
     for r in csv.DictReader(open(f)):
         if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
@@ -28,7 +28,7 @@ def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fetch, n1 = per_launch(fetch_dir, "FETCH_SIZE")
     write, n2 = per_launch(write_dir, "WRITE_SIZE")
-    algorithmic = 32 * 256 * 1836 * 32 * 4 * 2          # read a1 once + write a2 once, bs = 32
+    algorithmic = 32 * 256 * 1836 * (32 * 4 * 2 + 4)    # read a1 once + write a2 once + one sign word per pixel, bs = 32
     res = {"kernel": KERNEL, "batch": 32, "fetch_bytes": 2.0 * fetch, "write_bytes": write,
            "hbm_bytes_per_launch": 2.0 * fetch + write, "algorithmic_bytes": algorithmic,
            "launches": [n1, n2], "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); WRITE_SIZE exact",
