@@ -98,3 +98,47 @@ def test_double_resolution_encoder_against_oracle(dev):
     # reference's own fp32 run is 5e-3..1e-2 off its fp64 run on them (tests/golden/full_roadmap.npz), so is any fp32 order
     for k in ("c1.weight", "c2.weight", "c3.weight", "c3.bias", "fc2.fc1.weight", "fc_z_out.weight"):
         assert rel(dict(enc.named_parameters())[k].grad, refp[k].grad) < 1e-2, k
+
+
+def test_config5_bf16_conv_stack_against_oracle(dev):
+    """BASELINE config 5 input size (6 x 3 x 512 x 612 -> 512 x 3672 wide image) through the bf16 conv stack, one
+    scene, against the mixed-precision oracle (oracle/bf16_parts.py: fp64 between the bf16 rounding points): the pooled
+    feature and all six parameter gradients.  Also the size-independent adjointness of the bf16 kernels at bs = 16:
+    <dgrad(g), x> = <wgrad(x, g), W> (both sides are sums of exact bf16 products, accumulated in fp32)."""
+    from driving_dirty_amd import ops, ops_bf16 as ob, synth
+    from oracle import bf16_parts, steps
+    h, w = 512, 6 * 612
+    c1, c2, c3 = torch.nn.Conv2d(3, 32, 3, padding=1), torch.nn.Conv2d(32, 32, 3, padding=1), torch.nn.Conv2d(32, 32, 3, stride=2, padding=1)
+    for i, m in enumerate((c1, c2, c3)):
+        synth.fill_module(m, seed=70 + i)
+    views = synth.camera_batch(1, 512, 612, seed=70)
+    wide = steps.wide_stitch(views)
+    pooled_ref, _ = bf16_parts.conv_stack_pooled(bf16_parts.bf16r(wide), c1, c2, c3)
+    gp = synth.hash_uniform(tuple(pooled_ref.shape), synth.key_salt("gp5"))
+    pooled_ref.backward(gp.double())
+    ref = [p.grad.clone() for m in (c1, c2, c3) for p in (m.weight, m.bias)]
+    for m in (c1, c2, c3):
+        m.zero_grad()
+        m.to(dev)
+    pooled = ob.encoder_conv_stack(ob.stitch6_bf16(views.to(dev)), c1, c2, c3)
+    pooled.backward(gp.to(dev))
+    err = float((pooled.detach().cpu().double() - pooled_ref.detach()).abs().max() / pooled_ref.detach().abs().max())
+    assert err < 8e-3, err                                   # at most a couple of bf16 ulps (2^-8) on the largest values
+    frac_exact = float((pooled.detach().cpu().double() == pooled_ref.detach()).double().mean())
+    assert frac_exact > 0.97, frac_exact                     # and bit-identical almost everywhere
+    for name, g, r in zip(["c1.w", "c1.b", "c2.w", "c2.b", "c3.w", "c3.b"], [p.grad for m in (c1, c2, c3) for p in (m.weight, m.bias)], ref):
+        e = float((g.cpu().double() - r.double()).abs().max() / r.double().abs().max())
+        assert e < 5e-3, (name, e)
+
+    b = 16
+    d2 = ops.conv_desc(b, h, w, 32, 1)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(b, h, w, 32, device=dev, generator=gen).to(torch.bfloat16)
+    g = torch.randn(b, h, w, 32, device=dev, generator=gen).to(torch.bfloat16)
+    wt = torch.randn(32, 32, 3, 3, device=dev, generator=gen) * 0.06
+    wr = wt.to(torch.bfloat16).float()
+    ones = torch.full((b, h, w), -1, device=dev, dtype=torch.int32)          # all ReLU signs set: no masking
+    dx = ob.conv_dgrad(g, ob.conv_pack(wt, d2, ops.PACK_DGRAD_S1), ones, d2)
+    dw, _ = ob.conv_wgrad(x, g, d2)
+    lhs, rhs = dot(dx.float(), x.float()), dot(dw, wr)
+    assert abs(lhs - rhs) / abs(rhs) < 2e-3, (lhs, rhs)      # dx is rounded to bf16 once per element (2^-9 relative, random sign)
