@@ -250,3 +250,37 @@ def test_encoder_v2_conv_bn_relu_against_oracle(dev, hw):
     enc.c3_only = ref.c3_only = False
     enc.eval(); ref.eval()
     assert rel_err(enc(x.to(dev)), ref(x.double())) < CHAIN_TOL
+
+
+def test_dropout_statistics_and_masked_view_draws(dev):
+    """Glue the golden plan names: DenseBlock's dropout is always on (components.py:108), keeps with probability 0.8
+    and rescales by 1.25; six_to_one_task draws its slot from numpy's GLOBAL state with the exclusive bound 5
+    (autoencoder.py:59-60), reproduced here for the first ten draws under the reference's seed."""
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.components import DenseBlock
+    blk = DenseBlock(8, 4096).to(dev).eval()                 # eval mode: BN uses running stats, dropout still drops
+    with torch.no_grad():
+        blk.fc1.weight.zero_()
+        blk.fc1.bias.fill_(1.0)                              # every pre-dropout activation is exactly relu(bn(1)) = c > 0
+    x = torch.zeros(64, 8, device=dev)
+    y = blk(x)
+    c = float(y.detach().max()) / 1.25
+    assert c > 0
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01                            # 262144 draws: sigma = 0.0008
+    assert torch.allclose(y[y > 0], torch.full_like(y[y > 0], 1.25 * c))
+    assert not torch.equal(blk(x), y)                        # a fresh mask every call
+    blk.drop_p = 0.0
+    assert torch.equal(blk(x), blk(x))
+
+    ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132, output_height=16, output_width=22)).to(dev)
+    views = synth.camera_batch(2, 16, 22, seed=3).to(dev)
+    np.random.seed(20200505)                                 # autoencoder.py:16-18
+    want = np.random.RandomState(20200505).randint(0, 5, size=10)
+    for t in want:
+        wide, target = ae.six_to_one_task(views)
+        assert 0 <= t < 5
+        assert float(wide[..., t * 22:(t + 1) * 22].abs().sum()) == 0.0
+        assert float(wide.abs().sum()) > 0
+        order = (0, 1, 2, 5, 4, 3)
+        assert torch.equal(target, views[:, order[t]])
