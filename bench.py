@@ -63,19 +63,21 @@ class KernelTimer:
 
     def install(self):
         from driving_dirty_amd import ops
-        inner = ops.conv_fwd_bits            # the encoder stack runs c1 / c2 through the *_relu_bits forward
-
-        def timed(x, packed, bias, desc):
-            hot = self.enabled and desc.cin_real == 32 and desc.stride == 1
-            if not hot:
-                return inner(x, packed, bias, desc)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = inner(x, packed, bias, desc)
-            e.record()
-            self.pairs.append((s, e))
-            return out
-        ops.conv_fwd_bits = timed
+        # the encoder stack runs c2 forward through conv_wino_fwd_bits (Winograd, default) or conv_fwd_bits (direct)
+        def wrap(inner):
+            def timed(x, packed, bias, desc):
+                hot = self.enabled and desc.cin_real == 32 and desc.stride == 1
+                if not hot:
+                    return inner(x, packed, bias, desc)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = inner(x, packed, bias, desc)
+                e.record()
+                self.pairs.append((s, e))
+                return out
+            return timed
+        ops.conv_fwd_bits = wrap(ops.conv_fwd_bits)
+        ops.conv_wino_fwd_bits = wrap(ops.conv_wino_fwd_bits)
 
     def mean_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
@@ -148,6 +150,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
     ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
+    ap.add_argument("--direct-conv", action="store_true", help="c2 forward / data gradient on the direct kernels instead of Winograd F(2,3)")
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
     a = ap.parse_args()
 
@@ -184,6 +187,9 @@ def main():
     if a.cu_budget:
         _lib.check(_lib.lib().dd_set_cu_budget(a.cu_budget), "dd_set_cu_budget")
 
+    if a.direct_conv:
+        from driving_dirty_amd import ops as _o
+        _o.WINOGRAD = False
     model = build_model(dev)
     model.ae.encoder.rows_per_task = a.rows_per_task
     model.training_step(synthetic_batch(dev, 2, rank), 0)["loss"].backward()   # unfreezes the AE (epoch 0 >= 0)
@@ -231,7 +237,9 @@ def main():
         value = world * BATCH * a.steps / dt
         k_ms = timer.mean_ms()
         assert timer.pairs, "the dominant kernel was never launched through the timed entry point"
-        achieved = C2_FLOP_PER_SCENE * BATCH / (k_ms * 1e-3) / 1e12
+        achieved = C2_FLOP_PER_SCENE * BATCH / (k_ms * 1e-3) / 1e12      # ALGORITHMIC flops (direct-convolution count)
+        from driving_dirty_amd import ops as _ops
+        wino = bool(_ops.WINOGRAD)
         line = {
             "metric": "6-view scenes/sec fwd+bwd, roadmap model bs=32",
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -242,10 +250,12 @@ def main():
                        "global_batch": world * BATCH, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
             "step_frac_of_fp32_mfma_peak": round(STEP_FLOP_PER_SCENE * BATCH * world / (ms * 1e-3) / 1e12
                                                  / (PEAK_F32_MFMA_TF * world), 4),
-            "roofline": {"kernel": "conv_strip_fwd<CIN=32,S=1> (c2 forward, 74% of encoder FLOPs fwd)",
+            "roofline": {"kernel": ("conv_wino_fwd (c2 forward, Winograd F(2,3) along x: issues 2/3 of the algorithmic flops)"
+                                    if wino else "conv_strip_fwd<CIN=32,S=1> (c2 forward, direct)") + ", 74% of encoder FLOPs fwd",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": measured_traffic(),
-                         "launch_ms": round(k_ms, 4), "launches_timed": len(timer.pairs)},
+                         "launch_ms": round(k_ms, 4), "launches_timed": len(timer.pairs),
+                         "issued_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TF, 4)},
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

@@ -89,6 +89,10 @@ SIGNATURES = {
     "dd_linear_wgrad": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_threat_score_workspace_bytes": (_i64, []),
     "dd_threat_score": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
+    "dd_conv_wino_packed_floats": (_i64, [_p]),
+    "dd_conv_wino_pack": (_i32, [_p, _p, _p, _i32, _p]),
+    "dd_conv_wino_fwd_relu_bits": (_i32, [_p, _p, _p, _p, _p, _p, _p]),
+    "dd_conv_wino_dgrad_relu_bits": (_i32, [_p, _p, _p, _p, _p, _p]),
     "dd_stitch6_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_conv_bf16_packed_elems": (_i64, [_p]),
     "dd_conv_bf16_pack": (_i32, [_p, _p, _i32, _p, _p]),

@@ -601,6 +601,180 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2,3) along x for the 32 -> 32 stride-1 layer (c2 forward and its data gradient): two adjacent output
+// pixels share four transformed inputs, so a 3-tap row costs 4 multiplies instead of 6 -- 192 instead of 288
+// matrix-core cycles per pixel pair, in exact fp32 arithmetic (the transforms are adds and one halving):
+//   inputs   d0..d3 (pixels 2t-1 .. 2t+2)      v = (d0-d2, d1+d2, d2-d1, d1-d3)
+//   weights  g0..g2 (kx = 0..2, per ky)        u = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
+//   outputs  y(2t) = m0+m1+m2,  y(2t+1) = m1-m2-m3     with m_p = sum over ky, ci of v_p * u_p
+// A wave still owns 32 output pixels = 16 pairs; the GEMM tile is 16 (pairs) x 16 (channels) x 4 (input channels) on
+// v_mfma_f32_16x16x4_f32 (same flop rate as the 32x32x2 form), 4 positions x 2 channel halves = 8 accumulators of
+// 4 registers, issued round-robin (the 16x16 form has a 40-cycle dependent latency on a 32-cycle issue).  Lane
+// (pair t = lane&15, q = lane>>4) transforms input channels 8q..8q+7 of its own pair in registers, so the A operand
+// never goes back to LDS; U (48 KB) sits in LDS next to the eight 3-slot rings (13.5 KB each): 159.7 of 160 KB.
+// Rest of the machinery (ring, prefetch, ranges, buffer addressing) is conv_strip_fwd's.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define DD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+constexpr int WINO_UFLOATS = 3 * 4 * 2 * 2 * 64 * 4;      // [ky][pos][half][chunk][lane][4]
+
+template <int EPI, int WPB>   // EPI_BIAS_RELU_BITS (forward) or EPI_RELU_BITS (data gradient)
+__global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restrict__ x, const float* __restrict__ up,
+                                                          const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
+                                                          float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
+                                                          int W, int nstrips) {
+  using C = StripCfg<32, 1>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    f32x4* ul4 = (f32x4*)smem;
+    const f32x4* ug4 = (const f32x4*)up;
+    for (int i = tid; i < WINO_UFLOATS / 4; i += WPB * 64) ul4[i] = ug4[i];
+  }
+  __syncthreads();
+  char* ring = smem + WINO_UFLOATS * 4 + wave * C::WAVEB;
+  char* spill = ring + 3 * C::SLOTB;
+  const f32x4* ul = (const f32x4*)smem;
+  const int t16 = lane & 15, q4 = lane >> 4;
+  const float bv0 = (EPI == EPI_BIAS_RELU_BITS) ? bias[t16] : 0.f, bv1 = (EPI == EPI_BIAS_RELU_BITS) ? bias[16 + t16] : 0.f;
+
+  long idx, end;
+  wave_range((long)B * nstrips * H, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / H;
+    const int y0 = (int)(idx - col * H);
+    const int y1 = (int)min((long)H, y0 + (end - idx));
+    idx += y1 - y0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const float* xb = x + (long)b * H * W * 32;
+    const int gx0 = x0 - 1;
+
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      f32x4 t[C::NLOAD];
+      const int iy = y0 - 1 + d;
+      load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
+      store_row<32, 1, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
+    }
+
+    for (int yy = y0; yy < y1; ++yy) {
+      f32x4 pre[C::NLOAD];
+      load_row<32, 1>(xb, H, W, yy + 2, gx0, lane, pre);
+      const long opix = (long)(b * H + yy) * W;
+      unsigned mw[8];
+      if (EPI == EPI_RELU_BITS) {   // sign words of this lane's 8 output pixels: pairs 4q..4q+3 = pixels x0 + 8q .. +7
+        const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + opix, W * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)   // one dword each: every word is range-checked by itself at a ragged row end
+          mw[i] = __builtin_amdgcn_raw_buffer_load_b32(ms, (x0 + 8 * q4 + i) * 4, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      f32x4v acc[4][2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) acc[p][hf] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const char* rowb = ring + ((yy + ky) % 3) * C::SLOTB;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {          // input channels 8q + 4g .. + 3
+          f32x4 d[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int px = 2 * t16 + c;
+            d[c] = *(const f32x4*)(rowb + px * 128 + (((2 * q4 + g) ^ swz<32>(px)) << 4));
+          }
+          f32x4 v[4];
+          v[0] = d[0] - d[2];
+          v[1] = d[1] + d[2];
+          v[2] = d[2] - d[1];
+          v[3] = d[1] - d[3];
+          f32x4 u[4][2];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) u[p][hf] = ul[((((ky * 4 + p) * 2 + hf) * 2 + g) * 64) + lane];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) acc[p][hf] = DD_MFMA16(v[p][j], u[p][hf][j], acc[p][hf]);
+        }
+      }
+
+      store_row<32, 1, true>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, pre);
+
+      // output transform + epilogue: lane = channel t16 (+16 per half), register r = pair 4q + r
+      const __amdgpu_buffer_rsrc_t ys = rsrc(y + opix * 32, W * 128);
+      unsigned keep[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) keep[i] = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {          // the pair's even / odd pixel
+          const int opx = x0 + 2 * (4 * q4 + r) + e;
+          float o[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float m0 = acc[0][hf][r], m1 = acc[1][hf][r], m2 = acc[2][hf][r], m3 = acc[3][hf][r];
+            float v = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+            if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v + (hf ? bv1 : bv0), 0.f);
+            if (EPI == EPI_RELU_BITS) {
+              v = ((mw[2 * r + e] >> (t16 + 16 * hf)) & 1u) ? v : 0.f;
+            }
+            o[hf] = v;
+            bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
+          }
+          if (EPI == EPI_BIAS_RELU_BITS) {
+            // ballot bit L = (o > 0) of lane L = (channel L&15, pair group L>>4): 16 channel bits of 4 different pixels
+            const unsigned long long b0 = __ballot(o[0] > 0.f), b1 = __ballot(o[1] > 0.f);
+            // lane P (< 32) keeps the word of strip pixel P = 2*(4G + r) + e
+            const int G = (lane & 31) >> 3;
+            const unsigned w = (unsigned)((b0 >> (16 * G)) & 0xffffull) | ((unsigned)((b1 >> (16 * G)) & 0xffffull) << 16);
+            keep[2 * r + e] = w;
+          }
+        }
+      }
+      if (EPI == EPI_BIAS_RELU_BITS) {
+        const int P = lane & 31, sel = P & 7;          // P = 8G + 2r + e  ->  keep index 2r + e = P & 7
+        unsigned word = keep[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) word = (sel == i) ? keep[i] : word;
+        const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + opix, W * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(word, bs, (lane < 32) ? (x0 + P) * 4 : -16, 0, 0);
+      }
+    }
+  }
+}
+
+// U image for conv_wino_fwd: packed[((((ky*4 + p)*2 + half)*2 + g)*64 + lane)*4 + j] = u_p of the taps
+// Weff[co = (lane&15) + 16*half][ci = 8*(lane>>4) + 4g + j][ky][0..2];  kind 0: Weff = W (forward);
+// kind 1: Weff[co][ci][ky][kx] = W[ci][co][2-ky][2-kx] (stride-1 data gradient).
+__global__ void conv_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int kind) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= WINO_UFLOATS) return;
+  const int j = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 1, hf = (idx >> 9) & 1, pos = (idx >> 10) & 3, ky = idx >> 12;
+  const int co = (lane & 15) + 16 * hf, ci = 8 * (lane >> 4) + 4 * g + j;
+  float t[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+    t[kx] = kind == 0 ? w[((long)co * 32 + ci) * 9 + ky * 3 + kx] : w[((long)ci * 32 + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+  float u;
+  if (pos == 0) u = t[0];
+  else if (pos == 1) u = 0.5f * ((t[0] + t[1]) + t[2]);
+  else if (pos == 2) u = 0.5f * ((t[0] - t[1]) + t[2]);
+  else u = t[2];
+  p[idx] = u;
+}
+
 __global__ void relu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ y, f32x4* __restrict__ out,
                                 long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -661,6 +835,21 @@ int launch_fwd(const float* x, const float* wp, const float* bias, const float* 
   hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, wp, bias, msk, y, bits_out, d->batch, d->height, d->width,
                      Ho, Wo, nstrips, aff, stats);
   DD_LAUNCH_CHECK("conv_strip_fwd");
+  return 0;
+}
+
+template <int EPI>
+int launch_wino(const float* x, const float* up, const float* bias, const unsigned* bits_in, float* y, unsigned* bits_out,
+                const dd_conv_desc* d, hipStream_t st) {
+  using C = StripCfg<32, 1>;
+  constexpr int WPB = 8;
+  const int nstrips = (d->width + 31) / 32;
+  const size_t lds = (size_t)WINO_UFLOATS * 4 + (size_t)WPB * C::WAVEB;
+  const int grid = resident_grid(d, (long)d->batch * nstrips * d->height, WPB, 1);
+  auto k = conv_wino_fwd<EPI, WPB>;
+  if (int rc = allow_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
+  DD_LAUNCH_CHECK("conv_wino_fwd");
   return 0;
 }
 
@@ -870,6 +1059,39 @@ int dd_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* st
                      (f32x4*)out, n4);
   DD_LAUNCH_CHECK("relu_bwd");
   return 0;
+}
+
+// ---- Winograd F(2,3) path of the 32 -> 32 stride-1 layer ----
+int64_t dd_conv_wino_packed_floats(const dd_conv_desc* d) {
+  if (check_desc(d)) return -1;
+  if (d->cin_real != 32 || d->stride != 1) return -1;
+  return WINO_UFLOATS;
+}
+
+int dd_conv_wino_pack(const float* w_oihw, float* packed, const dd_conv_desc* d, int32_t kind, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(w_oihw && packed, DD_ERR_BAD_ARG, "conv_wino_pack: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  DD_REQUIRE(kind == 0 || kind == 1, DD_ERR_BAD_ARG, "conv_wino_pack: kind %d (0 forward, 1 data gradient)", kind);
+  hipLaunchKernelGGL(conv_wino_pack_kernel, dim3((WINO_UFLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, kind);
+  DD_LAUNCH_CHECK("conv_wino_pack");
+  return 0;
+}
+
+int dd_conv_wino_fwd_relu_bits(const float* x, const float* packed, const float* bias, float* y, uint32_t* relu_bits,
+                               const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && packed && bias && y && relu_bits, DD_ERR_BAD_ARG, "conv_wino_fwd_relu_bits: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  return launch_wino<EPI_BIAS_RELU_BITS>(x, packed, bias, nullptr, y, relu_bits, d, (hipStream_t)stream);
+}
+
+int dd_conv_wino_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
+                                 const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(dy && packed && relu_bits && dx, DD_ERR_BAD_ARG, "conv_wino_dgrad_relu_bits: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  return launch_wino<EPI_RELU_BITS>(dy, packed, nullptr, relu_bits, dx, nullptr, d, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -309,6 +309,17 @@ int dd_threat_score(const float* a, const float* b, float* out, int64_t n, int32
 int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, void* stream);
 
+/* ---- Winograd F(2,3) along x for the 32 -> 32 stride-1 layer (c2, components.py:20): the same outputs as
+ * dd_conv_fwd_relu_bits / dd_conv_dgrad_relu_bits from 2/3 of the multiplies (4 per output-pixel pair and tap row
+ * instead of 6), still exact fp32 arithmetic (the transforms are fp32 adds and one halving; results differ from the
+ * direct form by summation order only, ~1e-6 relative).  kind 0 = forward, 1 = stride-1 data gradient. */
+int64_t dd_conv_wino_packed_floats(const dd_conv_desc* d);
+int dd_conv_wino_pack(const float* w_oihw, float* packed, const dd_conv_desc* d, int32_t kind, void* stream);
+int dd_conv_wino_fwd_relu_bits(const float* x, const float* packed, const float* bias, float* y, uint32_t* relu_bits,
+                               const dd_conv_desc* d, void* stream);
+int dd_conv_wino_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
+                                 const dd_conv_desc* d, void* stream);
+
 /* ---- bf16 mixed precision (BASELINE config 5: 6x3x512x612 inputs, bf16) ---------------------------------
  * The encoder conv stack (components.py:19-21,41-43) with bf16 operands on the bf16 matrix cores and fp32
  * accumulation: activations and activation gradients are NHWC bf16 (raw uint16 bit patterns in this ABI), rounded

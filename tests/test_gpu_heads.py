@@ -88,9 +88,21 @@ def test_autoencoder_step_against_oracle(dev):
     assert abs(float(out["loss"].detach()) - float(ref_loss.detach())) / float(ref_loss.detach()) < 1e-4
     ref = dict(("encoder." + k, p) for k, p in enc.named_parameters())
     ref.update(("decoder." + k, p) for k, p in dec.named_parameters())
+    # Train-mode BatchNorm1d over a batch of 3 makes these gradients ill-conditioned: the oracle's OWN fp32 run is
+    # several % away from its fp64 run on the encoder side.  Budget per tensor: 1e-3 of peak, or three times the deviation
+    # the reference arithmetic shows between fp32 and fp64, whichever is larger (3x as in the full-size golden test).
+    enc32, dec32 = ae_parts.EncoderNet(16, 8, 3, 16, 132), ae_parts.DecoderNet(16, 8, 3, 16, 22)
+    enc32.load_state_dict({k: v.float() for k, v in enc.state_dict().items()})
+    dec32.load_state_dict({k: v.float() for k, v in dec.state_dict().items()})
+    for m in (enc32.fc1, enc32.fc2, dec32.fc1, dec32.fc2):
+        m.drop_p = 0.0
+    steps.ae_loss(enc32, dec32, views, np.random.RandomState(20200505))[0].backward()
+    ref32 = dict(("encoder." + k, p) for k, p in enc32.named_parameters())
+    ref32.update(("decoder." + k, p) for k, p in dec32.named_parameters())
     for k, p in ae.named_parameters():
         scale = max(float(ref[k].grad.abs().max()), 1e-2 * float(ref[k[:-4] + "weight"].grad.abs().max()) if k.endswith("bias") else 0.0)
-        assert rel_err(p.grad, ref[k].grad, floor=scale) < CHAIN_TOL, k
+        budget = max(CHAIN_TOL, 3.0 * rel_err(ref32[k].grad, ref[k].grad, floor=scale))
+        assert rel_err(p.grad, ref[k].grad, floor=scale) < budget, (k, budget)
     # the reference's API: six_to_one_task returns the NCHW wide image and the blanked view
     np.random.seed(20200505)
     x, y = ae.six_to_one_task(views.to(dev))

@@ -97,6 +97,34 @@ def test_conv_fwd_dgrad_wgrad(dev, b, h, w, cin, stride, rows):
     assert torch.equal(sb.long() & 0xFFFFFFFF, want)
 
 
+@pytest.mark.parametrize("b,h,w", CONV_SHAPES + [(1, 1, 1), (1, 3, 64), (2, 4, 33)])
+@pytest.mark.parametrize("rows", [0, 3])
+def test_conv_winograd_fwd_dgrad(dev, b, h, w, rows):
+    """The Winograd F(2,3) kernels of the 32 -> 32 stride-1 layer: forward (bias + ReLU + sign bits) and data gradient
+    (sign-bit mask) against the fp64 oracle, and against the direct kernels' sign bits."""
+    from driving_dirty_amd import _lib, ops
+    x = hu((b, 32, h, w), f"wx{b}{h}{w}", 0.0, 1.0).double().requires_grad_(True)
+    wt = hu((32, 32, 3, 3), "ww", -0.3, 0.3).double()
+    bias = hu((32,), "wb", -0.2, 0.2).double()
+    y_ref = F.relu(F.conv2d(x, wt, bias, padding=1))
+    gy = hu(tuple(y_ref.shape), f"wgy{b}{h}{w}").double() * (y_ref > 0)
+    y_ref.backward(gy)
+    desc = ops.conv_desc(b, h, w, 32, 1, rows)
+    x_nhwc = ops.nchw_to_nhwc(x.detach().float().to(dev), 32)
+    wd, bd = wt.float().to(dev), bias.float().to(dev)
+    y, bits = ops.conv_wino_fwd_bits(x_nhwc, ops.conv_wino_pack(wd, desc, 0), bd, desc)
+    assert rel_err(y.permute(0, 3, 1, 2), y_ref) < KERNEL_TOL
+    want = ((y > 0).long() << torch.arange(32, device=dev)).sum(-1)
+    assert torch.equal(bits.long() & 0xFFFFFFFF, want)
+    xm = x.detach().float() - 0.5
+    mbits = ((xm > 0).long() << torch.arange(32).view(1, 32, 1, 1)).sum(1)
+    mbits = torch.where(mbits >= 2 ** 31, mbits - 2 ** 32, mbits).to(torch.int32).to(dev)
+    dx = ops.conv_wino_dgrad_bits(nhwc(gy.float()).to(dev), ops.conv_wino_pack(wd, desc, 1), mbits, desc)
+    assert rel_err(dx.permute(0, 3, 1, 2), x.grad * (xm > 0)) < KERNEL_TOL
+    with pytest.raises(_lib.HotpathError):
+        ops.conv_wino_pack(wd, ops.conv_desc(b, h, w, 32, 2), 0)           # stride 2 has no Winograd path
+
+
 def test_conv_refuses_unsupported(dev):
     from driving_dirty_amd import _lib, ops
     d = _lib.ConvDesc(1, 8, 8, 32, 32, 32, 5, 1, 2, 0)
