@@ -679,34 +679,41 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restric
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) acc[p][hf] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
+      // 6 groups (tap row ky, channel quad g) of 12 reads (4 input pixels + 8 U vectors) + 32 MFMAs; the reads of the
+      // next group are issued before the MFMAs of the current one
+      f32x4 dbuf[2][4], ubuf[2][4][2];
+      auto rd = [&](int it, f32x4 (&d)[4], f32x4 (&u)[4][2]) {
+        const int ky = it >> 1, g = it & 1;
         const char* rowb = ring + ((yy + ky) % 3) * C::SLOTB;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {          // input channels 8q + 4g .. + 3
-          f32x4 d[4];
+        for (int c = 0; c < 4; ++c) {
+          const int px = 2 * t16 + c;
+          d[c] = *(const f32x4*)(rowb + px * 128 + (((2 * q4 + g) ^ swz<32>(px)) << 4));
+        }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int px = 2 * t16 + c;
-            d[c] = *(const f32x4*)(rowb + px * 128 + (((2 * q4 + g) ^ swz<32>(px)) << 4));
-          }
-          f32x4 v[4];
-          v[0] = d[0] - d[2];
-          v[1] = d[1] + d[2];
-          v[2] = d[2] - d[1];
-          v[3] = d[1] - d[3];
-          f32x4 u[4][2];
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) u[p][hf] = ul[((((ky * 4 + p) * 2 + hf) * 2 + g) * 64) + lane];
+      };
+      rd(0, dbuf[0], ubuf[0]);
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        if (it + 1 < 6) rd(it + 1, dbuf[(it + 1) & 1], ubuf[(it + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4(&d)[4] = dbuf[it & 1];
+        const f32x4(&u)[4][2] = ubuf[it & 1];
+        f32x4 v[4];
+        v[0] = d[0] - d[2];
+        v[1] = d[1] + d[2];
+        v[2] = d[2] - d[1];
+        v[3] = d[1] - d[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) u[p][hf] = ul[((((ky * 4 + p) * 2 + hf) * 2 + g) * 64) + lane];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-              for (int hf = 0; hf < 2; ++hf) acc[p][hf] = DD_MFMA16(v[p][j], u[p][hf][j], acc[p][hf]);
-        }
+            for (int hf = 0; hf < 2; ++hf) acc[p][hf] = DD_MFMA16(v[p][j], u[p][hf][j], acc[p][hf]);
+        __builtin_amdgcn_sched_barrier(0);
       }
 
       store_row<32, 1, true>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, pre);
@@ -753,6 +760,173 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restric
       }
     }
   }
+}
+
+// Weight gradient of the same layer by F(3,2) along x (the transpose of the algorithm above): per tile of two
+// adjacent output pixels the three taps' products  dW_k += g_j * x_{j+k}  (j = 0,1; k = 0..2) are
+//   dW_k = A^T[k][:] . ( (G g) * (B^T d) ),   G g = (g0, (g0+g1)/2, (g0-g1)/2, g1),   B^T d = (d0-d2, d1+d2, d2-d1, d3-d1)
+// and the sum over tiles commutes with A^T, so the kernel keeps 3 (ky) x 4 (position) accumulators S_p of 32 x 32
+// over K = tiles -- 96 instead of 144 MFMAs per 32 pixels -- and the reduce kernel applies
+//   dW_0 = S0+S1+S2,  dW_1 = S1-S2,  dW_2 = S1+S2+S3     once at the end.
+// GEMM view as in conv_wgrad: A = G g (lane = output channel, straight from HBM), B = B^T d (lane = input channel,
+// four ds_read_b32 per tile and tap row), k-step = the tile pair (2s, 2s+1) on the two half-waves.
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void conv_wino_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part, float* __restrict__ bpart, int B,
+                                                            int H, int W, int nstrips) {
+  using C = StripCfg<32, 1>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ring = smem + wave * C::WAVEB;
+  char* spill = ring + 3 * C::SLOTB;
+  const int h = lane >> 5, n = lane & 31;
+  const int gw = blockIdx.x * WPB + wave;
+
+  f32x16 acc[3][4];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ky][p][r] = 0.f;
+  float bsum = 0.f;
+
+  long idx, end;
+  wave_range((long)B * nstrips * H, gw, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / H;
+    const int y0 = (int)(idx - col * H);
+    const int y1 = (int)min((long)H, y0 + (end - idx));
+    idx += y1 - y0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const float* xb = x + (long)b * H * W * 32;
+    const float* dyb = dy + (long)b * H * W * 32;
+    const int gx0 = x0 - 1;
+    const int aoff = ((x0 + 2 * h) * 32 + n) * 4;   // tile 2s+h = pixels x0 + 4s + 2h, +1: + 512 bytes per s, + 128 for the odd pixel
+
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      f32x4 t[C::NLOAD];
+      const int iy = y0 - 1 + d;
+      load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
+      store_row<32, 1, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
+    }
+    float g0[8], g1[8];
+    {
+      const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)y0 * W * 32, W * 128);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        g0[s8] = bload1(as, aoff + s8 * 512);
+        g1[s8] = bload1(as, aoff + s8 * 512 + 128);
+      }
+    }
+
+    for (int yy = y0; yy < y1; ++yy) {
+      f32x4 pre[C::NLOAD];
+      load_row<32, 1>(xb, H, W, yy + 2, gx0, lane, pre);
+      float n0[8], n1[8];
+      {
+        const bool ok = yy + 1 < H;
+        const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? yy + 1 : 0) * W * 32, ok ? W * 128 : 0);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          n0[s8] = bload1(as, aoff + s8 * 512);
+          n1[s8] = bload1(as, aoff + s8 * 512 + 128);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      const char* rb[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) rb[ky] = ring + ((yy + ky) % 3) * C::SLOTB + n * 4;
+      // 24 groups (tile pair s8, tap row ky) of 4 reads + 4 MFMAs; the reads run one group ahead of the MFMAs (one wave
+      // per SIMD: nobody else hides an LDS round trip)
+      float dq[2][4];
+      auto rd = [&](int it, float (&d)[4]) {
+        const char* p = rb[it % 3] + (2 * (2 * (it / 3) + h)) * 128;      // ring pixel 2t of tile t = 2s + h
+        d[0] = *(const float*)p;
+        d[1] = *(const float*)(p + 128);
+        d[2] = *(const float*)(p + 256);
+        d[3] = *(const float*)(p + 384);
+      };
+      rd(0, dq[0]);
+#pragma unroll
+      for (int it = 0; it < 24; ++it) {
+        const int s8 = it / 3, ky = it % 3;
+        if (it + 1 < 24) rd(it + 1, dq[(it + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float a0 = g0[s8], a3 = g1[s8];
+        const float a1 = 0.5f * (a0 + a3), a2 = 0.5f * (a0 - a3);
+        if (ky == 0) bsum += a0 + a3;
+        const float(&d)[4] = dq[it & 1];
+        acc[ky][0] = DD_MFMA(a0, d[0] - d[2], acc[ky][0]);
+        acc[ky][1] = DD_MFMA(a1, d[1] + d[2], acc[ky][1]);
+        acc[ky][2] = DD_MFMA(a2, d[2] - d[1], acc[ky][2]);
+        acc[ky][3] = DD_MFMA(a3, d[3] - d[1], acc[ky][3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      store_row<32, 1, false>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, pre);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        g0[s8] = n0[s8];
+        g1[s8] = n1[s8];
+      }
+    }
+  }
+
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[((((long)gw * 3 + ky) * 4 + p) * 16 + r) * 64 + lane] = acc[ky][p][r];
+  bpart[(long)gw * 64 + lane] = bsum;
+}
+
+// Second stage: fixed-order sums of the per-wave partials S_p (one block per (ky, register) row), then the output
+// transform and the scatter to OIHW.  Block 48 reduces the bias partials.
+__global__ __launch_bounds__(1024) void conv_wino_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
+                                                               float* __restrict__ dw, float* __restrict__ db, int nw) {
+  constexpr int G = 16;
+  __shared__ float red[4][G][64];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int row = blockIdx.x;   // ky*16 + r, or 48 for the bias
+  if (row == 48) {
+    float s0 = 0.f;
+    for (int w = g; w < nw; w += G) s0 += bpart[(long)w * 64 + l];
+    red[0][g][l] = s0;
+    __syncthreads();
+    if (g != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) s += red[0][i][l];
+    const float other = __shfl_xor(s, 32);
+    if (l < 32) db[l] = s + other;
+    return;
+  }
+  const int ky = row >> 4, r = row & 15;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int w = g; w < nw; w += G) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s[p] += part[((((long)w * 3 + ky) * 4 + p) * 16 + r) * 64 + l];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) red[p][g][l] = s[p];
+  __syncthreads();
+  if (g != 0) return;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < G; ++i) t[p] += red[p][i][l];
+  const int o = dd_acc_row(r, l), j = l & 31;
+  float* out = dw + ((long)o * 32 + j) * 9 + ky * 3;
+  out[0] = (t[0] + t[1]) + t[2];
+  out[1] = t[1] - t[2];
+  out[2] = (t[1] + t[2]) + t[3];
 }
 
 // U image for conv_wino_fwd: packed[((((ky*4 + p)*2 + half)*2 + g)*64 + lane)*4 + j] = u_p of the taps
@@ -1075,6 +1249,36 @@ int dd_conv_wino_pack(const float* w_oihw, float* packed, const dd_conv_desc* d,
   DD_REQUIRE(kind == 0 || kind == 1, DD_ERR_BAD_ARG, "conv_wino_pack: kind %d (0 forward, 1 data gradient)", kind);
   hipLaunchKernelGGL(conv_wino_pack_kernel, dim3((WINO_UFLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, kind);
   DD_LAUNCH_CHECK("conv_wino_pack");
+  return 0;
+}
+
+int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d) {
+  if (check_desc(d)) return -1;
+  if (d->cin_real != 32 || d->stride != 1) return -1;
+  return (int64_t)4 * DD_NUM_CU * ((int64_t)12 * 1024 + 64) * 4;      // one 4-wave workgroup per CU, 12 accumulators per wave
+}
+
+int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,
+                       const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && dy && dw_oihw && dbias && workspace, DD_ERR_BAD_ARG, "conv_wino_wgrad: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  DD_REQUIRE(workspace_bytes >= dd_conv_wino_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wino_wgrad: workspace %ld < %ld bytes",
+             (long)workspace_bytes, (long)dd_conv_wino_wgrad_workspace_bytes(d));
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int WPB = 4;
+  const int nstrips = (d->width + 31) / 32;
+  const int grid = resident_grid(d, (long)d->batch * nstrips * d->height, WPB, 1);
+  const int nw = grid * WPB;
+  float* part = (float*)workspace;
+  float* bpart = part + (size_t)nw * 12 * 1024;
+  auto k = conv_wino_wgrad<WPB>;
+  const size_t lds = (size_t)WPB * StripCfg<32, 1>::WAVEB;
+  if (int rc = allow_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
+  DD_LAUNCH_CHECK("conv_wino_wgrad");
+  hipLaunchKernelGGL(conv_wino_wgrad_reduce, dim3(49), dim3(1024), 0, st, part, bpart, dw_oihw, dbias, nw);
+  DD_LAUNCH_CHECK("conv_wino_wgrad_reduce");
   return 0;
 }
 

@@ -217,6 +217,19 @@ def conv_wino_dgrad_bits(dy, packed, bits, desc):
     return dx
 
 
+def conv_wino_wgrad(x, dy, desc):
+    _dev(x, "x", (desc.batch, desc.height, desc.width, 32))
+    _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
+    nbytes = _lib.lib().dd_conv_wino_wgrad_workspace_bytes(C.byref(desc))
+    if nbytes <= 0:
+        raise _lib.HotpathError(f"conv_wino_wgrad: {_lib.lib().dd_last_error().decode()}")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    dw = torch.empty((32, 32, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty(32, device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_wino_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, C.byref(desc), _stream()), "dd_conv_wino_wgrad")
+    return dw, db
+
+
 def conv_dgrad_bits(dy, packed_dgrad, bits, desc):
     ho, wo = conv_out(desc.height, desc.stride), conv_out(desc.width, desc.stride)
     _dev(dy, "dy", (desc.batch, ho, wo, 32))
@@ -347,7 +360,7 @@ class EncoderConvStack(torch.autograd.Function):
             for hook in MFMA_PHASE_HOOKS:
                 hook()
             if need[3] or need[4]:
-                dw2, db2 = conv_wgrad(a1, g2, d2)
+                dw2, db2 = conv_wino_wgrad(a1, g2, d2) if WINOGRAD else conv_wgrad(a1, g2, d2)
             if need[1] or need[2]:
                 if WINOGRAD:
                     g1 = conv_wino_dgrad_bits(g2, conv_wino_pack(w2, d2, 1), s1, d2)

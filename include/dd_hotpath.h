@@ -319,6 +319,10 @@ int dd_conv_wino_fwd_relu_bits(const float* x, const float* packed, const float*
                                const dd_conv_desc* d, void* stream);
 int dd_conv_wino_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
                                  const dd_conv_desc* d, void* stream);
+/* weight + bias gradient of the same layer by F(3,2) along x (as dd_conv_wgrad: deterministic two-stage reduction) */
+int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d);
+int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                       int64_t workspace_bytes, const dd_conv_desc* d, void* stream);
 
 /* ---- bf16 mixed precision (BASELINE config 5: 6x3x512x612 inputs, bf16) ---------------------------------
  * The encoder conv stack (components.py:19-21,41-43) with bf16 operands on the bf16 matrix cores and fp32

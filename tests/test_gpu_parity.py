@@ -99,7 +99,7 @@ def test_conv_fwd_dgrad_wgrad(dev, b, h, w, cin, stride, rows):
 
 @pytest.mark.parametrize("b,h,w", CONV_SHAPES + [(1, 1, 1), (1, 3, 64), (2, 4, 33)])
 @pytest.mark.parametrize("rows", [0, 3])
-def test_conv_winograd_fwd_dgrad(dev, b, h, w, rows):
+def test_conv_winograd_fwd_dgrad_wgrad(dev, b, h, w, rows):
     """The Winograd F(2,3) kernels of the 32 -> 32 stride-1 layer: forward (bias + ReLU + sign bits) and data gradient
     (sign-bit mask) against the fp64 oracle, and against the direct kernels' sign bits."""
     from driving_dirty_amd import _lib, ops
@@ -121,6 +121,12 @@ def test_conv_winograd_fwd_dgrad(dev, b, h, w, rows):
     mbits = torch.where(mbits >= 2 ** 31, mbits - 2 ** 32, mbits).to(torch.int32).to(dev)
     dx = ops.conv_wino_dgrad_bits(nhwc(gy.float()).to(dev), ops.conv_wino_pack(wd, desc, 1), mbits, desc)
     assert rel_err(dx.permute(0, 3, 1, 2), x.grad * (xm > 0)) < KERNEL_TOL
+    wt64 = wt.clone().requires_grad_(True)
+    bias64 = bias.clone().requires_grad_(True)
+    F.conv2d(x.detach(), wt64, bias64, padding=1).backward(gy)
+    dw, db = ops.conv_wino_wgrad(x_nhwc, nhwc(gy.float()).to(dev), desc)
+    assert rel_err(dw, wt64.grad) < KERNEL_TOL
+    assert rel_err(db, bias64.grad) < KERNEL_TOL
     with pytest.raises(_lib.HotpathError):
         ops.conv_wino_pack(wd, ops.conv_desc(b, h, w, 32, 2), 0)           # stride 2 has no Winograd path
 
