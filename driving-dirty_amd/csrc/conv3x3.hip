@@ -823,26 +823,30 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_wgrad(const float* __restr
       }
     }
 
-    for (int yy = y0; yy < y1; ++yy) {
-      f32x4 pre[C::NLOAD];
-      load_row<32, 1>(xb, H, W, yy + 2, gx0, lane, pre);
-      float n0[8], n1[8];
-      {
-        const bool ok = yy + 1 < H;
-        const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? yy + 1 : 0) * W * 32, ok ? W * 128 : 0);
+    // Two groups in flight (one wave per SIMD and only 6144 MFMA cycles per row: a one-row prefetch distance is shorter
+    // than the HBM latency under load).  group(t) = input row t+2 and dy row t+1, i.e. what output row t+1 adds.
+    struct Group {
+      f32x4 xrow[C::NLOAD];
+      float d0[8], d1[8];
+    };
+    auto issue = [&](int t, Group& f) {
+      load_row<32, 1>(xb, H, W, t + 2, gx0, lane, f.xrow);
+      const bool ok = t + 1 < H;
+      const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? t + 1 : 0) * W * 32, ok ? W * 128 : 0);
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-          n0[s8] = bload1(as, aoff + s8 * 512);
-          n1[s8] = bload1(as, aoff + s8 * 512 + 128);
-        }
+      for (int s8 = 0; s8 < 8; ++s8) {
+        f.d0[s8] = bload1(as, aoff + s8 * 512);
+        f.d1[s8] = bload1(as, aoff + s8 * 512 + 128);
       }
+    };
+    auto step = [&](int yy, Group& cur, Group& nxt) {
+      issue(yy + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
 
       const char* rb[3];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) rb[ky] = ring + ((yy + ky) % 3) * C::SLOTB + n * 4;
-      // 24 groups (tile pair s8, tap row ky) of 4 reads + 4 MFMAs; the reads run one group ahead of the MFMAs (one wave
-      // per SIMD: nobody else hides an LDS round trip)
+      // 24 groups (tile pair s8, tap row ky) of 4 reads + 4 MFMAs; the reads run one group ahead of the MFMAs
       float dq[2][4];
       auto rd = [&](int it, float (&d)[4]) {
         const char* p = rb[it % 3] + (2 * (2 * (it / 3) + h)) * 128;      // ring pixel 2t of tile t = 2s + h
@@ -868,13 +872,24 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_wgrad(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
       }
 
-      store_row<32, 1, false>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, pre);
+      store_row<32, 1, false>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, cur.xrow);
+      const bool live = yy + 1 < y1;          // past the range end the next row's dy must not be accumulated
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        g0[s8] = n0[s8];
-        g1[s8] = n1[s8];
+        g0[s8] = live ? cur.d0[s8] : 0.f;
+        g1[s8] = live ? cur.d1[s8] : 0.f;
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Group ga, gb;
+    issue(y0, ga);
+    __builtin_amdgcn_sched_barrier(0);
+    int yy = y0;
+    do {                                      // pairs of rows; an odd range ends with one row of zero dy (no contribution)
+      step(yy, ga, gb);
+      step(yy + 1, gb, ga);
+      yy += 2;
+    } while (yy < y1);
   }
 
 #pragma unroll
