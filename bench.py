@@ -35,7 +35,13 @@ PEAK_F32_MFMA_TF = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: Pe
 # algorithmic work per scene, fwd+bwd: roadmap step 35.080 GFLOP; the dominant kernel is the
 # c2 forward convolution: 2 * 256*1836 pixels * 32 * (9*32) flop per scene
 C2_FLOP_PER_SCENE = 2.0 * 256 * 1836 * 32 * 288
-STEP_FLOP_PER_SCENE = 35.080e9
+STEP_FLOP_PER_SCENE = 35.080e9            # hidden 128 / latent 64; step_flop_per_scene() for other widths
+
+
+def step_flop_per_scene():
+    """Conv stack fwd+bwd (34.112 GF, no data gradient for c1) + 3 passes x 2 flop x MACs of the four Linear layers."""
+    pooled = 32 * 128 * 918 // 4
+    return 34.112e9 + 6.0 * (pooled * HIDDEN + HIDDEN * HIDDEN + HIDDEN * LATENT + LATENT * 640000)
 
 
 def build_model(dev):
@@ -150,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
     ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
+    ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
+    ap.add_argument("--latent", type=int, default=LATENT, help="latent width (64; with --hidden 256: 128)")
     ap.add_argument("--direct-conv", action="store_true", help="c2 forward / data gradient on the direct kernels instead of Winograd F(2,3)")
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
     a = ap.parse_args()
@@ -187,6 +195,7 @@ def main():
     if a.cu_budget:
         _lib.check(_lib.lib().dd_set_cu_budget(a.cu_budget), "dd_set_cu_budget")
 
+    globals().update(HIDDEN=a.hidden, LATENT=a.latent)
     if a.direct_conv:
         from driving_dirty_amd import ops as _o
         _o.WINOGRAD = False
@@ -246,9 +255,9 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: roadmap segmentation 6x3x256x306 -> 800x800 mask, "
-                                   "bs=32 per GPU, fp32, hidden 128 / latent 64, encoder unfrozen, fwd+bwd+Adam",
+                                   "bs=32 per GPU, fp32, hidden %d / latent %d, encoder unfrozen, fwd+bwd+Adam" % (HIDDEN, LATENT),
                        "global_batch": world * BATCH, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
-            "step_frac_of_fp32_mfma_peak": round(STEP_FLOP_PER_SCENE * BATCH * world / (ms * 1e-3) / 1e12
+            "step_frac_of_fp32_mfma_peak": round(step_flop_per_scene() * BATCH * world / (ms * 1e-3) / 1e12
                                                  / (PEAK_F32_MFMA_TF * world), 4),
             "roofline": {"kernel": ("conv_wino_fwd (c2 forward, Winograd F(2,3) along x: issues 2/3 of the algorithmic flops)"
                                     if wino else "conv_strip_fwd<CIN=32,S=1> (c2 forward, direct)") + ", 74% of encoder FLOPs fwd",
