@@ -418,8 +418,10 @@ int dd_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, in
   hipStream_t st = (hipStream_t)stream;
   if (k >= 512 && k % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dw % 16 == 0)) {   // long rows: 16-byte path
     const int gk = (k + 127) / 128;
-    const long total = (long)((n + 63) / 64) * gk;
-    hipLaunchKernelGGL((linear_wgrad_wide_kernel<2>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, dy, x, dw,
+    // 32 x 128 tiles (TN = 1): four times the waves of the 64 x 128 form re-read x from L2 but keep far more of the
+    // 481 MB write stream in flight (measured on fc1: 0.254 -> 0.19 ms)
+    const long total = (long)((n + 31) / 32) * gk;
+    hipLaunchKernelGGL((linear_wgrad_wide_kernel<1>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, dy, x, dw,
                        dbias, m, n, k, gk, total);
   } else if (n <= 256 || k > n) {   // few output rows: one k-tile x up to 4 n-tiles per wave
     const int gk = (k + 31) / 32;
