@@ -332,42 +332,49 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restric
   }
 }
 
-// dw[w_off + o*sn + c*sc + tap'] (+)= sum over ranges; one thread per accumulator element.
+// dw[w_off + o*sn + c*sc + tap'] (+)= sum over ranges.  One block = 256 consecutive accumulator elements (four register
+// rows of one tile) x 16 groups of ranges; a lane reads 16 bytes, so every wave-load is 1 KB of contiguous partials
+// (the partials of one range are `per` floats apart: 256-byte pieces ran at a quarter of the bandwidth).
 __global__ __launch_bounds__(1024) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
                                                            int nranges, int njobs, int no, int nb, int njg, int T, int cin,
                                                            long w_off, long sn, long sc, int flip, int n_real, int c_real,
                                                            int accumulate) {
-  // one block = 64 consecutive accumulator elements (one register row of one tile) x 16 groups of ranges
-  __shared__ float red[16][64];
+  __shared__ f32x4 red[16][64];
   const long per = (long)njobs * no * nb * 1024;
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long e = (long)blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int l64 = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long e0 = (long)blockIdx.x * 256 + 4 * l64;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s0 = z, s1 = z, s2 = z, s3 = z;
   int r = g;
   for (; r + 48 < nranges; r += 64) {
-    s0 += part[(long)r * per + e];
-    s1 += part[(long)(r + 16) * per + e];
-    s2 += part[(long)(r + 32) * per + e];
-    s3 += part[(long)(r + 48) * per + e];
+    s0 += *(const f32x4*)(part + (long)r * per + e0);
+    s1 += *(const f32x4*)(part + (long)(r + 16) * per + e0);
+    s2 += *(const f32x4*)(part + (long)(r + 32) * per + e0);
+    s3 += *(const f32x4*)(part + (long)(r + 48) * per + e0);
   }
-  for (; r < nranges; r += 16) s0 += part[(long)r * per + e];
-  red[g][lane] = (s0 + s1) + (s2 + s3);
+  for (; r < nranges; r += 16) s0 += *(const f32x4*)(part + (long)r * per + e0);
+  red[g][l64] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g != 0) return;
-  float s = 0.f;
+  f32x4 sv = z;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += red[i][lane];
-  const int reg = (int)((e >> 6) & 15);
-  const long jk = e >> 10;
-  const int k = (int)(jk % nb), a = (int)((jk / nb) % no), job = (int)(jk / ((long)nb * no));
-  const int og = job / njg, jg = job - og * njg;
-  const int o = (og * no + a) * 32 + dd_acc_row(reg, lane);
-  const int j = (jg * nb + k) * 32 + (lane & 31);
-  if (j >= T * cin) return;
-  const int tap = j / cin, c = j - tap * cin;
-  if (o >= n_real || c >= c_real) return;
-  const long wi = w_off + o * sn + c * sc + (flip ? T - 1 - tap : tap);
-  dw[wi] = accumulate ? dw[wi] + s : s;
+  for (int i = 0; i < 16; ++i) sv += red[i][l64];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long e = e0 + q;
+    const int lane = (int)(e & 63);
+    const int reg = (int)((e >> 6) & 15);
+    const long jk = e >> 10;
+    const int k = (int)(jk % nb), a = (int)((jk / nb) % no), job = (int)(jk / ((long)nb * no));
+    const int og = job / njg, jg = job - og * njg;
+    const int o = (og * no + a) * 32 + dd_acc_row(reg, lane);
+    const int j = (jg * nb + k) * 32 + (lane & 31);
+    if (j >= T * cin) continue;
+    const int tap = j / cin, c = j - tap * cin;
+    if (o >= n_real || c >= c_real) continue;
+    const long wi = w_off + o * sn + c * sc + (flip ? T - 1 - tap : tap);
+    dw[wi] = accumulate ? dw[wi] + sv[q] : sv[q];
+  }
 }
 
 __global__ __launch_bounds__(1024) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
@@ -625,6 +632,50 @@ __global__ __launch_bounds__(1024) void channel_sum_final(const float* __restric
   out[c] = accumulate ? out[c] + s : s;
 }
 
+// Streaming variant (cstore % 4 == 0): the buffer is read as one flat float4 stream, 16 bytes per lane and four loads
+// in flight; the grid's thread count is a multiple of the quads per pixel, so a thread keeps ONE channel quad for its
+// whole stride loop and needs no index arithmetic.  Partials are written channel-major so the final pass reads each
+// channel's partials contiguously (one block per channel).  Summation order is fixed: deterministic.
+__global__ __launch_bounds__(256) void channel_sum_stream(const f32x4* __restrict__ buf, float* __restrict__ partial_t, long nquads,
+                                                          int quads_per_px, int coff, int cout) {
+  __shared__ f32x4 red[256];
+  const int bs = blockDim.x;
+  const long t = (long)blockIdx.x * bs + threadIdx.x, T = (long)gridDim.x * bs;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  long i = t;
+  for (; i + 3 * T < nquads; i += 4 * T) {
+    const f32x4 a = buf[i], b = buf[i + T], c = buf[i + 2 * T], d = buf[i + 3 * T];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; i < nquads; i += T) s0 += buf[i];
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if ((int)threadIdx.x < quads_per_px) {
+    f32x4 s = red[threadIdx.x];
+    for (int k = threadIdx.x + quads_per_px; k < bs; k += quads_per_px) s += red[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * threadIdx.x + j - coff;
+      if (c >= 0 && c < cout) partial_t[(long)c * gridDim.x + blockIdx.x] = s[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_sum_stream_final(const float* __restrict__ partial_t, float* __restrict__ out, int nblocks,
+                                                                int accumulate) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial_t[(long)c * nblocks + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + red[0] : red[0];
+}
+
 }  // namespace
 
 extern "C" {
@@ -707,7 +758,7 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
 #undef DD_GW
   DD_LAUNCH_CHECK("gconv_wgrad");
   const long per = (long)p.njobs * p.no * p.nb * 1024;
-  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)(per / 64)), dim3(1024), 0, st, part, dw, p.nranges, p.njobs, p.no,
+  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)(per / 256)), dim3(1024), 0, st, part, dw, p.nranges, p.njobs, p.no,
                      p.nb, p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
   DD_LAUNCH_CHECK("gconv_wgrad_reduce");
   if (dbias) {
@@ -724,6 +775,17 @@ int dd_channel_sum(const float* buf, float* out, int64_t npix, int32_t cstore, i
   DD_REQUIRE(buf && out && workspace && npix > 0 && cstore > 0 && coff >= 0 && cout > 0 && coff + cout <= cstore, DD_ERR_BAD_ARG,
              "channel_sum: bad argument");
   DD_REQUIRE(cout <= 128, DD_ERR_UNSUPPORTED, "channel_sum: more than 128 channels");
+  if (cstore % 4 == 0 && cstore <= 256 && (uintptr_t)buf % 16 == 0) {
+    const int q = cstore / 4, bs = (256 / q) * q;
+    const long nquads = (long)npix * q;
+    const int grid = (int)max(1L, min((nquads + 4L * bs - 1) / (4L * bs), (long)DD_NUM_CU * 4));
+    hipLaunchKernelGGL(channel_sum_stream, dim3(grid), dim3(bs), 0, (hipStream_t)stream, (const f32x4*)buf, (float*)workspace, nquads, q,
+                       coff, cout);
+    DD_LAUNCH_CHECK("channel_sum");
+    hipLaunchKernelGGL(channel_sum_stream_final, dim3(cout), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, grid, accumulate);
+    DD_LAUNCH_CHECK("channel_sum final");
+    return 0;
+  }
   const int grid = (int)min((npix + 3) / 4, (long)DD_NUM_CU * 4);
   hipLaunchKernelGGL(channel_sum_partial, dim3(grid), dim3(256), 0, (hipStream_t)stream, buf, (float*)workspace, (long)npix, cstore,
                      coff, cout);

@@ -131,3 +131,24 @@ def test_view_transform(dev, view, tf):
     out = gconv.view_to_nhwc4(v.to(dev), view, tf)
     assert torch.equal(out[..., :3].permute(0, 3, 1, 2).cpu(), ref)
     assert float(out[..., 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,coff,chans", [((2, 37, 41, 96), 0, 96), ((3, 16, 20, 96), 32, 32), ((1, 5, 7, 8), 0, 8), ((2, 9, 9, 4), 1, 2),
+                                                ((1, 4, 6, 3), 0, 3), ((2, 200, 256, 64), 0, 64), ((1, 1, 1, 32), 0, 32)])
+def test_channel_sum(dev, shape, coff, chans):
+    """Per-channel sum over all pixels of an NHWC buffer (bias gradient of the role-swapped transposed convolutions):
+    the streaming path (channel count a multiple of 4) and the general path, plain and accumulating."""
+    from driving_dirty_amd import gconv
+    buf = synth.hash_uniform(shape, synth.key_salt("chs", shape[1])).to(dev)
+    out = torch.full((chans,), 3.0, device=dev)
+    gconv.channel_sum(gconv.View(buf, coff, chans), out)
+    ref = buf.double().sum(dim=(0, 1, 2))[coff:coff + chans]
+    scale = float(buf.double().abs().sum(dim=(0, 1, 2)).max())
+    assert float((out.double() - ref).abs().max()) / scale < 2e-6
+    gconv.channel_sum(gconv.View(buf, coff, chans), out, accumulate=True)
+    assert float((out.double() - 2 * ref).abs().max()) / scale < 4e-6
+    again = torch.empty_like(out)
+    gconv.channel_sum(gconv.View(buf, coff, chans), again)
+    twice = torch.empty_like(out)
+    gconv.channel_sum(gconv.View(buf, coff, chans), twice)
+    assert torch.equal(again, twice)            # fixed summation order
