@@ -695,18 +695,26 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restric
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) u[p][hf] = ul[((((ky * 4 + p) * 2 + hf) * 2 + g) * 64) + lane];
       };
-      rd(0, dbuf[0], ubuf[0]);
-#pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        if (it + 1 < 6) rd(it + 1, dbuf[(it + 1) & 1], ubuf[(it + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4(&d)[4] = dbuf[it & 1];
-        const f32x4(&u)[4][2] = ubuf[it & 1];
-        f32x4 v[4];
+      // the input transform of a group runs while the PREVIOUS group's MFMAs execute and lands in its own registers: an
+      // MFMA never waits for a VALU result, a VALU write never waits for an MFMA that has not read its operand yet
+      f32x4 vbuf[2][4];
+      auto tf = [&](const f32x4 (&d)[4], f32x4 (&v)[4]) {
         v[0] = d[0] - d[2];
         v[1] = d[1] + d[2];
         v[2] = d[2] - d[1];
         v[3] = d[1] - d[3];
+      };
+      rd(0, dbuf[0], ubuf[0]);
+      tf(dbuf[0], vbuf[0]);
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        if (it + 1 < 6) {
+          rd(it + 1, dbuf[(it + 1) & 1], ubuf[(it + 1) & 1]);
+          tf(dbuf[(it + 1) & 1], vbuf[(it + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4(&u)[4][2] = ubuf[it & 1];
+        const f32x4(&v)[4] = vbuf[it & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -813,82 +821,99 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_wgrad(const float* __restr
       load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
       store_row<32, 1, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
     }
-    float g0[8], g1[8];
-    {
-      const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)y0 * W * 32, W * 128);
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        g0[s8] = bload1(as, aoff + s8 * 512);
-        g1[s8] = bload1(as, aoff + s8 * 512 + 128);
-      }
-    }
-
-    // Two groups in flight (one wave per SIMD and only 6144 MFMA cycles per row: a one-row prefetch distance is shorter
-    // than the HBM latency under load).  group(t) = input row t+2 and dy row t+1, i.e. what output row t+1 adds.
+    // One wave per SIMD: whatever is not an MFMA must slip into the shadow of one, or the pipe idles.  So the row step
+    //  * keeps THREE rotating register groups (dy in use / rows arriving / rows just requested): no register moves;
+    //  * runs the 24 (tap row, tile pair) groups tap-row-major, so the ring slot of the oldest input row is free after
+    //    the first 8 groups and the arriving row is written into it in the middle of the MFMA stream;
+    //  * issues the next group's 21 loads one per MFMA group instead of in a burst at the row boundary.
+    // group(t) = input row t+2 and dy row t+1, i.e. what output row t+1 adds.
     struct Group {
       f32x4 xrow[C::NLOAD];
       float d0[8], d1[8];
     };
-    auto issue = [&](int t, Group& f) {
-      load_row<32, 1>(xb, H, W, t + 2, gx0, lane, f.xrow);
-      const bool ok = t + 1 < H;
-      const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? t + 1 : 0) * W * 32, ok ? W * 128 : 0);
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        f.d0[s8] = bload1(as, aoff + s8 * 512);
-        f.d1[s8] = bload1(as, aoff + s8 * 512 + 128);
+    auto issue_part = [&](int t, Group& f, int part) {       // part 0..7: dy pair s8 = part; parts 8..12: x chunks
+      if (part < 8) {
+        const bool ok = (t + 1 < y1);                        // dy rows past the range belong to the next wave: read zeros
+        const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? t + 1 : 0) * W * 32, ok ? W * 128 : 0);
+        f.d0[part] = bload1(as, aoff + part * 512);
+        f.d1[part] = bload1(as, aoff + part * 512 + 128);
+      } else {
+        const int i = part - 8;
+        const int iy = t + 2;
+        const bool rowok = (iy >= 0) && (iy < H);
+        const __amdgpu_buffer_rsrc_t rs = rsrc(xb + (long)(rowok ? iy : 0) * W * 32, rowok ? W * 128 : 0);
+        const int c = lane + 64 * i;
+        const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
+        f.xrow[i] = bload4(rs, (c < C::NCH) ? ((gx0 + q) * C::PXB + ch * 16) : -16);
       }
     };
-    auto step = [&](int yy, Group& cur, Group& nxt) {
-      issue(yy + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-
+    auto step = [&](int yy, const Group& prev, Group& cur, Group& nxt) {
       const char* rb[3];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) rb[ky] = ring + ((yy + ky) % 3) * C::SLOTB + n * 4;
-      // 24 groups (tile pair s8, tap row ky) of 4 reads + 4 MFMAs; the reads run one group ahead of the MFMAs
-      float dq[2][4];
+      float a1[8], a2[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        a1[s8] = 0.5f * (prev.d0[s8] + prev.d1[s8]);
+        a2[s8] = 0.5f * (prev.d0[s8] - prev.d1[s8]);
+        bsum += prev.d0[s8] + prev.d1[s8];
+      }
+      // reads run two groups ahead, the input transform one group ahead, each in its own registers: an MFMA must never
+      // wait for a VALU result, nor a VALU write for an MFMA that has not read its operand yet
+      float dq[3][4], vq[2][4];
       auto rd = [&](int it, float (&d)[4]) {
-        const char* p = rb[it % 3] + (2 * (2 * (it / 3) + h)) * 128;      // ring pixel 2t of tile t = 2s + h
+        const char* p = rb[it >> 3] + (2 * (2 * (it & 7) + h)) * 128;      // ring pixel 2t of tile t = 2s + h
         d[0] = *(const float*)p;
         d[1] = *(const float*)(p + 128);
         d[2] = *(const float*)(p + 256);
         d[3] = *(const float*)(p + 384);
       };
+      auto tf = [&](const float (&d)[4], float (&v)[4]) {
+        v[0] = d[0] - d[2];
+        v[1] = d[1] + d[2];
+        v[2] = d[2] - d[1];
+        v[3] = d[3] - d[1];
+      };
       rd(0, dq[0]);
+      rd(1, dq[1]);
+      tf(dq[0], vq[0]);
 #pragma unroll
       for (int it = 0; it < 24; ++it) {
-        const int s8 = it / 3, ky = it % 3;
-        if (it + 1 < 24) rd(it + 1, dq[(it + 1) & 1]);
+        const int ky = it >> 3, s8 = it & 7;
+        if (it + 2 < 24) rd(it + 2, dq[(it + 2) % 3]);
+        if (it + 1 < 24) tf(dq[(it + 1) % 3], vq[(it + 1) & 1]);
+        if (it < 13) issue_part(yy + 1, nxt, it);            // next group's loads, one (pair) per MFMA group
         __builtin_amdgcn_sched_barrier(0);
-        const float a0 = g0[s8], a3 = g1[s8];
-        const float a1 = 0.5f * (a0 + a3), a2 = 0.5f * (a0 - a3);
-        if (ky == 0) bsum += a0 + a3;
-        const float(&d)[4] = dq[it & 1];
-        acc[ky][0] = DD_MFMA(a0, d[0] - d[2], acc[ky][0]);
-        acc[ky][1] = DD_MFMA(a1, d[1] + d[2], acc[ky][1]);
-        acc[ky][2] = DD_MFMA(a2, d[2] - d[1], acc[ky][2]);
-        acc[ky][3] = DD_MFMA(a3, d[3] - d[1], acc[ky][3]);
+        const float(&v)[4] = vq[it & 1];
+        acc[ky][0] = DD_MFMA(prev.d0[s8], v[0], acc[ky][0]);
+        acc[ky][1] = DD_MFMA(a1[s8], v[1], acc[ky][1]);
+        acc[ky][2] = DD_MFMA(a2[s8], v[2], acc[ky][2]);
+        acc[ky][3] = DD_MFMA(prev.d1[s8], v[3], acc[ky][3]);
         __builtin_amdgcn_sched_barrier(0);
+        if (it == 15) {   // tap row 0 (the oldest input row) was read by groups 0..7 and tap-row-1 reads (8..15) are out too
+          store_row<32, 1, false>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, cur.xrow);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-
-      store_row<32, 1, false>(ring + ((yy + 3) % 3) * C::SLOTB, spill, lane, cur.xrow);
-      const bool live = yy + 1 < y1;          // past the range end the next row's dy must not be accumulated
+    };
+    Group ga, gb, gc;
+    {   // dy row y0 (group y0-1's dy half) and group y0, synchronously enough: the loop waits for them where it uses them
+      const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)y0 * W * 32, W * 128);
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        g0[s8] = live ? cur.d0[s8] : 0.f;
-        g1[s8] = live ? cur.d1[s8] : 0.f;
+        ga.d0[s8] = bload1(as, aoff + s8 * 512);
+        ga.d1[s8] = bload1(as, aoff + s8 * 512 + 128);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    Group ga, gb;
-    issue(y0, ga);
+#pragma unroll
+      for (int part = 0; part < 13; ++part) issue_part(y0, gb, part);
+    }
     __builtin_amdgcn_sched_barrier(0);
     int yy = y0;
-    do {                                      // pairs of rows; an odd range ends with one row of zero dy (no contribution)
-      step(yy, ga, gb);
-      step(yy + 1, gb, ga);
-      yy += 2;
+    do {                                      // triples of rows; rows past the range see zero dy (no contribution)
+      step(yy, ga, gb, gc);
+      step(yy + 1, gb, gc, ga);
+      step(yy + 2, gc, ga, gb);
+      yy += 3;
     } while (yy < y1);
   }
 
