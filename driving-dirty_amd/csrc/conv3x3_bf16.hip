@@ -516,17 +516,26 @@ __global__ __launch_bounds__(WPB * 64) void bf_wgrad(const unsigned short* __res
       }
 
       if constexpr (CIN == 32) {
+        // 18 (tap, k16 half) steps of 2 transpose reads + 1 MFMA; one wave per SIMD, so the reads run four steps ahead
+        const char* rowb[3];
 #pragma unroll
-        for (int dyy = 0; dyy < 3; ++dyy) {
-          const char* rowb = ring + ((S * yy + dyy) % 3) * C::SLOTB + x_lane;
+        for (int dyy = 0; dyy < 3; ++dyy) rowb[dyy] = ring + ((S * yy + dyy) % 3) * C::SLOTB + x_lane;
+        constexpr int AH = 4;
+        s16x4 lo[AH + 1], hi[AH + 1];
+        auto rd = [&](int it) {
+          const int tap = it >> 1, m = it & 1;
+          const char* pa = rowb[tap / 3] + (S * 16 * m + tap % 3) * 64;
+          lo[it % (AH + 1)] = tr_read(pa);
+          hi[it % (AH + 1)] = tr_read(pa + S * 4 * 64);
+        };
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
+        for (int it = 0; it < AH; ++it) rd(it);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const char* pa = rowb + (S * 16 * m + dx) * 64;
-              const bf16x8 am = join(tr_read(pa), tr_read(pa + S * 4 * 64));
-              acc[dyy * 3 + dx] = BF_MFMA(am, bm[m], acc[dyy * 3 + dx]);
-            }
+        for (int it = 0; it < 18; ++it) {
+          if (it + AH < 18) rd(it + AH);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[it >> 1] = BF_MFMA(join(lo[it % (AH + 1)], hi[it % (AH + 1)]), bm[it & 1], acc[it >> 1]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
         // rows of D: i = 16*(ky select) + 4*shift + channel; accumulator 0 takes ky 0 (rows 0-15) and 1 (rows 16-31),
