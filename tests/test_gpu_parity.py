@@ -464,3 +464,17 @@ def test_cu_budget_never_changes_results(dev):
         _lib.lib().dd_set_cu_budget(256)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel_err(outs[1][2], outs[0][2]) < 1e-5 and rel_err(outs[1][3], outs[0][3]) < 1e-5
+
+
+@pytest.mark.parametrize("b,c,cs,h,w", [(2, 64, 64, 13, 17), (1, 3, 4, 5, 9), (3, 32, 32, 8, 64), (2, 5, 8, 7, 11), (1, 64, 64, 128, 153),
+                                        (2, 96, 96, 6, 6), (1, 1, 8, 1, 1)])
+def test_layout_round_trip(dev, b, c, cs, h, w):
+    """NCHW <-> NHWC(c_store): exact copies, zero padding channels, both the tiled (8..64 stored channels) and the
+    element-wise kernels."""
+    from driving_dirty_amd import ops
+    x = hu((b, c, h, w), f"lay{c}{h}{w}").to(dev)
+    y = ops.nchw_to_nhwc(x, cs)
+    assert torch.equal(y[..., :c], x.permute(0, 2, 3, 1))
+    if cs > c:
+        assert float(y[..., c:].abs().max()) == 0.0
+    assert torch.equal(ops.nhwc_to_nchw(y, c), x)

@@ -43,6 +43,7 @@ def main():
     if "ae" in a.which:
         ae = BasicAE(Namespace(hidden_dim=128, latent_dim=64, learning_rate=1e-3, output_img_freq=500)).to(dev)
         opt = HipAdam(ae.parameters(), lr=1e-3)
+        opt.overlap_with_backward()          # big tensors' Adam pass rides under the MFMA-bound conv backward (as bench.py)
         views = torch.rand(b, 6, 3, 256, 306, device=dev)
 
         def step(i):
