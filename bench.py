@@ -84,6 +84,7 @@ class KernelTimer:
             return timed
         ops.conv_fwd_bits = wrap(ops.conv_fwd_bits)
         ops.conv_wino_fwd_bits = wrap(ops.conv_wino_fwd_bits)
+        ops.conv_wino2_fwd_bits = wrap(ops.conv_wino2_fwd_bits)
 
     def mean_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
@@ -158,6 +159,7 @@ def main():
     ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
     ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
     ap.add_argument("--latent", type=int, default=LATENT, help="latent width (64; with --hidden 256: 128)")
+    ap.add_argument("--wino-1d", action="store_true", help="c2 forward / data gradient by F(2,3) along x instead of F(2x2,3x3)")
     ap.add_argument("--direct-conv", action="store_true", help="c2 forward / data gradient on the direct kernels instead of Winograd F(2,3)")
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
     a = ap.parse_args()
@@ -199,6 +201,9 @@ def main():
     if a.direct_conv:
         from driving_dirty_amd import ops as _o
         _o.WINOGRAD = False
+    if a.wino_1d:
+        from driving_dirty_amd import ops as _o
+        _o.WINOGRAD_2D = False
     model = build_model(dev)
     model.ae.encoder.rows_per_task = a.rows_per_task
     model.training_step(synthetic_batch(dev, 2, rank), 0)["loss"].backward()   # unfreezes the AE (epoch 0 >= 0)
@@ -249,6 +254,7 @@ def main():
         achieved = C2_FLOP_PER_SCENE * BATCH / (k_ms * 1e-3) / 1e12      # ALGORITHMIC flops (direct-convolution count)
         from driving_dirty_amd import ops as _ops
         wino = bool(_ops.WINOGRAD)
+        wino2 = wino and bool(_ops.WINOGRAD_2D)
         line = {
             "metric": "6-view scenes/sec fwd+bwd, roadmap model bs=32",
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -259,12 +265,13 @@ def main():
                        "global_batch": world * BATCH, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
             "step_frac_of_fp32_mfma_peak": round(step_flop_per_scene() * BATCH * world / (ms * 1e-3) / 1e12
                                                  / (PEAK_F32_MFMA_TF * world), 4),
-            "roofline": {"kernel": ("conv_wino_fwd (c2 forward, Winograd F(2,3) along x: issues 2/3 of the algorithmic flops)"
+            "roofline": {"kernel": ("conv_wino2_fwd (c2 forward, Winograd F(2x2,3x3): issues 4/9 of the algorithmic flops)" if wino2 else
+                                    "conv_wino_fwd (c2 forward, Winograd F(2,3) along x: issues 2/3 of the algorithmic flops)"
                                     if wino else "conv_strip_fwd<CIN=32,S=1> (c2 forward, direct)") + ", 74% of encoder FLOPs fwd",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": measured_traffic(),
                          "launch_ms": round(k_ms, 4), "launches_timed": len(timer.pairs),
-                         "issued_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TF, 4)},
+                         "issued_frac": round(achieved * (4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TF, 4)},
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

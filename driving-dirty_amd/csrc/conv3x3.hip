@@ -770,6 +770,258 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3): the same transform along y as well -- a 2x2 output tile from a 4x4 input patch with 16
+// multiplies instead of 36 (4/9 of the direct form's matrix-core work, 2/3 of the 1-D form's).  Needs four ring rows
+// per wave and 64 KB of transformed weights, which leaves room for ONE wave per SIMD (4-wave workgroups, 134 KB): every
+// non-MFMA instruction therefore has to sit in the shadow of an MFMA, and no MFMA may wait for a VALU result.
+// Per iteration a wave produces 2 output rows x 32 pixels = 16 tiles: 16 positions x 2 channel halves x 8 k-steps =
+// 256 v_mfma_f32_16x16x4_f32 (8192 cycles).  Lane (tile t = lane&15, q = lane>>4) transforms input channels 8q..8q+7
+// of its own tile; per channel quad g the x-stage results w[4][4] live in registers, the y-stage row V[u][0..3] of the
+// NEXT position row is computed while the current row's 32 MFMAs execute, and its 8 U vectors are read a stage earlier.
+// ------------------------------------------------------------------------------------------------
+constexpr int WINO2_UFLOATS = 16 * 2 * 2 * 64 * 4;      // [pos = 4u+v][half][chunk][lane][4]
+
+template <int EPI, int WPB, int DBG = 0>   // EPI_BIAS_RELU_BITS (forward) or EPI_RELU_BITS (data gradient)
+__global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restrict__ x, const float* __restrict__ up,
+                                                           const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
+                                                           float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
+                                                           int W, int nstrips) {
+  using C = StripCfg<32, 1>;
+  constexpr int RINGB = 4 * C::SLOTB + C::SPILLB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    f32x4* ul4 = (f32x4*)smem;
+    const f32x4* ug4 = (const f32x4*)up;
+    for (int i = tid; i < WINO2_UFLOATS / 4; i += WPB * 64) ul4[i] = ug4[i];
+  }
+  __syncthreads();
+  char* ring = smem + WINO2_UFLOATS * 4 + wave * RINGB;
+  char* spill = ring + 4 * C::SLOTB;
+  const f32x4* ul = (const f32x4*)smem;
+  const int t16 = lane & 15, q4 = lane >> 4;
+  const float bv0 = (EPI == EPI_BIAS_RELU_BITS) ? bias[t16] : 0.f, bv1 = (EPI == EPI_BIAS_RELU_BITS) ? bias[16 + t16] : 0.f;
+  const int HT = (H + 1) / 2;                         // tile rows
+
+  long idx, end;
+  wave_range((long)B * nstrips * HT, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / HT;
+    const int r0 = (int)(idx - col * HT);
+    const int r1 = (int)min((long)HT, r0 + (end - idx));
+    idx += r1 - r0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const float* xb = x + (long)b * H * W * 32;
+    const int gx0 = x0 - 1;
+
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {      // input rows 2*r0 - 1 .. 2*r0 + 2; slot of row iy = (iy + 1) & 3
+      f32x4 t[C::NLOAD];
+      const int iy = 2 * r0 - 1 + d;
+      load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
+      store_row<32, 1, true>(ring + ((iy + 1) & 3) * C::SLOTB, spill, lane, t);
+    }
+
+    // Operand pipeline.  With one wave per SIMD an instruction hides only in the ~24 issue cycles an MFMA leaves free,
+    // so (a) every stage is ONE scheduling region in which the 32 MFMAs and the work for LATER stages are interleaved
+    // (sched_group_barrier), and (b) nothing in a stage waits for a load issued in the same stage:
+    //   patch reads of the next channel quad (or of the next tile-row's first quad)   issued in stage 2 (6)
+    //   their x-stage (64 VALU, in place: the old w is dead once V of stage 3 (7) exists)   in stage 3 (7)
+    //   U vectors of stage s+1   read in stage s;   V of stage s+1   computed from w in stage s
+    //   arriving rows -> ring   in stage 4 (the last patch read of this tile-row left in stage 2)
+    auto rowslot = [&](int tr, int r) { return ring + ((2 * tr + r) & 3) * C::SLOTB; };      // slot of input row 2*tr - 1 + r
+    auto patch_read = [&](int tr, int g, f32x4 (&d)[4][4]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const char* rp = rowslot(tr, r);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int px = 2 * t16 + c;
+          d[r][c] = *(const f32x4*)(rp + px * 128 + (((2 * q4 + g) ^ swz<32>(px)) << 4));
+        }
+      }
+    };
+    auto xstage = [&](const f32x4 (&d)[4][4], f32x4 (&w)[4][4]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        w[r][0] = d[r][0] - d[r][2];
+        w[r][1] = d[r][1] + d[r][2];
+        w[r][2] = d[r][2] - d[r][1];
+        w[r][3] = d[r][1] - d[r][3];
+      }
+    };
+    auto ystage = [&](int u, const f32x4 (&w)[4][4], f32x4 (&v)[4]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (u == 0) v[c] = w[0][c] - w[2][c];
+        else if (u == 1) v[c] = w[1][c] + w[2][c];
+        else if (u == 2) v[c] = w[2][c] - w[1][c];
+        else v[c] = w[1][c] - w[3][c];
+      }
+    };
+    auto uread = [&](int g, int u, f32x4 (&uu)[4][2]) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) uu[v][hf] = ul[((((u * 4 + v) * 2 + hf) * 2 + g) * 64) + lane];
+    };
+
+    f32x4 dp[4][4];                 // patch of the quad whose x-stage comes next
+    f32x4 wq[4][4];                 // x-stage results of the current channel quad
+    f32x4 vq[2][4], uq[2][4][2];    // V row and U vectors of the current / next stage
+    patch_read(r0, 0, dp);
+    xstage(dp, wq);
+    ystage(0, wq, vq[0]);
+    uread(0, 0, uq[0]);
+
+    for (int tr = r0; tr < r1; ++tr) {
+      f32x4 pre[2][C::NLOAD];
+      load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
+      load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
+      unsigned mw[2][8];
+      if (EPI == EPI_RELU_BITS) {   // sign words of this lane's 2 x 8 output pixels (tiles 4q..4q+3)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int oy = 2 * tr + a;
+          const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * H + min(oy, H - 1)) * W, (oy < H) ? W * 4 : 0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mw[a][i] = __builtin_amdgcn_raw_buffer_load_b32(ms, (x0 + 8 * q4 + i) * 4, 0, 0);
+        }
+      }
+
+      f32x4v acc[16][2];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int g = st >> 2, u = st & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- work for later stages (independent of this stage's MFMAs) ----
+        if (st == 2) patch_read(tr, 1, dp);
+        if (st == 6) patch_read(tr + 1, 0, dp);
+        if (st == 3 || st == 7) xstage(dp, wq);
+        if (st + 1 < 8) {
+          uread((st + 1) >> 2, (st + 1) & 3, uq[(st + 1) & 1]);
+          ystage((st + 1) & 3, wq, vq[(st + 1) & 1]);
+        } else {
+          uread(0, 0, uq[0]);
+          ystage(0, wq, vq[0]);
+        }
+        if (st == 4) {      // rows 2tr+3, 2tr+4 replace rows 2tr-1, 2tr in the ring
+          store_row<32, 1, true>(ring + ((2 * tr + 4) & 3) * C::SLOTB, spill, lane, pre[0]);
+          store_row<32, 1, true>(ring + ((2 * tr + 5) & 3) * C::SLOTB, spill, lane, pre[1]);
+        }
+        // ---- this stage's 32 MFMAs ----
+        const f32x4(&vv)[4] = vq[st & 1];
+        const f32x4(&uu)[4][2] = uq[st & 1];
+        const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)      // the first MFMA of an accumulator takes a literal zero: no register clears
+              acc[u * 4 + v][hf] = DD_MFMA16(vv[v][j], uu[v][hf][j], (g == 0 && j == 0) ? zero : acc[u * 4 + v][hf]);
+        // interleave: one MFMA, then a few of the other instructions, 32 times
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      if (DBG == 1) {   // timing experiment: no output transform / stores (one store keeps the accumulators alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) sacc += acc[p][0][0] + acc[p][1][3];
+        if (sacc == 12345.678f) y[lane] = sacc;
+        continue;
+      }
+      // output transform + epilogue: lane = channel t16 (+16 per half), register r = tile 4q + r
+      unsigned keep[2][8];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep[a][i] = 0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int oy = 2 * tr + a;
+        const long opix = (long)(b * H + min(oy, H - 1)) * W;
+        const __amdgpu_buffer_rsrc_t ys = rsrc(y + opix * 32, (oy < H) ? W * 128 : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int opx = x0 + 2 * (4 * q4 + r) + e;
+            float o[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              float z[4];      // z[u] = x-direction output transform of position row u
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float m0 = acc[u * 4 + 0][hf][r], m1 = acc[u * 4 + 1][hf][r], m2 = acc[u * 4 + 2][hf][r], m3 = acc[u * 4 + 3][hf][r];
+                z[u] = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+              }
+              float v = a == 0 ? (z[0] + z[1]) + z[2] : (z[1] - z[2]) - z[3];
+              if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v + (hf ? bv1 : bv0), 0.f);
+              if (EPI == EPI_RELU_BITS) v = ((mw[a][2 * r + e] >> (t16 + 16 * hf)) & 1u) ? v : 0.f;
+              o[hf] = v;
+              bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
+            }
+            if (EPI == EPI_BIAS_RELU_BITS) {
+              const unsigned long long b0 = __ballot(o[0] > 0.f), b1 = __ballot(o[1] > 0.f);
+              const int G = (lane & 31) >> 3;
+              keep[a][2 * r + e] = (unsigned)((b0 >> (16 * G)) & 0xffffull) | ((unsigned)((b1 >> (16 * G)) & 0xffffull) << 16);
+            }
+          }
+        }
+        if (EPI == EPI_BIAS_RELU_BITS) {
+          const int P = lane & 31, sel = P & 7;
+          unsigned word = keep[a][0];
+#pragma unroll
+          for (int i = 1; i < 8; ++i) word = (sel == i) ? keep[a][i] : word;
+          const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + opix, (oy < H) ? W * 4 : 0);
+          __builtin_amdgcn_raw_buffer_store_b32(word, bs, (lane < 32) ? (x0 + P) * 4 : -16, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// U image for conv_wino2_fwd: packed[((((4u+v)*2 + half)*2 + g)*64 + lane)*4 + j] = (G Weff G^T)[u][v] of
+// Weff[co = (lane&15) + 16*half][ci = 8*(lane>>4) + 4g + j]; kind as conv_wino_pack_kernel.
+__global__ void conv_wino2_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int kind) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= WINO2_UFLOATS) return;
+  const int j = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 1, hf = (idx >> 9) & 1, pos = idx >> 10;
+  const int u = pos >> 2, v = pos & 3;
+  const int co = (lane & 15) + 16 * hf, ci = 8 * (lane >> 4) + 4 * g + j;
+  float t[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      t[ky][kx] = kind == 0 ? w[((long)co * 32 + ci) * 9 + ky * 3 + kx] : w[((long)ci * 32 + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+  float rowt[3];      // x-direction transform of each tap row
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    if (v == 0) rowt[ky] = t[ky][0];
+    else if (v == 1) rowt[ky] = 0.5f * ((t[ky][0] + t[ky][1]) + t[ky][2]);
+    else if (v == 2) rowt[ky] = 0.5f * ((t[ky][0] - t[ky][1]) + t[ky][2]);
+    else rowt[ky] = t[ky][2];
+  }
+  float out;
+  if (u == 0) out = rowt[0];
+  else if (u == 1) out = 0.5f * ((rowt[0] + rowt[1]) + rowt[2]);
+  else if (u == 2) out = 0.5f * ((rowt[0] - rowt[1]) + rowt[2]);
+  else out = rowt[2];
+  p[idx] = out;
+}
+
 // Weight gradient of the same layer by F(3,2) along x (the transpose of the algorithm above): per tile of two
 // adjacent output pixels the three taps' products  dW_k += g_j * x_{j+k}  (j = 0,1; k = 0..2) are
 //   dW_k = A^T[k][:] . ( (G g) * (B^T d) ),   G g = (g0, (g0+g1)/2, (g0-g1)/2, g1),   B^T d = (d0-d2, d1+d2, d2-d1, d3-d1)
@@ -1053,6 +1305,32 @@ int launch_fwd(const float* x, const float* wp, const float* bias, const float* 
 }
 
 template <int EPI>
+int launch_wino2(const float* x, const float* up, const float* bias, const unsigned* bits_in, float* y, unsigned* bits_out,
+                 const dd_conv_desc* d, hipStream_t st) {
+  using C = StripCfg<32, 1>;
+  constexpr int WPB = 4;
+  const int nstrips = (d->width + 31) / 32;
+  const size_t lds = (size_t)WINO2_UFLOATS * 4 + (size_t)WPB * (4 * C::SLOTB + C::SPILLB);
+  const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
+  static const int dbg = getenv("DD_W2_DBG") ? atoi(getenv("DD_W2_DBG")) : 0;
+  if (dbg == 2) {
+    auto k = conv_wino2_fwd<EPI, WPB, 2>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
+  } else if (dbg == 1) {
+    auto k = conv_wino2_fwd<EPI, WPB, 1>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
+  } else {
+    auto k = conv_wino2_fwd<EPI, WPB>;
+    if (int rc = allow_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
+  }
+  DD_LAUNCH_CHECK("conv_wino2_fwd");
+  return 0;
+}
+
+template <int EPI>
 int launch_wino(const float* x, const float* up, const float* bias, const unsigned* bits_in, float* y, unsigned* bits_out,
                 const dd_conv_desc* d, hipStream_t st) {
   using C = StripCfg<32, 1>;
@@ -1290,6 +1568,38 @@ int dd_conv_wino_pack(const float* w_oihw, float* packed, const dd_conv_desc* d,
   hipLaunchKernelGGL(conv_wino_pack_kernel, dim3((WINO_UFLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, kind);
   DD_LAUNCH_CHECK("conv_wino_pack");
   return 0;
+}
+
+int64_t dd_conv_wino2_packed_floats(const dd_conv_desc* d) {
+  if (check_desc(d)) return -1;
+  if (d->cin_real != 32 || d->stride != 1) return -1;
+  return WINO2_UFLOATS;
+}
+
+int dd_conv_wino2_pack(const float* w_oihw, float* packed, const dd_conv_desc* d, int32_t kind, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(w_oihw && packed, DD_ERR_BAD_ARG, "conv_wino2_pack: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  DD_REQUIRE(kind == 0 || kind == 1, DD_ERR_BAD_ARG, "conv_wino2_pack: kind %d (0 forward, 1 data gradient)", kind);
+  hipLaunchKernelGGL(conv_wino2_pack_kernel, dim3((WINO2_UFLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, kind);
+  DD_LAUNCH_CHECK("conv_wino2_pack");
+  return 0;
+}
+
+int dd_conv_wino2_fwd_relu_bits(const float* x, const float* packed, const float* bias, float* y, uint32_t* relu_bits,
+                                const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && packed && bias && y && relu_bits, DD_ERR_BAD_ARG, "conv_wino2_fwd_relu_bits: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  return launch_wino2<EPI_BIAS_RELU_BITS>(x, packed, bias, nullptr, y, relu_bits, d, (hipStream_t)stream);
+}
+
+int dd_conv_wino2_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
+                                  const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(dy && packed && relu_bits && dx, DD_ERR_BAD_ARG, "conv_wino2_dgrad_relu_bits: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  return launch_wino2<EPI_RELU_BITS>(dy, packed, nullptr, relu_bits, dx, nullptr, d, (hipStream_t)stream);
 }
 
 int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d) {

@@ -185,6 +185,7 @@ def conv_fwd_bits(x, packed, bias, desc):
 # arithmetic.  On by default for c2's forward and data gradient inside EncoderConvStack; the direct kernels stay
 # available (set ops.WINOGRAD = False) and are what the kernel-level entry points above call.
 WINOGRAD = True
+WINOGRAD_2D = True      # forward / data gradient of c2 by F(2x2,3x3) instead of F(2,3) along x (16 instead of 24 multiplies per tile)
 
 
 def conv_wino_pack(weight, desc, kind):
@@ -214,6 +215,36 @@ def conv_wino_dgrad_bits(dy, packed, bits, desc):
     dx = torch.empty((desc.batch, desc.height, desc.width, 32), device=dy.device, dtype=torch.float32)
     check(_lib.lib().dd_conv_wino_dgrad_relu_bits(_p(dy), _p(packed), _p(bits), _p(dx), C.byref(desc), _stream()),
           "dd_conv_wino_dgrad_relu_bits")
+    return dx
+
+
+def conv_wino2_pack(weight, desc, kind):
+    _dev(weight, "weight", (32, 32, 3, 3))
+    n = _lib.lib().dd_conv_wino2_packed_floats(C.byref(desc))
+    if n <= 0:
+        raise _lib.HotpathError(f"conv_wino2_pack: {_lib.lib().dd_last_error().decode()}")
+    packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_wino2_pack(_p(weight), _p(packed), C.byref(desc), kind, _stream()), "dd_conv_wino2_pack")
+    return packed
+
+
+def conv_wino2_fwd_bits(x, packed, bias, desc):
+    _dev(x, "x", (desc.batch, desc.height, desc.width, 32))
+    _dev(bias, "bias", (32,))
+    y = torch.empty((desc.batch, desc.height, desc.width, 32), device=x.device, dtype=torch.float32)
+    bits = torch.empty((desc.batch, desc.height, desc.width), device=x.device, dtype=torch.int32)
+    check(_lib.lib().dd_conv_wino2_fwd_relu_bits(_p(x), _p(packed), _p(bias), _p(y), _p(bits), C.byref(desc), _stream()),
+          "dd_conv_wino2_fwd_relu_bits")
+    return y, bits
+
+
+def conv_wino2_dgrad_bits(dy, packed, bits, desc):
+    _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
+    if not (bits.is_cuda and bits.dtype == torch.int32 and bits.is_contiguous() and tuple(bits.shape) == (desc.batch, desc.height, desc.width)):
+        raise _lib.HotpathError("conv_wino2_dgrad_bits: relu_bits must be a contiguous int32 [B,H,W] device tensor")
+    dx = torch.empty((desc.batch, desc.height, desc.width, 32), device=dy.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_wino2_dgrad_relu_bits(_p(dy), _p(packed), _p(bits), _p(dx), C.byref(desc), _stream()),
+          "dd_conv_wino2_dgrad_relu_bits")
     return dx
 
 
@@ -321,7 +352,9 @@ class EncoderConvStack(torch.autograd.Function):
         d3 = conv_desc(b, h, w, 32, 2, rows_per_task)
         # c1 / c2 also emit their ReLU signs as bit planes (60 MB instead of 1.9 GB to re-read in the backward)
         a1, s1 = conv_fwd_bits(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
-        if WINOGRAD:
+        if WINOGRAD and WINOGRAD_2D:
+            a2, s2 = conv_wino2_fwd_bits(a1, conv_wino2_pack(w2, d2, 0), b2, d2)
+        elif WINOGRAD:
             a2, s2 = conv_wino_fwd_bits(a1, conv_wino_pack(w2, d2, 0), b2, d2)
         else:
             a2, s2 = conv_fwd_bits(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
@@ -362,7 +395,9 @@ class EncoderConvStack(torch.autograd.Function):
             if need[3] or need[4]:
                 dw2, db2 = conv_wino_wgrad(a1, g2, d2) if WINOGRAD else conv_wgrad(a1, g2, d2)
             if need[1] or need[2]:
-                if WINOGRAD:
+                if WINOGRAD and WINOGRAD_2D:
+                    g1 = conv_wino2_dgrad_bits(g2, conv_wino2_pack(w2, d2, 1), s1, d2)
+                elif WINOGRAD:
                     g1 = conv_wino_dgrad_bits(g2, conv_wino_pack(w2, d2, 1), s1, d2)
                 else:
                     g1 = conv_dgrad_bits(g2, conv_pack(w2, d2, PACK_DGRAD_S1), s1, d2)

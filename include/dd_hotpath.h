@@ -319,6 +319,14 @@ int dd_conv_wino_fwd_relu_bits(const float* x, const float* packed, const float*
                                const dd_conv_desc* d, void* stream);
 int dd_conv_wino_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
                                  const dd_conv_desc* d, void* stream);
+/* The 2-D form F(2x2,3x3) of the forward and data gradient: 16 multiplies per 2x2 output tile instead of 36 (one wave
+ * per SIMD: four ring rows and 64 KB of transformed weights per workgroup).  Same contract as the 1-D entry points. */
+int64_t dd_conv_wino2_packed_floats(const dd_conv_desc* d);
+int dd_conv_wino2_pack(const float* w_oihw, float* packed, const dd_conv_desc* d, int32_t kind, void* stream);
+int dd_conv_wino2_fwd_relu_bits(const float* x, const float* packed, const float* bias, float* y, uint32_t* relu_bits,
+                                const dd_conv_desc* d, void* stream);
+int dd_conv_wino2_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
+                                  const dd_conv_desc* d, void* stream);
 /* weight + bias gradient of the same layer by F(3,2) along x (as dd_conv_wgrad: deterministic two-stage reduction) */
 int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d);
 int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,

@@ -121,6 +121,12 @@ def test_conv_winograd_fwd_dgrad_wgrad(dev, b, h, w, rows):
     mbits = torch.where(mbits >= 2 ** 31, mbits - 2 ** 32, mbits).to(torch.int32).to(dev)
     dx = ops.conv_wino_dgrad_bits(nhwc(gy.float()).to(dev), ops.conv_wino_pack(wd, desc, 1), mbits, desc)
     assert rel_err(dx.permute(0, 3, 1, 2), x.grad * (xm > 0)) < KERNEL_TOL
+    # the 2-D form F(2x2,3x3): same contract
+    y2, bits2 = ops.conv_wino2_fwd_bits(x_nhwc, ops.conv_wino2_pack(wd, desc, 0), bd, desc)
+    assert rel_err(y2.permute(0, 3, 1, 2), y_ref) < KERNEL_TOL
+    assert torch.equal(bits2.long() & 0xFFFFFFFF, ((y2 > 0).long() << torch.arange(32, device=dev)).sum(-1))
+    dx2 = ops.conv_wino2_dgrad_bits(nhwc(gy.float()).to(dev), ops.conv_wino2_pack(wd, desc, 1), mbits, desc)
+    assert rel_err(dx2.permute(0, 3, 1, 2), x.grad * (xm > 0)) < KERNEL_TOL
     wt64 = wt.clone().requires_grad_(True)
     bias64 = bias.clone().requires_grad_(True)
     F.conv2d(x.detach(), wt64, bias64, padding=1).backward(gy)
