@@ -782,7 +782,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr int WINO2_UFLOATS = 16 * 2 * 2 * 64 * 4;      // [pos = 4u+v][half][chunk][lane][4]
 
-template <int EPI, int WPB, int DBG = 0>   // EPI_BIAS_RELU_BITS (forward) or EPI_RELU_BITS (data gradient)
+template <int EPI, int WPB>   // EPI_BIAS_RELU_BITS (forward) or EPI_RELU_BITS (data gradient)
 __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restrict__ x, const float* __restrict__ up,
                                                            const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
                                                            float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
@@ -934,13 +934,6 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
         __builtin_amdgcn_sched_barrier(0);
       }
 
-      if (DBG == 1) {   // timing experiment: no output transform / stores (one store keeps the accumulators alive)
-        float sacc = 0.f;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) sacc += acc[p][0][0] + acc[p][1][3];
-        if (sacc == 12345.678f) y[lane] = sacc;
-        continue;
-      }
       // output transform + epilogue: lane = channel t16 (+16 per half), register r = tile 4q + r
       unsigned keep[2][8];
 #pragma unroll
@@ -1312,20 +1305,9 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
   const int nstrips = (d->width + 31) / 32;
   const size_t lds = (size_t)WINO2_UFLOATS * 4 + (size_t)WPB * (4 * C::SLOTB + C::SPILLB);
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
-  static const int dbg = getenv("DD_W2_DBG") ? atoi(getenv("DD_W2_DBG")) : 0;
-  if (dbg == 2) {
-    auto k = conv_wino2_fwd<EPI, WPB, 2>;
-    if (int rc = allow_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
-  } else if (dbg == 1) {
-    auto k = conv_wino2_fwd<EPI, WPB, 1>;
-    if (int rc = allow_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
-  } else {
-    auto k = conv_wino2_fwd<EPI, WPB>;
-    if (int rc = allow_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
-  }
+  auto k = conv_wino2_fwd<EPI, WPB>;
+  if (int rc = allow_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
   DD_LAUNCH_CHECK("conv_wino2_fwd");
   return 0;
 }
