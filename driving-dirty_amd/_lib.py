@@ -97,6 +97,8 @@ SIGNATURES = {
     "dd_conv_wino2_pack": (_i32, [_p, _p, _p, _i32, _p]),
     "dd_conv_wino2_fwd_relu_bits": (_i32, [_p, _p, _p, _p, _p, _p, _p]),
     "dd_conv_wino2_dgrad_relu_bits": (_i32, [_p, _p, _p, _p, _p, _p]),
+    "dd_conv_wino2_wgrad_workspace_bytes": (_i64, [_p]),
+    "dd_conv_wino2_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "dd_conv_wino_wgrad_workspace_bytes": (_i64, [_p]),
     "dd_conv_wino_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "dd_stitch6_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _p]),

@@ -1171,6 +1171,217 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_wgrad(const float* __restr
   bpart[(long)gw * 64 + lane] = bsum;
 }
 
+// Weight gradient by the 2-D form F(3x3, 2x2): per 2x2 tile of dy and its 4x4 input patch
+//   S[u][v] += (G g G^T)[u][v] (x) (B^T d B)[u][v],    dW = A^T S A   (A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]),
+// 16 accumulators of 32x32 over K = tiles: 128 MFMAs per 2 output rows x 32 pixels instead of 192 (1-D) or 288 (direct).
+// A = transformed dy tile (lane = output channel, four 4-byte loads per tile straight from HBM), B = transformed patch
+// (lane = input channel, sixteen ds_read_b32 per tile from a plain 4-slot ring), k-step = the tile pair (2s, 2s+1) on
+// the two half-waves.  One wave per SIMD (256 accumulator registers): the operands of tile s+1 are transformed into
+// their own registers while tile s's 16 MFMAs execute, its patch reads are issued a tile earlier still.
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ part, float* __restrict__ bpart, int B,
+                                                             int H, int W, int nstrips) {
+  using C = StripCfg<32, 1>;
+  constexpr int RINGB = 4 * C::SLOTB + C::SPILLB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ring = smem + wave * RINGB;
+  char* spill = ring + 4 * C::SLOTB;
+  const int h = lane >> 5, n = lane & 31;
+  const int gw = blockIdx.x * WPB + wave;
+  const int HT = (H + 1) / 2;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  float bsum = 0.f;
+
+  long idx, end;
+  wave_range((long)B * nstrips * HT, gw, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / HT;
+    const int r0 = (int)(idx - col * HT);
+    const int r1 = (int)min((long)HT, r0 + (end - idx));
+    idx += r1 - r0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const float* xb = x + (long)b * H * W * 32;
+    const float* dyb = dy + (long)b * H * W * 32;
+    const int gx0 = x0 - 1;
+    const int aoff = ((x0 + 2 * h) * 32 + n) * 4;   // tile 2s+h = pixels x0 + 4s + 2h, +1: + 512 bytes per s, + 128 for the odd pixel
+
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {      // input rows 2*r0 - 1 .. 2*r0 + 2; slot of row iy = (iy + 1) & 3
+      f32x4 t[C::NLOAD];
+      const int iy = 2 * r0 - 1 + d;
+      load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
+      store_row<32, 1, false>(ring + ((iy + 1) & 3) * C::SLOTB, spill, lane, t);
+    }
+    // dy rows 2tr, 2tr+1 of the strip: g[a][e][s]
+    auto load_dy = [&](int tr, float (&g)[2][2][8]) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int oy = 2 * tr + a;
+        const bool ok = (tr < r1) && (oy < H);       // rows past the range belong to the next wave: read zeros
+        const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? oy : 0) * W * 32, ok ? W * 128 : 0);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          g[a][0][s8] = bload1(as, aoff + s8 * 512);
+          g[a][1][s8] = bload1(as, aoff + s8 * 512 + 128);
+        }
+      }
+    };
+    float gc[2][2][8];
+    load_dy(r0, gc);
+
+    for (int tr = r0; tr < r1; ++tr) {
+      f32x4 pre[2][C::NLOAD];
+      load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
+      load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
+      float gn[2][2][8];
+      load_dy(tr + 1, gn);
+      __builtin_amdgcn_sched_barrier(0);
+
+      const char* rb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rb[r] = ring + ((2 * tr + r) & 3) * C::SLOTB + n * 4;      // slot of input row 2*tr - 1 + r
+      float dq[2][4][4];          // patches of tile s+1 / s+2 (reads in flight)
+      float aq[2][16], bq[2][16];   // transformed operands of tile s / s+1
+      auto rd = [&](int s8, float (&d)[4][4]) {
+        const int poff = (2 * (2 * s8 + h)) * 128;      // ring pixel 2t of tile t = 2s + h
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[r][c] = *(const float*)(rb[r] + poff + c * 128);
+      };
+      auto tf = [&](int s8, const float (&d)[4][4], float (&av)[16], float (&bv)[16]) {
+        float w[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          w[r][0] = d[r][0] - d[r][2];
+          w[r][1] = d[r][1] + d[r][2];
+          w[r][2] = d[r][2] - d[r][1];
+          w[r][3] = d[r][3] - d[r][1];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bv[0 * 4 + c] = w[0][c] - w[2][c];
+          bv[1 * 4 + c] = w[1][c] + w[2][c];
+          bv[2 * 4 + c] = w[2][c] - w[1][c];
+          bv[3 * 4 + c] = w[3][c] - w[1][c];
+        }
+        float gr[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float g0 = gc[a][0][s8], g1 = gc[a][1][s8];
+          gr[a][0] = g0;
+          gr[a][1] = 0.5f * (g0 + g1);
+          gr[a][2] = 0.5f * (g0 - g1);
+          gr[a][3] = g1;
+          bsum += g0 + g1;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          av[0 * 4 + v] = gr[0][v];
+          av[1 * 4 + v] = 0.5f * (gr[0][v] + gr[1][v]);
+          av[2 * 4 + v] = 0.5f * (gr[0][v] - gr[1][v]);
+          av[3 * 4 + v] = gr[1][v];
+        }
+      };
+      rd(0, dq[0]);
+      rd(1, dq[1]);
+      tf(0, dq[0], aq[0], bq[0]);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        if (s8 + 2 < 8) rd(s8 + 2, dq[s8 & 1]);                      // dq[s8&1] held tile s8: already transformed
+        if (s8 + 1 < 8) tf(s8 + 1, dq[(s8 + 1) & 1], aq[(s8 + 1) & 1], bq[(s8 + 1) & 1]);
+        if (s8 == 6) {      // every patch read of this tile-row is out (tile 7's was issued at s8 = 5): the new rows may land
+          store_row<32, 1, false>(ring + ((2 * tr + 4) & 3) * C::SLOTB, spill, lane, pre[0]);
+          store_row<32, 1, false>(ring + ((2 * tr + 5) & 3) * C::SLOTB, spill, lane, pre[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc[p] = DD_MFMA(aq[s8 & 1][p], bq[s8 & 1][p], acc[p]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) gc[a][e][s8] = gn[a][e][s8];
+    }
+  }
+
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(((long)gw * 16 + p) * 16 + r) * 64 + lane] = acc[p][r];
+  bpart[(long)gw * 64 + lane] = bsum;
+}
+
+// Second stage of conv_wino2_wgrad: fixed-order sums of S[u][v] per (register row r) block, output transform A^T S A,
+// scatter to OIHW.  Block 16 reduces the bias partials.
+__global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
+                                                                float* __restrict__ dw, float* __restrict__ db, int nw) {
+  constexpr int G = 16;
+  __shared__ float red[16][G][64];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = blockIdx.x;   // accumulator register row, or 16 for the bias
+  if (r == 16) {
+    float s0 = 0.f;
+    for (int w = g; w < nw; w += G) s0 += bpart[(long)w * 64 + l];
+    red[0][g][l] = s0;
+    __syncthreads();
+    if (g != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) s += red[0][i][l];
+    const float other = __shfl_xor(s, 32);
+    if (l < 32) db[l] = s + other;
+    return;
+  }
+  float s[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) s[p] = 0.f;
+  for (int w = g; w < nw; w += G) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s[p] += part[(((long)w * 16 + p) * 16 + r) * 64 + l];
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) red[p][g][l] = s[p];
+  __syncthreads();
+  if (g != 0) return;
+  float t[4][4];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) v += red[p][i][l];
+    t[p >> 2][p & 3] = v;
+  }
+  // rows: z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
+  float z[3][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    z[0][v] = (t[0][v] + t[1][v]) + t[2][v];
+    z[1][v] = t[1][v] - t[2][v];
+    z[2][v] = (t[1][v] + t[2][v]) + t[3][v];
+  }
+  const int o = dd_acc_row(r, l), j = l & 31;
+  float* out = dw + ((long)o * 32 + j) * 9;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    out[ky * 3 + 0] = (z[ky][0] + z[ky][1]) + z[ky][2];
+    out[ky * 3 + 1] = z[ky][1] - z[ky][2];
+    out[ky * 3 + 2] = (z[ky][1] + z[ky][2]) + z[ky][3];
+  }
+}
+
 // Second stage: fixed-order sums of the per-wave partials S_p (one block per (ky, register) row), then the output
 // transform and the scatter to OIHW.  Block 48 reduces the bias partials.
 __global__ __launch_bounds__(1024) void conv_wino_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
@@ -1588,6 +1799,36 @@ int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d) {
   if (check_desc(d)) return -1;
   if (d->cin_real != 32 || d->stride != 1) return -1;
   return (int64_t)4 * DD_NUM_CU * ((int64_t)12 * 1024 + 64) * 4;      // one 4-wave workgroup per CU, 12 accumulators per wave
+}
+
+int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d) {
+  if (check_desc(d)) return -1;
+  if (d->cin_real != 32 || d->stride != 1) return -1;
+  return (int64_t)4 * DD_NUM_CU * ((int64_t)16 * 1024 + 64) * 4;      // one 4-wave workgroup per CU, 16 accumulators per wave
+}
+
+int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,
+                        const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(x && dy && dw_oihw && dbias && workspace, DD_ERR_BAD_ARG, "conv_wino2_wgrad: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  DD_REQUIRE(workspace_bytes >= dd_conv_wino2_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wino2_wgrad: workspace %ld < %ld bytes",
+             (long)workspace_bytes, (long)dd_conv_wino2_wgrad_workspace_bytes(d));
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int WPB = 4;
+  const int nstrips = (d->width + 31) / 32;
+  const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
+  const int nw = grid * WPB;
+  float* part = (float*)workspace;
+  float* bpart = part + (size_t)nw * 16 * 1024;
+  auto k = conv_wino2_wgrad<WPB>;
+  const size_t lds = (size_t)WPB * (4 * StripCfg<32, 1>::SLOTB + StripCfg<32, 1>::SPILLB);
+  if (int rc = allow_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
+  DD_LAUNCH_CHECK("conv_wino2_wgrad");
+  hipLaunchKernelGGL(conv_wino2_wgrad_reduce, dim3(17), dim3(1024), 0, st, part, bpart, dw_oihw, dbias, nw);
+  DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce");
+  return 0;
 }
 
 int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,

@@ -248,6 +248,19 @@ def conv_wino2_dgrad_bits(dy, packed, bits, desc):
     return dx
 
 
+def conv_wino2_wgrad(x, dy, desc):
+    _dev(x, "x", (desc.batch, desc.height, desc.width, 32))
+    _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
+    nbytes = _lib.lib().dd_conv_wino2_wgrad_workspace_bytes(C.byref(desc))
+    if nbytes <= 0:
+        raise _lib.HotpathError(f"conv_wino2_wgrad: {_lib.lib().dd_last_error().decode()}")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    dw = torch.empty((32, 32, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty(32, device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_wino2_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, C.byref(desc), _stream()), "dd_conv_wino2_wgrad")
+    return dw, db
+
+
 def conv_wino_wgrad(x, dy, desc):
     _dev(x, "x", (desc.batch, desc.height, desc.width, 32))
     _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
@@ -393,7 +406,12 @@ class EncoderConvStack(torch.autograd.Function):
             for hook in MFMA_PHASE_HOOKS:
                 hook()
             if need[3] or need[4]:
-                dw2, db2 = conv_wino_wgrad(a1, g2, d2) if WINOGRAD else conv_wgrad(a1, g2, d2)
+                if WINOGRAD and WINOGRAD_2D:
+                    dw2, db2 = conv_wino2_wgrad(a1, g2, d2)
+                elif WINOGRAD:
+                    dw2, db2 = conv_wino_wgrad(a1, g2, d2)
+                else:
+                    dw2, db2 = conv_wgrad(a1, g2, d2)
             if need[1] or need[2]:
                 if WINOGRAD and WINOGRAD_2D:
                     g1 = conv_wino2_dgrad_bits(g2, conv_wino2_pack(w2, d2, 1), s1, d2)

@@ -327,6 +327,10 @@ int dd_conv_wino2_fwd_relu_bits(const float* x, const float* packed, const float
                                 const dd_conv_desc* d, void* stream);
 int dd_conv_wino2_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
                                   const dd_conv_desc* d, void* stream);
+/* ... and of the weight gradient: F(3x3,2x2), 16 accumulators S[u][v] over tiles, dW = A^T S A in the reduce kernel */
+int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d);
+int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
+                        int64_t workspace_bytes, const dd_conv_desc* d, void* stream);
 /* weight + bias gradient of the same layer by F(3,2) along x (as dd_conv_wgrad: deterministic two-stage reduction) */
 int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d);
 int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,

@@ -133,6 +133,9 @@ def test_conv_winograd_fwd_dgrad_wgrad(dev, b, h, w, rows):
     dw, db = ops.conv_wino_wgrad(x_nhwc, nhwc(gy.float()).to(dev), desc)
     assert rel_err(dw, wt64.grad) < KERNEL_TOL
     assert rel_err(db, bias64.grad) < KERNEL_TOL
+    dw2, db2 = ops.conv_wino2_wgrad(x_nhwc, nhwc(gy.float()).to(dev), desc)
+    assert rel_err(dw2, wt64.grad) < KERNEL_TOL
+    assert rel_err(db2, bias64.grad) < KERNEL_TOL
     with pytest.raises(_lib.HotpathError):
         ops.conv_wino_pack(wd, ops.conv_desc(b, h, w, 32, 2), 0)           # stride 2 has no Winograd path
 
