@@ -1235,14 +1235,13 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
         }
       }
     };
-    float gc[2][2][8];
-    load_dy(r0, gc);
+    float ga[2][2][8], gb[2][2][8];      // dy of the current / next tile-row, alternating (no register moves)
+    load_dy(r0, ga);
 
-    for (int tr = r0; tr < r1; ++tr) {
+    auto step = [&](int tr, const float (&gc)[2][2][8], float (&gn)[2][2][8]) {
       f32x4 pre[2][C::NLOAD];
       load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
       load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
-      float gn[2][2][8];
       load_dy(tr + 1, gn);
       __builtin_amdgcn_sched_barrier(0);
 
@@ -1280,9 +1279,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
           const float g0 = gc[a][0][s8], g1 = gc[a][1][s8];
           gr[a][0] = g0;
           gr[a][1] = 0.5f * (g0 + g1);
-          gr[a][2] = 0.5f * (g0 - g1);
+          gr[a][2] = g0 - gr[a][1];                 // = (g0 - g1) / 2 exactly: x - (x+y)/2 has no rounding of its own beyond the first
           gr[a][3] = g1;
-          bsum += g0 + g1;
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -1291,6 +1289,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
           av[2 * 4 + v] = 0.5f * (gr[0][v] - gr[1][v]);
           av[3 * 4 + v] = gr[1][v];
         }
+        bsum += 4.f * av[5];                        // (1,1) position = (g00 + g01 + g10 + g11) / 4: the tile's bias contribution
       };
       rd(0, dq[0]);
       rd(1, dq[1]);
@@ -1308,13 +1307,13 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
         for (int p = 0; p < 16; ++p) acc[p] = DD_MFMA(aq[s8 & 1][p], bq[s8 & 1][p], acc[p]);
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) gc[a][e][s8] = gn[a][e][s8];
-    }
+    };
+    int tr = r0;
+    do {      // pairs of tile-rows; a trailing odd one sees zero dy (no contribution)
+      step(tr, ga, gb);
+      step(tr + 1, gb, ga);
+      tr += 2;
+    } while (tr < r1);
   }
 
 #pragma unroll
