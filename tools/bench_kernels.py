@@ -63,6 +63,9 @@ def main():
         ("c3_dgrad", lambda: ops.conv_dgrad_bits(g3, ops.conv_pack(w2, d3, 2), bits, d3), 2 * pxo * 32 * 288, pxo * 128 + px * 132),
         ("c1_wgrad", lambda: ops.conv_wgrad(x4, g, d1), 2 * px * 32 * 27, px * (16 + 128)),
         ("c2_wgrad", lambda: ops.conv_wgrad(a1, g, d2), 2 * px * 32 * 288, px * 256),
+        ("c2_wino2_fwd", lambda: ops.conv_wino2_fwd_bits(a1, ops.conv_wino2_pack(w2, d2, 0), bias, d2), 2 * px * 32 * 288, px * 260),
+        ("c2_wino2_dgrad", lambda: ops.conv_wino2_dgrad_bits(g, ops.conv_wino2_pack(w2, d2, 1), bits, d2), 2 * px * 32 * 288, px * 260),
+        ("c2_wino2_wgrad", lambda: ops.conv_wino2_wgrad(a1, g, d2), 2 * px * 32 * 288, px * 256),
         ("c2_wino_fwd", lambda: ops.conv_wino_fwd_bits(a1, ops.conv_wino_pack(w2, d2, 0), bias, d2), 2 * px * 32 * 288, px * 260),
         ("c2_wino_wgrad", lambda: ops.conv_wino_wgrad(a1, g, d2), 2 * px * 32 * 288, px * 256),
         ("c2_wino_dgrad", lambda: ops.conv_wino_dgrad_bits(g, ops.conv_wino_pack(w2, d2, 1), bits, d2), 2 * px * 32 * 288, px * 260),

@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-KERNEL = "conv_wino_fwd<5, 8"                # c2 forward (Winograd F(2,3), bias+ReLU+sign bits, 8 waves)
+KERNEL = "conv_wino2_fwd<5, 4"               # c2 forward (Winograd F(2x2,3x3), bias+ReLU+sign bits, 4 waves)
 
 
 def per_launch(directory, counter):
@@ -32,7 +32,7 @@ def main():
     res = {"kernel": KERNEL, "batch": 32, "fetch_bytes": 2.0 * fetch, "write_bytes": write,
            "hbm_bytes_per_launch": 2.0 * fetch + write, "algorithmic_bytes": algorithmic,
            "launches": [n1, n2], "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); WRITE_SIZE exact",
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/bench_kernels.py --only c2_wino_fwd"}
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/bench_kernels.py --only c2_wino2_fwd"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
