@@ -1323,48 +1323,57 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
   bpart[(long)gw * 64 + lane] = bsum;
 }
 
-// Second stage of conv_wino2_wgrad: fixed-order sums of S[u][v] per (register row r) block, output transform A^T S A,
-// scatter to OIHW.  Block 16 reduces the bias partials.
-__global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
-                                                                float* __restrict__ dw, float* __restrict__ db, int nw) {
+// Second stage of conv_wino2_wgrad, in two launches (one block per accumulator row would leave 17 blocks to read 64 MB):
+//  a) 256 blocks, one per (position p, register row r): fixed-order sum over the waves' partials -> tsum[p][r][64]
+//  b) one block per register row r (+ one for the bias): output transform A^T S A, scatter to OIHW.
+__global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_a(const float* __restrict__ part, float* __restrict__ tsum, int nw) {
   constexpr int G = 16;
-  __shared__ float red[16][G][64];
+  __shared__ float red[G][64];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int row = blockIdx.x;      // p * 16 + r
+  const float* src = part + (long)row * 64 + l;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = g;
+  for (; w + 3 * G < nw; w += 4 * G) {
+    s0 += src[(long)w * 16384];
+    s1 += src[(long)(w + G) * 16384];
+    s2 += src[(long)(w + 2 * G) * 16384];
+    s3 += src[(long)(w + 3 * G) * 16384];
+  }
+  for (; w < nw; w += G) s0 += src[(long)w * 16384];
+  red[g][l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < G; ++i) s += red[i][l];
+  tsum[(long)row * 64 + l] = s;
+}
+
+__global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
+                                                                  float* __restrict__ dw, float* __restrict__ db, int nw) {
+  constexpr int G = 16;
+  __shared__ float red[G][64];
   const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = blockIdx.x;   // accumulator register row, or 16 for the bias
   if (r == 16) {
     float s0 = 0.f;
     for (int w = g; w < nw; w += G) s0 += bpart[(long)w * 64 + l];
-    red[0][g][l] = s0;
+    red[g][l] = s0;
     __syncthreads();
     if (g != 0) return;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < G; ++i) s += red[0][i][l];
+    for (int i = 0; i < G; ++i) s += red[i][l];
     const float other = __shfl_xor(s, 32);
     if (l < 32) db[l] = s + other;
     return;
   }
-  float s[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p) s[p] = 0.f;
-  for (int w = g; w < nw; w += G) {
-#pragma unroll
-    for (int p = 0; p < 16; ++p) s[p] += part[(((long)w * 16 + p) * 16 + r) * 64 + l];
-  }
-#pragma unroll
-  for (int p = 0; p < 16; ++p) red[p][g][l] = s[p];
-  __syncthreads();
   if (g != 0) return;
   float t[4][4];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < G; ++i) v += red[p][i][l];
-    t[p >> 2][p & 3] = v;
-  }
-  // rows: z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
-  float z[3][4];
+  for (int p = 0; p < 16; ++p) t[p >> 2][p & 3] = tsum[((long)p * 16 + r) * 64 + l];
+  float z[3][4];      // z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     z[0][v] = (t[0][v] + t[1][v]) + t[2][v];
@@ -1803,7 +1812,7 @@ int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d) {
 int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d) {
   if (check_desc(d)) return -1;
   if (d->cin_real != 32 || d->stride != 1) return -1;
-  return (int64_t)4 * DD_NUM_CU * ((int64_t)16 * 1024 + 64) * 4;      // one 4-wave workgroup per CU, 16 accumulators per wave
+  return ((int64_t)4 * DD_NUM_CU * ((int64_t)16 * 1024 + 64) + 16 * 1024) * 4;      // per-wave partials (16 accumulators) + their sums
 }
 
 int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,
@@ -1820,13 +1829,16 @@ int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* 
   const int nw = grid * WPB;
   float* part = (float*)workspace;
   float* bpart = part + (size_t)nw * 16 * 1024;
+  float* tsum = bpart + (size_t)nw * 64;
   auto k = conv_wino2_wgrad<WPB>;
   const size_t lds = (size_t)WPB * (4 * StripCfg<32, 1>::SLOTB + StripCfg<32, 1>::SPILLB);
   if (int rc = allow_lds(k, lds)) return rc;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
   DD_LAUNCH_CHECK("conv_wino2_wgrad");
-  hipLaunchKernelGGL(conv_wino2_wgrad_reduce, dim3(17), dim3(1024), 0, st, part, bpart, dw_oihw, dbias, nw);
-  DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce");
+  hipLaunchKernelGGL(conv_wino2_wgrad_reduce_a, dim3(256), dim3(1024), 0, st, part, tsum, nw);
+  DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce_a");
+  hipLaunchKernelGGL(conv_wino2_wgrad_reduce_b, dim3(17), dim3(1024), 0, st, tsum, bpart, dw_oihw, dbias, nw);
+  DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce_b");
   return 0;
 }
 
