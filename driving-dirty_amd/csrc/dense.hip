@@ -4,6 +4,8 @@
 //                       (roadmap_bce_v2.py:81,106)
 //   dd_mse              mean squared error fwd + bwd (autoencoder.py:91, roadmap_pretrain_ae.py:100)
 //   dd_adam_step        torch.optim.Adam over one flat buffer (autoencoder.py:119-120)
+#include <stdlib.h>
+
 #include "dd_common.h"
 
 namespace {
@@ -384,7 +386,11 @@ int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   DD_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, DD_ERR_BAD_ARG, "adam: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)DD_NUM_CU * 8);
+  // Persistent blocks, but only a few per CU: this pass usually runs BESIDE the backward (optim.HipAdam.overlap_with_backward),
+  // and 8 long-running blocks per CU would hold every wave slot -- the backward's small kernels (reductions, packs) then
+  // wait for an Adam block to finish its whole share (measured: 5 us kernels taking 300-700 us).
+  static const int per_cu = getenv("DD_ADAM_BLOCKS_PER_CU") ? max(1, atoi(getenv("DD_ADAM_BLOCKS_PER_CU"))) : 4;      // measured 1 / 2 / 3 / 4 / 6 / 8: 9.51 / 9.20 / 9.04 / 9.05 / 9.44 / 9.49 ms per step
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)DD_NUM_CU * per_cu);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
                      eps, (float)bc1, (float)sqrt(bc2), grad_scale);
   DD_LAUNCH_CHECK("adam");
