@@ -129,12 +129,19 @@ class EncoderConvStackBf16(torch.autograd.Function):
         a1, s1 = conv_fwd(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
         a2, s2 = conv_fwd(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
         a3, _ = conv_fwd(a2, conv_pack(w3, d3, PACK_FWD), b3, d3, want_bits=False)
-        ctx.save_for_backward(x4, a1, a2, a3, w2, w3, s1, s2)
+        # the backward's operand images are packed here (see ops.EncoderConvStack.forward)
+        need = ctx.needs_input_grad
+        p2d = p3d = torch.empty(0, device=x4.device, dtype=torch.bfloat16)
+        if need[1] or need[2] or need[3] or need[4]:
+            p3d = conv_pack(w3, d3, PACK_DGRAD_S2)
+        if need[1] or need[2]:
+            p2d = conv_pack(w2, d2, PACK_DGRAD_S1)
+        ctx.save_for_backward(x4, a1, a2, a3, p2d, p3d, s1, s2)
         return pool4_fwd(a3)
 
     @staticmethod
     def backward(ctx, grad_pooled):
-        x4, a1, a2, a3, w2, w3, s1, s2 = ctx.saved_tensors
+        x4, a1, a2, a3, p2d, p3d, s1, s2 = ctx.saved_tensors
         b, h, w, _ = x4.shape
         d1, d2, d3 = conv_desc(b, h, w, 3, 1), conv_desc(b, h, w, 32, 1), conv_desc(b, h, w, 32, 2)
         g3 = pool4_relu_bwd(grad_pooled.contiguous(), a3)
@@ -142,14 +149,14 @@ class EncoderConvStackBf16(torch.autograd.Function):
         dw3, db3 = conv_wgrad(a2, g3, d3) if (need[5] or need[6]) else (None, None)
         dw2 = db2 = dw1 = db1 = None
         if need[1] or need[2] or need[3] or need[4]:
-            g2 = conv_dgrad(g3, conv_pack(w3, d3, PACK_DGRAD_S2), s2, d3)
+            g2 = conv_dgrad(g3, p3d, s2, d3)
             del g3
             for hook in ops.MFMA_PHASE_HOOKS:
                 hook()
             if need[3] or need[4]:
                 dw2, db2 = conv_wgrad(a1, g2, d2)
             if need[1] or need[2]:
-                g1 = conv_dgrad(g2, conv_pack(w2, d2, PACK_DGRAD_S1), s1, d2)
+                g1 = conv_dgrad(g2, p2d, s1, d2)
                 del g2
                 dw1, db1 = conv_wgrad(x4, g1, d1)
         return None, dw1, db1, dw2, db2, dw3, db3
