@@ -487,3 +487,34 @@ def test_layout_round_trip(dev, b, c, cs, h, w):
     if cs > c:
         assert float(y[..., c:].abs().max()) == 0.0
     assert torch.equal(ops.nhwc_to_nchw(y, c), x)
+
+
+def test_encoder_conv_stack_modes_agree(dev):
+    """The encoder conv stack with c2 on the direct kernels, on Winograd F(2,3) along x and on F(2x2,3x3): same pooled
+    feature and the same six parameter gradients up to summation order."""
+    from driving_dirty_amd import ops
+    b, h, w = 2, 18, 70
+    x4 = hu((b, h, w, 4), "modes_x", 0.0, 1.0)
+    x4[..., 3] = 0
+    x4 = x4.to(dev)
+    ws = [hu((32, 3, 3, 3), "mw1", -0.3, 0.3), hu((32,), "mb1", -0.1, 0.1), hu((32, 32, 3, 3), "mw2", -0.1, 0.1), hu((32,), "mb2", -0.1, 0.1),
+          hu((32, 32, 3, 3), "mw3", -0.1, 0.1), hu((32,), "mb3", -0.1, 0.1)]
+    gp = None
+    results = []
+    saved = (ops.WINOGRAD, ops.WINOGRAD_2D)
+    try:
+        for wino, wino2 in ((False, False), (True, False), (True, True)):
+            ops.WINOGRAD, ops.WINOGRAD_2D = wino, wino2
+            params = [t.clone().to(dev).requires_grad_(True) for t in ws]
+            pooled = ops.EncoderConvStack.apply(x4, *params, 1, 0)
+            if gp is None:
+                gp = hu(tuple(pooled.shape), "modes_g").to(dev)
+            pooled.backward(gp)
+            results.append((pooled.detach(), [p.grad for p in params]))
+    finally:
+        ops.WINOGRAD, ops.WINOGRAD_2D = saved
+    ref_p, ref_g = results[0]
+    for pooled, grads in results[1:]:
+        assert rel_err(pooled, ref_p.double()) < 1e-5
+        for g, r in zip(grads, ref_g):
+            assert rel_err(g, r.double()) < 1e-4
