@@ -804,6 +804,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
   const f32x4* ul = (const f32x4*)smem;
   const int t16 = lane & 15, q4 = lane >> 4;
   const float bv0 = (EPI == EPI_BIAS_RELU_BITS) ? bias[t16] : 0.f, bv1 = (EPI == EPI_BIAS_RELU_BITS) ? bias[16 + t16] : 0.f;
+  const f32x4v bias0 = {bv0, bv0, bv0, bv0}, bias1 = {bv1, bv1, bv1, bv1};
   const int HT = (H + 1) / 2;                         // tile rows
 
   long idx, end;
@@ -921,8 +922,12 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
 #pragma unroll
           for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf)      // the first MFMA of an accumulator takes a literal zero: no register clears
-              acc[u * 4 + v][hf] = DD_MFMA16(vv[v][j], uu[v][hf][j], (g == 0 && j == 0) ? zero : acc[u * 4 + v][hf]);
+            for (int hf = 0; hf < 2; ++hf) {
+              // the first MFMA of an accumulator takes a literal zero (no register clears) -- or, at position (1,1), the
+              // bias: A^T e11 A = all ones, so a constant in M[1][1] reaches all four outputs of the tile once
+              const f32x4v init = (EPI == EPI_BIAS_RELU_BITS && u == 1 && v == 1) ? (hf ? bias1 : bias0) : zero;
+              acc[u * 4 + v][hf] = DD_MFMA16(vv[v][j], uu[v][hf][j], (g == 0 && j == 0) ? init : acc[u * 4 + v][hf]);
+            }
         // interleave: one MFMA, then a few of the other instructions, 32 times
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -960,7 +965,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
                 z[u] = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
               }
               float v = a == 0 ? (z[0] + z[1]) + z[2] : (z[1] - z[2]) - z[3];
-              if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v + (hf ? bv1 : bv0), 0.f);
+              if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v, 0.f);      // the bias came in through the accumulator
               if (EPI == EPI_RELU_BITS) v = ((mw[a][2 * r + e] >> (t16 + 16 * hf)) & 1u) ? v : 0.f;
               o[hf] = v;
               bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
