@@ -619,6 +619,22 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define DD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 constexpr int WINO_UFLOATS = 3 * 4 * 2 * 2 * 64 * 4;      // [ky][pos][half][chunk][lane][4]
 
+// Packed fp32 add / subtract on 4-channel vectors: the fp32 matrix and vector instructions share the ALUs, so every VALU
+// instruction beside the MFMAs costs matrix time; v_pk_add_f32 does two lanes' worth per issue.  (hipcc selects it for
+// a 2-vector add but splits a subtract into scalars, hence the explicit form with the negate modifiers.)
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
+  const f32x2p lo = f32x2p{a.x, a.y} + f32x2p{b.x, b.y}, hi = f32x2p{a.z, a.w} + f32x2p{b.z, b.w};
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b) {
+  f32x2p lo, hi;
+  const f32x2p alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 template <int EPI, int WPB>   // EPI_BIAS_RELU_BITS (forward) or EPI_RELU_BITS (data gradient)
 __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restrict__ x, const float* __restrict__ up,
                                                           const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
@@ -699,10 +715,10 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_fwd(const float* __restric
       // MFMA never waits for a VALU result, a VALU write never waits for an MFMA that has not read its operand yet
       f32x4 vbuf[2][4];
       auto tf = [&](const f32x4 (&d)[4], f32x4 (&v)[4]) {
-        v[0] = d[0] - d[2];
-        v[1] = d[1] + d[2];
-        v[2] = d[2] - d[1];
-        v[3] = d[1] - d[3];
+        v[0] = pk_sub4(d[0], d[2]);
+        v[1] = pk_add4(d[1], d[2]);
+        v[2] = pk_sub4(d[2], d[1]);
+        v[3] = pk_sub4(d[1], d[3]);
       };
       rd(0, dbuf[0], ubuf[0]);
       tf(dbuf[0], vbuf[0]);
@@ -848,19 +864,19 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
     auto xstage = [&](const f32x4 (&d)[4][4], f32x4 (&w)[4][4]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        w[r][0] = d[r][0] - d[r][2];
-        w[r][1] = d[r][1] + d[r][2];
-        w[r][2] = d[r][2] - d[r][1];
-        w[r][3] = d[r][1] - d[r][3];
+        w[r][0] = pk_sub4(d[r][0], d[r][2]);
+        w[r][1] = pk_add4(d[r][1], d[r][2]);
+        w[r][2] = pk_sub4(d[r][2], d[r][1]);
+        w[r][3] = pk_sub4(d[r][1], d[r][3]);
       }
     };
     auto ystage = [&](int u, const f32x4 (&w)[4][4], f32x4 (&v)[4]) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (u == 0) v[c] = w[0][c] - w[2][c];
-        else if (u == 1) v[c] = w[1][c] + w[2][c];
-        else if (u == 2) v[c] = w[2][c] - w[1][c];
-        else v[c] = w[1][c] - w[3][c];
+        if (u == 0) v[c] = pk_sub4(w[0][c], w[2][c]);
+        else if (u == 1) v[c] = pk_add4(w[1][c], w[2][c]);
+        else if (u == 2) v[c] = pk_sub4(w[2][c], w[1][c]);
+        else v[c] = pk_sub4(w[1][c], w[3][c]);
       }
     };
     auto uread = [&](int g, int u, f32x4 (&uu)[4][2]) {
