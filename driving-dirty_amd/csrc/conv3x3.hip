@@ -623,6 +623,11 @@ constexpr int WINO_UFLOATS = 3 * 4 * 2 * 2 * 64 * 4;      // [ky][pos][half][chu
 // instruction beside the MFMAs costs matrix time; v_pk_add_f32 does two lanes' worth per issue.  (hipcc selects it for
 // a 2-vector add but splits a subtract into scalars, hence the explicit form with the negate modifiers.)
 typedef float f32x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2p pk_sub2(f32x2p a, f32x2p b) {
+  f32x2p r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
   const f32x2p lo = f32x2p{a.x, a.y} + f32x2p{b.x, b.y}, hi = f32x2p{a.z, a.w} + f32x2p{b.z, b.w};
   return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -1243,7 +1248,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
       store_row<32, 1, false>(ring + ((iy + 1) & 3) * C::SLOTB, spill, lane, t);
     }
     // dy rows 2tr, 2tr+1 of the strip: g[a][e][s]
-    auto load_dy = [&](int tr, float (&g)[2][2][8]) {
+    auto load_dy = [&](int tr, f32x2p (&g)[2][8]) {      // g[e][s] = (row 2tr, row 2tr+1) of the tile's column e
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int oy = 2 * tr + a;
@@ -1251,15 +1256,15 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
         const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? oy : 0) * W * 32, ok ? W * 128 : 0);
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
-          g[a][0][s8] = bload1(as, aoff + s8 * 512);
-          g[a][1][s8] = bload1(as, aoff + s8 * 512 + 128);
+          g[0][s8][a] = bload1(as, aoff + s8 * 512);
+          g[1][s8][a] = bload1(as, aoff + s8 * 512 + 128);
         }
       }
     };
-    float ga[2][2][8], gb[2][2][8];      // dy of the current / next tile-row, alternating (no register moves)
+    f32x2p ga[2][8], gb[2][8];      // dy of the current / next tile-row, alternating (no register moves)
     load_dy(r0, ga);
 
-    auto step = [&](int tr, const float (&gc)[2][2][8], float (&gn)[2][2][8]) {
+    auto step = [&](int tr, const f32x2p (&gc)[2][8], f32x2p (&gn)[2][8]) {
       f32x4 pre[2][C::NLOAD];
       load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
       load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
@@ -1279,38 +1284,38 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
           for (int c = 0; c < 4; ++c) d[r][c] = *(const float*)(rb[r] + poff + c * 128);
       };
       auto tf = [&](int s8, const float (&d)[4][4], float (&av)[16], float (&bv)[16]) {
-        float w[4][4];
+        // packed fp32 throughout (the vector ALUs are the matrix ALUs: every instruction here is matrix time lost).
+        // x stage on register pairs (c0,c1) / (c2,c3) with a broadcast operand, y stage pairwise over c.
+        f32x2p wl[4], wh[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          w[r][0] = d[r][0] - d[r][2];
-          w[r][1] = d[r][1] + d[r][2];
-          w[r][2] = d[r][2] - d[r][1];
-          w[r][3] = d[r][3] - d[r][1];
+          const f32x2p lo = {d[r][0], d[r][1]}, hi = {d[r][2], d[r][3]};
+          asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(wl[r]) : "v"(lo), "v"(hi));                // d0 - d2, d1 + d2
+          asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(wh[r]) : "v"(hi), "v"(lo));  // d2 - d1, d3 - d1
         }
+        const f32x2p bl[4] = {pk_sub2(wl[0], wl[2]), wl[1] + wl[2], pk_sub2(wl[2], wl[1]), pk_sub2(wl[3], wl[1])};
+        const f32x2p bh[4] = {pk_sub2(wh[0], wh[2]), wh[1] + wh[2], pk_sub2(wh[2], wh[1]), pk_sub2(wh[3], wh[1])};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bv[0 * 4 + c] = w[0][c] - w[2][c];
-          bv[1 * 4 + c] = w[1][c] + w[2][c];
-          bv[2 * 4 + c] = w[2][c] - w[1][c];
-          bv[3 * 4 + c] = w[3][c] - w[1][c];
+        for (int u = 0; u < 4; ++u) {
+          bv[u * 4 + 0] = bl[u].x;
+          bv[u * 4 + 1] = bl[u].y;
+          bv[u * 4 + 2] = bh[u].x;
+          bv[u * 4 + 3] = bh[u].y;
         }
-        float gr[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const float g0 = gc[a][0][s8], g1 = gc[a][1][s8];
-          gr[a][0] = g0;
-          gr[a][1] = 0.5f * (g0 + g1);
-          gr[a][2] = g0 - gr[a][1];                 // = (g0 - g1) / 2 exactly: x - (x+y)/2 has no rounding of its own beyond the first
-          gr[a][3] = g1;
-        }
+        // dy tile (pairs over the tile's two rows), WITHOUT the halves of G = [[1,0],[.5,.5],[.5,-.5],[0,1]]: position
+        // (u,v) carries the factor (1,2,2,1)[u] * (1,2,2,1)[v], taken out again (exactly) in conv_wino2_wgrad_reduce_b.
+        const f32x2p g0 = gc[0][s8], g1 = gc[1][s8];
+        const f32x2p gr[4] = {g0, g0 + g1, pk_sub2(g0, g1), g1};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          av[0 * 4 + v] = gr[0][v];
-          av[1 * 4 + v] = 0.5f * (gr[0][v] + gr[1][v]);
-          av[2 * 4 + v] = 0.5f * (gr[0][v] - gr[1][v]);
-          av[3 * 4 + v] = gr[1][v];
+          f32x2p sd;      // (row0 + row1, row0 - row1)
+          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(sd) : "v"(gr[v]));
+          av[0 * 4 + v] = gr[v].x;
+          av[1 * 4 + v] = sd.x;
+          av[2 * 4 + v] = sd.y;
+          av[3 * 4 + v] = gr[v].y;
         }
-        bsum += 4.f * av[5];                        // (1,1) position = (g00 + g01 + g10 + g11) / 4: the tile's bias contribution
+        bsum += av[5];                              // (1,1) position = g00 + g01 + g10 + g11: the tile's bias contribution
       };
       rd(0, dq[0]);
       rd(1, dq[1]);
@@ -1393,7 +1398,8 @@ __global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_b(const float* _
   if (g != 0) return;
   float t[4][4];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) t[p >> 2][p & 3] = tsum[((long)p * 16 + r) * 64 + l];
+  for (int p = 0; p < 16; ++p)      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
+    t[p >> 2][p & 3] = tsum[((long)p * 16 + r) * 64 + l] * (((p >> 2) == 1 || (p >> 2) == 2) ? 0.5f : 1.f) * (((p & 3) == 1 || (p & 3) == 2) ? 0.5f : 1.f);
   float z[3][4];      // z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
