@@ -1350,30 +1350,30 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
 }
 
 // Second stage of conv_wino2_wgrad, in two launches (one block per accumulator row would leave 17 blocks to read 64 MB):
-//  a) 256 blocks, one per (position p, register row r): fixed-order sum over the waves' partials -> tsum[p][r][64]
-//  b) one block per register row r (+ one for the bias): output transform A^T S A, scatter to OIHW.
+//  a) 256 blocks = (position p, chunk c of the waves): fixed-order sum over the chunk's partials.  A wave's partial of
+//     one position is 16 rows x 64 lanes = 4 KB contiguous, read as 256 float4 (the first version read one 256-byte
+//     row per wave, 64 KB apart: 0.57 TB/s) -> tsum[c][p][r][64]
+//  b) one block per register row r (+ one for the bias): sum of the 16 chunks, output transform A^T S A, scatter to OIHW.
+constexpr int W2R_CHUNKS = 16;
 __global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_a(const float* __restrict__ part, float* __restrict__ tsum, int nw) {
-  constexpr int G = 16;
-  __shared__ float red[G][64];
-  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int row = blockIdx.x;      // p * 16 + r
-  const float* src = part + (long)row * 64 + l;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int w = g;
-  for (; w + 3 * G < nw; w += 4 * G) {
-    s0 += src[(long)w * 16384];
-    s1 += src[(long)(w + G) * 16384];
-    s2 += src[(long)(w + 2 * G) * 16384];
-    s3 += src[(long)(w + 3 * G) * 16384];
+  __shared__ f32x4 red[4][256];
+  const int f = threadIdx.x & 255, sub = threadIdx.x >> 8;
+  const int p = blockIdx.x & 15, c = blockIdx.x >> 4;
+  const int per = (nw + W2R_CHUNKS - 1) / W2R_CHUNKS;
+  const int w0 = c * per, w1 = min(nw, w0 + per);
+  const f32x4* src = (const f32x4*)part + (long)p * 256 + f;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  int w = w0 + sub;
+  for (; w + 4 < w1; w += 8) {
+    const f32x4 a0 = src[(long)w * 4096], a1 = src[(long)(w + 4) * 4096];
+    s0 += a0;
+    s1 += a1;
   }
-  for (; w < nw; w += G) s0 += src[(long)w * 16384];
-  red[g][l] = (s0 + s1) + (s2 + s3);
+  if (w < w1) s0 += src[(long)w * 4096];
+  red[sub][f] = s0 + s1;
   __syncthreads();
-  if (g != 0) return;
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < G; ++i) s += red[i][l];
-  tsum[(long)row * 64 + l] = s;
+  if (sub != 0) return;
+  ((f32x4*)tsum)[((long)c * 16 + p) * 256 + f] = (red[0][f] + red[1][f]) + (red[2][f] + red[3][f]);
 }
 
 __global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
@@ -1399,7 +1399,12 @@ __global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_b(const float* _
   float t[4][4];
 #pragma unroll
   for (int p = 0; p < 16; ++p)      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
-    t[p >> 2][p & 3] = tsum[((long)p * 16 + r) * 64 + l] * (((p >> 2) == 1 || (p >> 2) == 2) ? 0.5f : 1.f) * (((p & 3) == 1 || (p & 3) == 2) ? 0.5f : 1.f);
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < W2R_CHUNKS; ++c) v += tsum[(((long)c * 16 + p) * 16 + r) * 64 + l];
+    t[p >> 2][p & 3] = v * (((p >> 2) == 1 || (p >> 2) == 2) ? 0.5f : 1.f) * (((p & 3) == 1 || (p & 3) == 2) ? 0.5f : 1.f);
+  }
   float z[3][4];      // z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
@@ -1839,7 +1844,7 @@ int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d) {
 int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d) {
   if (check_desc(d)) return -1;
   if (d->cin_real != 32 || d->stride != 1) return -1;
-  return ((int64_t)4 * DD_NUM_CU * ((int64_t)16 * 1024 + 64) + 16 * 1024) * 4;      // per-wave partials (16 accumulators) + their sums
+  return ((int64_t)4 * DD_NUM_CU * ((int64_t)16 * 1024 + 64) + 16 * 16 * 1024) * 4;      // per-wave partials (16 accumulators) + 16 chunk sums
 }
 
 int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,
