@@ -27,6 +27,11 @@ class GConvDesc(C.Structure):
                                     "ostride_w", "ooff_h", "ooff_w")]
 
 
+class AdamTensor(C.Structure):
+    """struct dd_adam_tensor"""
+    _fields_ = [("p", _p), ("g", _p), ("m", _p), ("v", _p), ("n", _i64)]
+
+
 _DP = C.POINTER(ConvDesc)
 _GP = C.POINTER(GConvDesc)
 
@@ -113,6 +118,7 @@ SIGNATURES = {
     "dd_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
     "dd_bf16_to_f32": (_i32, [_p, _p, _i64, _p]),
     "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
+    "dd_adam_step_multi": (_i32, [C.POINTER(AdamTensor), _i32, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 
 _lib = None

@@ -619,6 +619,19 @@ def sigmoid_and_loss(logits, target):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+def adam_step_multi(tensors, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """One launch for a list of small (p, g, m, v) quadruples that share ``step`` (dd_adam_step_multi)."""
+    if not tensors:
+        return
+    table = (_lib.AdamTensor * len(tensors))()
+    for i, quad in enumerate(tensors):
+        for name, t in zip("pgmv", quad):
+            _dev(t, name, quad[0].shape)
+        table[i] = _lib.AdamTensor(_p(quad[0]), _p(quad[1]), _p(quad[2]), _p(quad[3]), quad[0].numel())
+    check(_lib.lib().dd_adam_step_multi(table, len(tensors), lr, beta1, beta2, eps, int(step), grad_scale, _stream()),
+          "dd_adam_step_multi")
+
+
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _dev(t, name, p.shape)

@@ -4,6 +4,8 @@ executed by ``dd_adam_step``, one fused read-modify-write pass per parameter ten
 ``grad_scale`` folds the 1/world_size of data-parallel gradient averaging into the same pass, so the
 all-reduced SUM never needs a separate divide kernel.
 """
+import os
+
 import torch
 
 from . import ops
@@ -19,12 +21,18 @@ class HipAdam(torch.optim.Optimizer):
         self._scale = 1.0
         self._sync = None
 
-    def _update(self, p, group, grad_scale):
+    SMALL_NUMEL = int(os.environ.get("DD_ADAM_MULTI_NUMEL", 1 << 16))      # tensors up to this size go into one multi-tensor launch (0: never)
+
+    def _state_of(self, p):
         st = self.state[p]
         if not st:
             st["step"] = 0
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
+    def _update(self, p, group, grad_scale):
+        st = self._state_of(p)
         st["step"] += 1
         b1, b2 = group["betas"]
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -74,10 +82,20 @@ class HipAdam(torch.optim.Optimizer):
         if self._side is not None:
             self._flush_pending()                 # backward never reached an MFMA phase hook (other models)
         for group in self.param_groups:
+            small = {}                            # step count -> [(p, g, m, v)]: one launch for all the small tensors
             for p in group["params"]:
                 if p.grad is None or p in self._early:
                     continue
-                self._update(p, group, grad_scale)
+                if p.numel() > self.SMALL_NUMEL or not p.grad.is_contiguous() or not p.data.is_contiguous():
+                    self._update(p, group, grad_scale)
+                    continue
+                st = self._state_of(p)
+                st["step"] += 1
+                small.setdefault(st["step"], []).append((p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1),
+                                                          st["exp_avg_sq"].view(-1)))
+            b1, b2 = group["betas"]
+            for step, quads in small.items():
+                ops.adam_step_multi(quads, group["lr"], b1, b2, group["eps"], step, grad_scale)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._early.clear()

@@ -308,6 +308,18 @@ int dd_threat_score(const float* a, const float* b, float* out, int64_t n, int32
  * no amsgrad) over one flat fp32 buffer: p, g, m, v of n elements; step >= 1. */
 int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, void* stream);
+/* The same update for `count` tensors in one launch (the model's many small parameters: biases, BatchNorm vectors,
+ * 3x3 filters -- torch.optim.Adam loops over them, roadmap_bce_v2.py:154-157).  `tensors` is a HOST array; all share
+ * `step`.  Meant for tensors of up to a few thousand elements (one element per thread). */
+typedef struct dd_adam_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} dd_adam_tensor;
+int dd_adam_step_multi(const dd_adam_tensor* tensors, int32_t count, float lr, float beta1, float beta2, float eps,
+                       int32_t step, float grad_scale, void* stream);
 
 /* ---- Winograd F(2,3) along x for the 32 -> 32 stride-1 layer (c2, components.py:20): the same outputs as
  * dd_conv_fwd_relu_bits / dd_conv_dgrad_relu_bits from 2/3 of the multiplies (4 per output-pixel pair and tap row

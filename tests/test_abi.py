@@ -57,6 +57,7 @@ def test_host_side_validation_without_a_gpu():
     assert lib.dd_stitch6(None, None, None, None, 1, 4, 4, -1, None) == 2
     assert lib.dd_linear_fwd(None, None, None, None, 4, 8, 6, None, 0, None) != 0          # K % 4 != 0 -> unsupported first
     assert lib.dd_adam_step(None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == 2
+    assert lib.dd_adam_step_multi(None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == 2
     # the Python shims refuse CPU tensors loudly: there is no CPU fallback
     with pytest.raises(_lib.HotpathError):
         ops.pool4_fwd(torch.zeros(1, 4, 4, 32))

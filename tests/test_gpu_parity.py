@@ -290,6 +290,26 @@ def test_adam_matches_torch(dev):
     assert rel_err(p, p_ref) < 1e-6
 
 
+def test_adam_multi_tensor_matches_torch(dev):
+    """dd_adam_step_multi: the model's small tensors in one launch (ragged sizes, more tensors than one table holds)."""
+    from driving_dirty_amd import ops
+    sizes = [1, 3, 32, 255, 256, 257, 864, 4097] + [7 + i for i in range(50)]
+    ps = [hu((n,), f"p{i}") for i, n in enumerate(sizes)]
+    gs = [hu((n,), f"g{i}", -0.1, 0.1) for i, n in enumerate(sizes)]
+    refs = [p.clone().double().requires_grad_(True) for p in ps]
+    opt = torch.optim.Adam(refs, lr=1e-3)
+    quads = [(p.clone().to(dev), torch.empty(p.shape, device=dev), torch.zeros(p.shape, device=dev), torch.zeros(p.shape, device=dev))
+             for p in ps]
+    for step in range(1, 4):
+        for r, q, g in zip(refs, quads, gs):
+            r.grad = (g * step).double() * 0.5
+            q[1].copy_(g * step)
+        opt.step()
+        ops.adam_step_multi(quads, 1e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.5)
+    for r, q in zip(refs, quads):
+        assert rel_err(q[0], r) < 1e-6
+
+
 def _grad_floor(g, key):
     """A Linear bias in front of a train-mode BatchNorm has an exactly-zero gradient; in fp32 (the reference's
     own fp32 run included: 3.6e-5 in the fixture) it is rounding noise of the layer's gradient scale, so it is
