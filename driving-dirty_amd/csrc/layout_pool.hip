@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256) void layout_tile_kernel(const float* __restric
 
 // ---- pool, fast path: H*W % 4 == 0 and C % 4 == 0, so a window of 4 never leaves its channel plane.
 // thread = (quad of 4 consecutive flat pixels, group of 4 channels): 4 x 16-byte loads, 4 outputs.
+template <bool IDX>
 __global__ __launch_bounds__(256) void pool4_fwd_quad(const f32x4* __restrict__ feat, float* __restrict__ pooled,
-                                                      int B, long HW, int C) {
+                                                      unsigned short* __restrict__ idx, int B, long HW, int C) {
   const int groups = C / 4;
   const long quads = HW / 4;
   const long total = (long)B * quads * groups;
@@ -149,8 +150,53 @@ __global__ __launch_bounds__(256) void pool4_fwd_quad(const f32x4* __restrict__ 
     const f32x4* p = feat + ((b * HW + 4 * q) * groups + g);
     const f32x4 v0 = p[0], v1 = p[groups], v2 = p[2 * groups], v3 = p[3 * groups];
     float* o = pooled + b * (quads * C) + q;
+    unsigned code = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[(long)(4 * g + k) * quads] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+    for (int k = 0; k < 4; ++k) {
+      if (!IDX) {
+        o[(long)(4 * g + k) * quads] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+      } else {      // the backward's routing decided here, 4 bits per window: first maximum (torch keeps the earliest) | (max > 0) << 2
+        float m = v0[k];
+        unsigned am = 0;
+        if (v1[k] > m) { m = v1[k]; am = 1; }
+        if (v2[k] > m) { m = v2[k]; am = 2; }
+        if (v3[k] > m) { m = v3[k]; am = 3; }
+        o[(long)(4 * g + k) * quads] = m;
+        code |= (am | (m > 0.f ? 4u : 0u)) << (4 * k);
+      }
+    }
+    if (IDX) idx[i] = (unsigned short)code;
+  }
+}
+
+// Backward from the routing codes of pool4_fwd_quad<true>: the 481 MB feature is not read again (15 MB of codes instead).
+__global__ __launch_bounds__(256) void pool4_bwd_idx_quad(const float* __restrict__ dpooled, const unsigned short* __restrict__ idx,
+                                                          f32x4* __restrict__ dfeat, int B, long HW, int C) {
+  const int groups = C / 4;
+  const long quads = HW / 4;
+  const long total = (long)B * quads * groups;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long q = (i / groups) % quads;
+    const long b = i / (groups * quads);
+    const long base = (b * HW + 4 * q) * groups + g;
+    const float* gp = dpooled + b * (quads * C) + q;
+    const unsigned code = idx[i];
+    f32x4 d0, d1, d2, d3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned c4 = (code >> (4 * k)) & 15u;
+      const float gv = (c4 & 4u) ? gp[(long)(4 * g + k) * quads] : 0.f;
+      const unsigned am = c4 & 3u;
+      d0[k] = am == 0 ? gv : 0.f;
+      d1[k] = am == 1 ? gv : 0.f;
+      d2[k] = am == 2 ? gv : 0.f;
+      d3[k] = am == 3 ? gv : 0.f;
+    }
+    dfeat[base] = d0;
+    dfeat[base + groups] = d1;
+    dfeat[base + 2 * groups] = d2;
+    dfeat[base + 3 * groups] = d3;
   }
 }
 
@@ -319,8 +365,8 @@ int dd_pool4_fwd(const float* feat, float* pooled, int32_t batch, int32_t h, int
   DD_REQUIRE(((long)c * HW) / 4 > 0, DD_ERR_UNSUPPORTED, "pool4_fwd: fewer than 4 elements");
   if (HW % 4 == 0 && c % 4 == 0) {
     const long total = (long)batch * (HW / 4) * (c / 4);
-    hipLaunchKernelGGL(pool4_fwd_quad, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat,
-                       pooled, batch, HW, c);
+    hipLaunchKernelGGL(pool4_fwd_quad<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat,
+                       pooled, (unsigned short*)nullptr, batch, HW, c);
   } else {
     const long total = (long)batch * (((long)c * HW) / 4);
     hipLaunchKernelGGL(pool4_fwd_any, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pooled, batch, HW,
@@ -344,6 +390,36 @@ int dd_pool4_relu_bwd(const float* dpooled, const float* feat, float* dfeat, int
                        batch, HW, c);
   }
   DD_LAUNCH_CHECK("pool4_bwd");
+  return 0;
+}
+
+int64_t dd_pool4_idx_elems(int32_t batch, int32_t h, int32_t w, int32_t c) {
+  const long HW = (long)h * w;
+  if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || HW % 4 != 0 || c % 4 != 0) {
+    dd_fail(DD_ERR_UNSUPPORTED, "pool4_idx: needs H*W %% 4 == 0 and C %% 4 == 0 (windows inside one channel plane), got %d x %d x %d", h, w, c);
+    return -1;
+  }
+  return (int64_t)batch * (HW / 4) * (c / 4);
+}
+
+int dd_pool4_fwd_idx(const float* feat, float* pooled, uint16_t* idx, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+  DD_REQUIRE(feat && pooled && idx, DD_ERR_BAD_ARG, "pool4_fwd_idx: NULL pointer");
+  const int64_t total = dd_pool4_idx_elems(batch, h, w, c);
+  if (total < 0) return DD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pool4_fwd_quad<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat, pooled,
+                     (unsigned short*)idx, batch, (long)h * w, c);
+  DD_LAUNCH_CHECK("pool4_fwd_idx");
+  return 0;
+}
+
+int dd_pool4_idx_relu_bwd(const float* dpooled, const uint16_t* idx, float* dfeat, int32_t batch, int32_t h, int32_t w, int32_t c,
+                          void* stream) {
+  DD_REQUIRE(dpooled && idx && dfeat, DD_ERR_BAD_ARG, "pool4_idx_bwd: NULL pointer");
+  const int64_t total = dd_pool4_idx_elems(batch, h, w, c);
+  if (total < 0) return DD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pool4_bwd_idx_quad, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dpooled, (const unsigned short*)idx,
+                     (f32x4*)dfeat, batch, (long)h * w, c);
+  DD_LAUNCH_CHECK("pool4_idx_bwd");
   return 0;
 }
 

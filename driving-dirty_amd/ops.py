@@ -330,6 +330,34 @@ def pool4_fwd(feat):
     return out
 
 
+def pool4_has_idx(h, w, c):
+    """The routing-code form needs windows that stay inside one channel plane."""
+    return (h * w) % 4 == 0 and c % 4 == 0
+
+
+def pool4_fwd_idx(feat):
+    """pooled, codes: max_pool1d(4) + the backward's routing (dd_pool4_fwd_idx)."""
+    b, h, w, c = feat.shape
+    _dev(feat, "feat")
+    n = _lib.lib().dd_pool4_idx_elems(b, h, w, c)
+    if n < 0:
+        raise _lib.HotpathError(_lib.lib().dd_last_error().decode())
+    out = torch.empty((b, (c * h * w) // 4), device=feat.device, dtype=torch.float32)
+    idx = torch.empty((n,), device=feat.device, dtype=torch.int16)
+    check(_lib.lib().dd_pool4_fwd_idx(_p(feat), _p(out), _p(idx), b, h, w, c, _stream()), "dd_pool4_fwd_idx")
+    return out, idx
+
+
+def pool4_idx_relu_bwd(dpooled, idx, shape):
+    b, h, w, c = shape
+    _dev(dpooled, "dpooled", (b, (c * h * w) // 4))
+    if idx.dtype != torch.int16 or not idx.is_cuda or idx.numel() != b * (h * w // 4) * (c // 4):
+        raise _lib.HotpathError(f"pool4_idx_relu_bwd: bad routing codes {tuple(idx.shape)} {idx.dtype}")
+    out = torch.empty(shape, device=dpooled.device, dtype=torch.float32)
+    check(_lib.lib().dd_pool4_idx_relu_bwd(_p(dpooled), _p(idx), _p(out), b, h, w, c, _stream()), "dd_pool4_idx_relu_bwd")
+    return out
+
+
 def pool4_relu_bwd(dpooled, feat):
     b, h, w, c = feat.shape
     _dev(dpooled, "dpooled", (b, (c * h * w) // 4))
@@ -386,10 +414,18 @@ class EncoderConvStack(torch.autograd.Function):
                 p2d = conv_wino_pack(w2, d2, 1)
             else:
                 p2d = conv_pack(w2, d2, PACK_DGRAD_S1)
-        ctx.save_for_backward(x4, a1, a2, a3, p2d, p3d, s1, s2)
         ctx.wino = (bool(WINOGRAD), bool(WINOGRAD and WINOGRAD_2D))
         ctx.pool = int(pool)                  # 0: conv feature, 1: pooled vector, 2: both (joint roadmap + box model)
         ctx.rows_per_task = rows_per_task
+        ctx.a3_shape = tuple(a3.shape)
+        if ctx.pool == 1 and pool4_has_idx(*a3.shape[1:]):
+            # the pool decides the backward's routing now (4 bits per window): the feature itself is not kept
+            pooled, codes = pool4_fwd_idx(a3)
+            ctx.save_for_backward(x4, a1, a2, codes, p2d, p3d, s1, s2)
+            ctx.codes = True
+            return pooled
+        ctx.codes = False
+        ctx.save_for_backward(x4, a1, a2, a3, p2d, p3d, s1, s2)
         if ctx.pool == 2:
             return a3, pool4_fwd(a3)
         if ctx.pool:
@@ -412,7 +448,10 @@ class EncoderConvStack(torch.autograd.Function):
             g3 = parts[0] if len(parts) == 1 else add(parts[0], parts[1])
         else:
             grad = grad.contiguous()
-            g3 = pool4_relu_bwd(grad, a3) if ctx.pool else relu_bwd(grad, a3)
+            if ctx.codes:
+                g3 = pool4_idx_relu_bwd(grad, a3, ctx.a3_shape)      # a3 holds the routing codes here
+            else:
+                g3 = pool4_relu_bwd(grad, a3) if ctx.pool else relu_bwd(grad, a3)
         need = ctx.needs_input_grad
         dw3, db3 = conv_wgrad(a2, g3, d3) if (need[5] or need[6]) else (None, None)
         dw2 = db2 = dw1 = db1 = None

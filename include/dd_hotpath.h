@@ -179,6 +179,15 @@ int dd_pool4_fwd(const float* feat, float* pooled, int32_t batch, int32_t h, int
                  void* stream);
 int dd_pool4_relu_bwd(const float* dpooled, const float* feat, float* dfeat, int32_t batch, int32_t h,
                       int32_t w, int32_t c, void* stream);
+/* The same pooling with the backward's routing decided in the forward: `idx` receives one uint16 per thread-quad
+ * (4 bits per window: index of the first maximum | (max > 0) << 2; dd_pool4_idx_elems of them, -1 when H*W or C
+ * is not a multiple of 4), and dd_pool4_idx_relu_bwd scatters dpooled from those codes alone -- the 481 MB c3
+ * feature (components.py:43) is neither kept for nor re-read by the backward. */
+int64_t dd_pool4_idx_elems(int32_t batch, int32_t h, int32_t w, int32_t c);
+int dd_pool4_fwd_idx(const float* feat, float* pooled, uint16_t* idx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                     void* stream);
+int dd_pool4_idx_relu_bwd(const float* dpooled, const uint16_t* idx, float* dfeat, int32_t batch, int32_t h, int32_t w,
+                          int32_t c, void* stream);
 
 /* ---- dense head pieces (K8, K9) ---------------------------------------------------------
  * BatchNorm1d (batch statistics when training != 0, else running statistics) -> ReLU ->

@@ -67,6 +67,9 @@ def test_full_size_pool_roundtrip(dev):
     assert int((dfeat != 0).sum()) == pooled.numel()
     # the maximum of every window, gathered back through the routing, reproduces the pooled values
     assert abs(dot(dfeat, feat) - dot(gp, pooled)) / dot(gp, pooled) < 1e-6
+    pooled2, codes = ops.pool4_fwd_idx(feat)             # the routing-code form the encoder stack uses
+    assert torch.equal(pooled2, pooled)
+    assert torch.equal(ops.pool4_idx_relu_bwd(gp, codes, tuple(feat.shape)), dfeat)
 
 
 def test_double_resolution_encoder_against_oracle(dev):

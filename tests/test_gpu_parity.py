@@ -182,6 +182,29 @@ def test_pool4_nchw_order(dev, b, c, h, w):
     assert torch.equal(dfeat.permute(0, 3, 1, 2).cpu(), feat.grad * (feat.detach() > 0))
 
 
+@pytest.mark.parametrize("b,c,h,w", [(2, 32, 8, 11), (2, 32, 16, 22), (1, 8, 2, 2)])
+def test_pool4_routing_codes(dev, b, c, h, w):
+    """dd_pool4_fwd_idx / dd_pool4_idx_relu_bwd: routing decided in the forward (ties -> first index, all-zero windows
+    -> no gradient), bit-identical to max_pool1d + its backward + the ReLU mask; shapes whose windows leave the channel
+    plane are refused."""
+    from driving_dirty_amd import _lib, ops
+    feat = torch.relu(hu((b, c, h, w), f"cfeat{h}{w}", -1.0, 1.0))
+    feat = (feat * 4).round() / 4                       # many ties and many all-zero windows
+    feat.requires_grad_(True)
+    ref = F.max_pool1d(feat.reshape(b, 1, -1), 4).squeeze(1)
+    gp = hu(tuple(ref.shape), f"cgp{h}{w}")
+    ref.backward(gp)
+    f_nhwc = nhwc(feat.detach()).to(dev)
+    out, codes = ops.pool4_fwd_idx(f_nhwc)
+    assert torch.equal(out.cpu(), ref.detach())
+    dfeat = ops.pool4_idx_relu_bwd(gp.to(dev), codes, tuple(f_nhwc.shape))
+    assert torch.equal(dfeat.permute(0, 3, 1, 2).cpu(), feat.grad * (feat.detach() > 0))
+    assert torch.equal(dfeat, ops.pool4_relu_bwd(gp.to(dev), f_nhwc))
+    assert not ops.pool4_has_idx(5, 7, 32)
+    with pytest.raises(_lib.HotpathError):
+        ops.pool4_fwd_idx(torch.zeros(1, 5, 7, 32, device=dev))
+
+
 @pytest.mark.parametrize("rows,feat,training,drop", [(3, 16, True, 0.0), (32, 128, True, 0.2), (5, 300, False, 0.2)])
 def test_bn_relu_dropout(dev, rows, feat, training, drop):
     from driving_dirty_amd import ops
