@@ -95,23 +95,52 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
-// out[e] = sum_s part[s][e] (+ bias[e % ncols]); fixed order -> deterministic
+// out[e] = sum_s part[s][e] (+ bias[e % ncols]); fixed order -> deterministic.
+// A block owns 8 consecutive elements; its 32 thread groups each sum the splits s = g, g + 32, ... (four independent
+// chains), LDS adds the groups in order.  (One thread per element walking all the splits alone was a pure latency
+// chain: 41 us for the head's 2048 x 1024 partials.)
 __global__ __launch_bounds__(256) void splits_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                             float* __restrict__ out, long elems, int nsplit, int ncols) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
+  __shared__ float red[32][8];
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const long e = (long)blockIdx.x * 8 + el;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
-  for (; s + 4 <= nsplit; s += 4) {
-    s0 += part[(long)(s + 0) * elems + e];
-    s1 += part[(long)(s + 1) * elems + e];
-    s2 += part[(long)(s + 2) * elems + e];
-    s3 += part[(long)(s + 3) * elems + e];
+  if (e < elems) {
+    int s = g;
+    for (; s + 96 < nsplit; s += 128) {
+      s0 += part[(long)(s + 0) * elems + e];
+      s1 += part[(long)(s + 32) * elems + e];
+      s2 += part[(long)(s + 64) * elems + e];
+      s3 += part[(long)(s + 96) * elems + e];
+    }
+    for (; s < nsplit; s += 32) s0 += part[(long)s * elems + e];
   }
-  for (; s < nsplit; ++s) s0 += part[(long)s * elems + e];
-  float v = (s0 + s1) + (s2 + s3);
+  red[g][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0 || e >= elems) return;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v += red[i][el];
   if (bias) v += bias[e % ncols];
   out[e] = v;
+}
+
+// The same for a handful of splits (one thread per element is then the better shape).
+__global__ __launch_bounds__(256) void splits_reduce_few_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                float* __restrict__ out, long elems, int nsplit, int ncols) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  float v = 0.f;
+  for (int s = 0; s < nsplit; ++s) v += part[(long)s * elems + e];
+  if (bias) v += bias[e % ncols];
+  out[e] = v;
+}
+
+static inline void launch_splits_reduce(const float* part, const float* bias, float* out, long elems, int nsplit, int ncols, hipStream_t st) {
+  if (nsplit >= 16)
+    hipLaunchKernelGGL(splits_reduce_kernel, dim3((unsigned)((elems + 7) / 8)), dim3(256), 0, st, part, bias, out, elems, nsplit, ncols);
+  else
+    hipLaunchKernelGGL(splits_reduce_few_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, part, bias, out, elems, nsplit, ncols);
 }
 
 // ---------------------------------------------------------------------------------------------- dgrad
@@ -377,8 +406,7 @@ int dd_linear_fwd(const float* x, const float* w, const float* bias, float* y, i
   DD_LAUNCH_CHECK("linear_fwd");
   if (nsplit > 1) {
     const long elems = (long)m * n;
-    hipLaunchKernelGGL(splits_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, part, bias, y, elems,
-                       nsplit, n);
+    launch_splits_reduce(part, bias, y, elems, nsplit, n, st);
     DD_LAUNCH_CHECK("linear_fwd reduce");
   }
   return 0;
@@ -404,8 +432,7 @@ int dd_linear_dgrad(const float* dy, const float* w, float* dx, int32_t m, int32
   DD_LAUNCH_CHECK("linear_dgrad");
   if (nsplit > 1) {
     const long elems = (long)m * k;
-    hipLaunchKernelGGL(splits_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, part,
-                       (const float*)nullptr, dx, elems, nsplit, k);
+    launch_splits_reduce(part, nullptr, dx, elems, nsplit, k, st);
     DD_LAUNCH_CHECK("linear_dgrad reduce");
   }
   return 0;
