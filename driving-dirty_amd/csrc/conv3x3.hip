@@ -1204,6 +1204,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino_wgrad(const float* __restr
 // (lane = input channel, sixteen ds_read_b32 per tile from a plain 4-slot ring), k-step = the tile pair (2s, 2s+1) on
 // the two half-waves.  One wave per SIMD (256 accumulator registers): the operands of tile s+1 are transformed into
 // their own registers while tile s's 16 MFMAs execute, its patch reads are issued a tile earlier still.
+constexpr int W2W_STAGE4 = 65 * 64;      // float4s per staging area of the final in-LDS reduction (64 KB of sums + the bias row)
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                              float* __restrict__ part, float* __restrict__ bpart, int B,
@@ -1342,11 +1343,48 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
     } while (tr < r1);
   }
 
+  // The workgroup's four partials are added in LDS, ((w0 + w1) + (w2 + w3)), before anything goes to HBM: 16 MB of
+  // partials instead of 67 (the reduce kernel reads them beside the overlapped optimizer pass, at a fraction of the
+  // HBM rate).  Two 64 KB staging areas over the rings, which nobody reads any more.
+  static_assert(WPB == 4, "conv_wino2_wgrad: the in-LDS reduction is written for four waves");
+  f32x4* stage = (f32x4*)smem + (wave >> 1) * W2W_STAGE4;      // [chunk = 4p + r/4][lane] float4, + one row for the bias sums
+  auto put = [&]() {
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) stage[(4 * p + c) * 64 + lane] = f32x4{acc[p][4 * c], acc[p][4 * c + 1], acc[p][4 * c + 2], acc[p][4 * c + 3]};
+    stage[64 * 64 + lane] = f32x4{bsum, 0.f, 0.f, 0.f};
+  };
+  auto get = [&]() {
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 v = stage[(4 * p + c) * 64 + lane];
+        acc[p][4 * c] += v.x;
+        acc[p][4 * c + 1] += v.y;
+        acc[p][4 * c + 2] += v.z;
+        acc[p][4 * c + 3] += v.w;
+      }
+    bsum += stage[64 * 64 + lane].x;
+  };
+  __syncthreads();
+  if (wave & 1) put();
+  __syncthreads();
+  if (!(wave & 1)) get();
+  __syncthreads();
+  if (wave == 2) {
+    stage = (f32x4*)smem;
+    put();
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  get();
 #pragma unroll
   for (int p = 0; p < 16; ++p)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[(((long)gw * 16 + p) * 16 + r) * 64 + lane] = acc[p][r];
-  bpart[(long)gw * 64 + lane] = bsum;
+    for (int r = 0; r < 16; ++r) part[(((long)blockIdx.x * 16 + p) * 16 + r) * 64 + lane] = acc[p][r];
+  bpart[(long)blockIdx.x * 64 + lane] = bsum;
 }
 
 // Second stage of conv_wino2_wgrad, in two launches (one block per accumulator row would leave 17 blocks to read 64 MB):
@@ -1858,12 +1896,12 @@ int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* 
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
-  const int nw = grid * WPB;
+  const int nw = grid;      // one partial per WORKGROUP (its four waves are added in LDS)
   float* part = (float*)workspace;
   float* bpart = part + (size_t)nw * 16 * 1024;
   float* tsum = bpart + (size_t)nw * 64;
   auto k = conv_wino2_wgrad<WPB>;
-  const size_t lds = (size_t)WPB * (4 * StripCfg<32, 1>::SLOTB + StripCfg<32, 1>::SPILLB);
+  const size_t lds = max((size_t)WPB * (4 * StripCfg<32, 1>::SLOTB + StripCfg<32, 1>::SPILLB), (size_t)2 * W2W_STAGE4 * 16);
   if (int rc = allow_lds(k, lds)) return rc;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
   DD_LAUNCH_CHECK("conv_wino2_wgrad");
