@@ -254,8 +254,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const long n4 = n / 4;
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-    const f32x4 gv = ((const f32x4*)g)[i];
+    // streaming accesses: this pass runs beside the conv backward and should not push its 4.5 GB through the caches
+    f32x4 pv = __builtin_nontemporal_load((f32x4*)p + i), mv = __builtin_nontemporal_load((f32x4*)m + i),
+          vv = __builtin_nontemporal_load((f32x4*)v + i);
+    const f32x4 gv = __builtin_nontemporal_load((const f32x4*)g + i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gg = gv[k] * gscale;
@@ -263,9 +265,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
       pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
     }
-    ((f32x4*)p)[i] = pv;
-    ((f32x4*)m)[i] = mv;
-    ((f32x4*)v)[i] = vv;
+    __builtin_nontemporal_store(pv, (f32x4*)p + i);
+    __builtin_nontemporal_store(mv, (f32x4*)m + i);
+    __builtin_nontemporal_store(vv, (f32x4*)v + i);
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
     const long i = 4 * n4 + threadIdx.x;
