@@ -63,7 +63,7 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 2);
 }
 
 // XOR swizzle of the 16-byte chunk index inside a 128-byte pixel so that the ds_read_b128 of 16
