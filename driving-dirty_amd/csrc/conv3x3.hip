@@ -57,10 +57,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int byt
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2));
 }
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 2));
 }
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 2);
