@@ -193,10 +193,10 @@ __global__ __launch_bounds__(256) void pool4_bwd_idx_quad(const float* __restric
       d2[k] = am == 2 ? gv : 0.f;
       d3[k] = am == 3 ? gv : 0.f;
     }
-    dfeat[base] = d0;
-    dfeat[base + groups] = d1;
-    dfeat[base + 2 * groups] = d2;
-    dfeat[base + 3 * groups] = d3;
+    __builtin_nontemporal_store(d0, dfeat + base);
+    __builtin_nontemporal_store(d1, dfeat + base + groups);
+    __builtin_nontemporal_store(d2, dfeat + base + 2 * groups);
+    __builtin_nontemporal_store(d3, dfeat + base + 3 * groups);
   }
 }
 
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(256) void pool4_bwd_quad(const float* __restrict__ 
       d2[k] = am == 2 ? gv : 0.f;
       d3[k] = am == 3 ? gv : 0.f;
     }
-    dfeat[base] = d0;
-    dfeat[base + groups] = d1;
-    dfeat[base + 2 * groups] = d2;
-    dfeat[base + 3 * groups] = d3;
+    __builtin_nontemporal_store(d0, dfeat + base);
+    __builtin_nontemporal_store(d1, dfeat + base + groups);
+    __builtin_nontemporal_store(d2, dfeat + base + 2 * groups);
+    __builtin_nontemporal_store(d3, dfeat + base + 3 * groups);
   }
 }
 

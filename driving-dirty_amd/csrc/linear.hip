@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int n = n0 + p * 16 + lrow;
-      const f32x4 v = *(const f32x4*)(Wt + (long)min(n, N - 1) * K + min(kc, K - 4));
+      const f32x4 v = __builtin_nontemporal_load((const f32x4*)(Wt + (long)min(n, N - 1) * K + min(kc, K - 4)));      // the weight streams through once
       wreg[p] = (kok && n < N) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int n = nb + p * 8 + wrow, c = c0 + wch * 4;
-      const f32x4 v = *(const f32x4*)(Wt + (long)min(n, N - 1) * K + min(c, K - 4));
+      const f32x4 v = __builtin_nontemporal_load((const f32x4*)(Wt + (long)min(n, N - 1) * K + min(c, K - 4)));
       wreg[p] = (n < N && c < K) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = nbase + 32 * a + dd_acc_row(i, lane);
-        if (n < N && k < K) dW[(long)n * K + k] = acc[a][b][i];
+        if (n < N && k < K) __builtin_nontemporal_store(acc[a][b][i], dW + (long)n * K + k);
       }
     }
     if (db && kg == 0) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_wide_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int n = nbase + 32 * a + dd_acc_row(i, lane);
-      if (n < N && kok) *(f32x4*)(dW + (long)n * K + kcol) = f32x4{acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
+      if (n < N && kok) __builtin_nontemporal_store(f32x4{acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]}, (f32x4*)(dW + (long)n * K + kcol));
     }
     if (db && kg == 0) {
       const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
