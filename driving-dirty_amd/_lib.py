@@ -105,6 +105,8 @@ SIGNATURES = {
     "dd_conv_wino2_pack": (_i32, [_p, _p, _p, _i32, _p]),
     "dd_conv_wino2_fwd_relu_bits": (_i32, [_p, _p, _p, _p, _p, _p, _p]),
     "dd_conv_wino2_dgrad_relu_bits": (_i32, [_p, _p, _p, _p, _p, _p]),
+    "dd_conv_wino2_dgrad_w1_workspace_bytes": (_i64, [_DP]),
+    "dd_conv_wino2_dgrad_w1": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _DP, _p]),
     "dd_conv_wino2_wgrad_workspace_bytes": (_i64, [_p]),
     "dd_conv_wino2_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "dd_conv_wino_wgrad_workspace_bytes": (_i64, [_p]),

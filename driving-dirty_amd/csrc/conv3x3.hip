@@ -36,6 +36,7 @@ constexpr int EPI_RELU_BITS = 6;        // y = conv * bit(channel) of bits[pixel
 // (next conv's row loader, pool, mask tests) from a per-channel (scale, shift), so the activation is never rewritten.
 constexpr int EPI_BIAS_STATS = 7;       // u = conv + bias; per-lane sum / sum of squares of u -> stats[wave][lane][2]
 constexpr int EPI_RELU_MASK_AFF = 8;    // y = conv * (mask*m_scale[c] + m_shift[c] > 0)
+constexpr int EPI_RELU_BITS_W1 = 9;     // conv_wino2_fwd only: as EPI_RELU_BITS, but y is not stored -- it feeds the 3 -> 32 layer's weight gradient in place
 
 // per-channel affine tables handed to the kernels: [0:32) input scale, [32:64) input shift, [64:96) mask scale, [96:128) mask shift
 
@@ -807,9 +808,13 @@ template <int EPI, int WPB>   // EPI_BIAS_RELU_BITS (forward) or EPI_RELU_BITS (
 __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restrict__ x, const float* __restrict__ up,
                                                            const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
                                                            float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
-                                                           int W, int nstrips) {
+                                                           int W, int nstrips, const float* __restrict__ x4 = nullptr,
+                                                           float* __restrict__ w1part = nullptr) {
   using C = StripCfg<32, 1>;
+  using C4 = StripCfg<4, 1>;
   constexpr int RINGB = 4 * C::SLOTB + C::SPILLB;
+  constexpr bool W1 = (EPI == EPI_RELU_BITS_W1);
+  constexpr bool MASKED = (EPI == EPI_RELU_BITS) || W1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -819,11 +824,32 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
     const f32x4* ug4 = (const f32x4*)up;
     for (int i = tid; i < WINO2_UFLOATS / 4; i += WPB * 64) ul4[i] = ug4[i];
   }
+  // W1: the 3 -> 32 layer's weight gradient dW1[co][(ky,kx,ci)] += g1[pixel][co] * x[pixel + (ky-1, kx-1)][ci] taken from
+  // the outputs while they are in registers (they are exactly the A operand of a 16x16x4 MFMA: lane = channel, k = the
+  // four tiles 4q+r of the lane groups); B = the image patch, gathered from a 4-row ring of the NHWC4 input (16 bytes a
+  // pixel) in LDS with one ds_read_b32 per MFMA pair.  Column 27 reads a constant 1 (bias gradient), 28..31 are ignored.
+  constexpr int W2_XRINGB = 4 * C4::SLOTB + C4::SPILLB;
+  constexpr int W2_XBASE = WINO2_UFLOATS * 4 + WPB * RINGB;
+  if (W1 && tid < 32) ((float*)(smem + W2_XBASE + WPB * W2_XRINGB))[tid] = 1.f;
   __syncthreads();
+  char* xring = smem + W2_XBASE + wave * W2_XRINGB;
+  char* xspill = xring + 4 * C4::SLOTB;
+  f32x4v wacc[2][2];      // [channel half][column half] of dW1, this wave's share
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) wacc[hf][nh] = f32x4v{0.f, 0.f, 0.f, 0.f};
   char* ring = smem + WINO2_UFLOATS * 4 + wave * RINGB;
   char* spill = ring + 4 * C::SLOTB;
   const f32x4* ul = (const f32x4*)smem;
   const int t16 = lane & 15, q4 = lane >> 4;
+  int xky[2], xlane[2];      // W1: this lane's patch column c = t16 + 16 nh -> tap row, byte offset inside a ring slot
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int c = min(t16 + 16 * nh, 26), tap = c / 3, ci = c - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+    xky[nh] = ky;
+    xlane[nh] = (8 * q4 + kx) * 16 + ci * 4;
+  }
   const float bv0 = (EPI == EPI_BIAS_RELU_BITS) ? bias[t16] : 0.f, bv1 = (EPI == EPI_BIAS_RELU_BITS) ? bias[16 + t16] : 0.f;
   const f32x4v bias0 = {bv0, bv0, bv0, bv0}, bias1 = {bv1, bv1, bv1, bv1};
   const int HT = (H + 1) / 2;                         // tile rows
@@ -837,6 +863,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
     idx += r1 - r0;
     const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
     const float* xb = x + (long)b * H * W * 32;
+    const float* x4b = x4 + (long)b * H * W * 4;
     const int gx0 = x0 - 1;
 
 #pragma unroll
@@ -845,6 +872,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
       const int iy = 2 * r0 - 1 + d;
       load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
       store_row<32, 1, true>(ring + ((iy + 1) & 3) * C::SLOTB, spill, lane, t);
+      if (W1) {      // the same four rows of the image, same slots
+        f32x4 t4[C4::NLOAD];
+        load_row<4, 1>(x4b, H, W, iy, gx0, lane, t4);
+        store_row<4, 1, false>(xring + ((iy + 1) & 3) * C4::SLOTB, xspill, lane, t4);
+      }
     }
 
     // Operand pipeline.  With one wave per SIMD an instruction hides only in the ~24 issue cycles an MFMA leaves free,
@@ -903,8 +935,9 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
       f32x4 pre[2][C::NLOAD];
       load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
       load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
+      f32x4 xpre[2][C4::NLOAD];
       unsigned mw[2][8];
-      if (EPI == EPI_RELU_BITS) {   // sign words of this lane's 2 x 8 output pixels (tiles 4q..4q+3)
+      if (MASKED) {   // sign words of this lane's 2 x 8 output pixels (tiles 4q..4q+3)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const int oy = 2 * tr + a;
@@ -929,6 +962,10 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
         } else {
           uread(0, 0, uq[0]);
           ystage(0, wq, vq[0]);
+        }
+        if (W1 && st == 7) {      // image rows for the next tile-row: they land after this tile-row's epilogue has read the old ones
+          load_row<4, 1>(x4b, H, W, 2 * tr + 3, gx0, lane, xpre[0]);
+          load_row<4, 1>(x4b, H, W, 2 * tr + 4, gx0, lane, xpre[1]);
         }
         if (st == 4) {      // rows 2tr+3, 2tr+4 replace rows 2tr-1, 2tr in the ring
           store_row<32, 1, true>(ring + ((2 * tr + 4) & 3) * C::SLOTB, spill, lane, pre[0]);
@@ -970,7 +1007,13 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
       for (int a = 0; a < 2; ++a) {
         const int oy = 2 * tr + a;
         const long opix = (long)(b * H + min(oy, H - 1)) * W;
-        const __amdgpu_buffer_rsrc_t ys = rsrc(y + opix * 32, (oy < H) ? W * 128 : 0);
+        const __amdgpu_buffer_rsrc_t ys = rsrc(y + (W1 ? 0 : opix * 32), (!W1 && oy < H) ? W * 128 : 0);
+        const char* xa[2];      // W1: this lane's patch element of output pixel (row a, tile 4q, e = 0): ring slot of image row oy + ky - 1
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const char* in_ring = xring + ((2 * tr + a + xky[nh]) & 3) * C4::SLOTB + xlane[nh];
+          xa[nh] = (t16 + 16 * nh >= 27) ? smem + W2_XBASE + WPB * W2_XRINGB : in_ring;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -987,9 +1030,16 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
               }
               float v = a == 0 ? (z[0] + z[1]) + z[2] : (z[1] - z[2]) - z[3];
               if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v, 0.f);      // the bias came in through the accumulator
-              if (EPI == EPI_RELU_BITS) v = ((mw[a][2 * r + e] >> (t16 + 16 * hf)) & 1u) ? v : 0.f;
+              if (MASKED) v = ((mw[a][2 * r + e] >> (t16 + 16 * hf)) & 1u) ? v : 0.f;
               o[hf] = v;
-              bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
+              if (!W1) bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
+            }
+            if (W1) {
+              const float b0 = *(const float*)(xa[0] + (2 * r + e) * 16), b1 = *(const float*)(xa[1] + (2 * r + e) * 16);
+              wacc[0][0] = DD_MFMA16(o[0], b0, wacc[0][0]);
+              wacc[0][1] = DD_MFMA16(o[0], b1, wacc[0][1]);
+              wacc[1][0] = DD_MFMA16(o[1], b0, wacc[1][0]);
+              wacc[1][1] = DD_MFMA16(o[1], b1, wacc[1][1]);
             }
             if (EPI == EPI_BIAS_RELU_BITS) {
               const unsigned long long b0 = __ballot(o[0] > 0.f), b1 = __ballot(o[1] > 0.f);
@@ -1007,7 +1057,50 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
           __builtin_amdgcn_raw_buffer_store_b32(word, bs, (lane < 32) ? (x0 + P) * 4 : -16, 0, 0);
         }
       }
+      if (W1) {
+        store_row<4, 1, false>(xring + ((2 * tr + 4) & 3) * C4::SLOTB, xspill, lane, xpre[0]);
+        store_row<4, 1, false>(xring + ((2 * tr + 5) & 3) * C4::SLOTB, xspill, lane, xpre[1]);
+      }
     }
+  }
+  if (W1) {
+    const long gw = (long)blockIdx.x * WPB + wave;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1part[((gw * 2 + hf) * 2 + nh) * 256 + i * 64 + lane] = wacc[hf][nh][i];
+  }
+}
+
+// Reduce of conv_wino2_fwd<EPI_RELU_BITS_W1>'s per-wave dW1 partials ([wave][half][column half][reg][lane]) in a fixed order and
+// scatter to OIHW [32][3][3][3] + bias [32]: a block owns 8 elements, 32 thread groups share the waves.
+__global__ __launch_bounds__(256) void conv_w1_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                      int nw) {
+  __shared__ float red[32][8];
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int e = blockIdx.x * 8 + el;      // < 1024
+  float s0 = 0.f, s1 = 0.f;
+  int w = g;
+  for (; w + 32 < nw; w += 64) {
+    s0 += part[(long)w * 1024 + e];
+    s1 += part[(long)(w + 32) * 1024 + e];
+  }
+  if (w < nw) s0 += part[(long)w * 1024 + e];
+  red[g][el] = s0 + s1;
+  __syncthreads();
+  if (g != 0) return;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v += red[i][el];
+  const int l = e & 63, reg = (e >> 6) & 3, nh = (e >> 8) & 1, hf = e >> 9;
+  const int co = 16 * hf + 4 * (l >> 4) + reg, col = 16 * nh + (l & 15);
+  if (col < 27) {
+    const int tap = col / 3, ci = col - 3 * tap;
+    dw[(co * 3 + ci) * 9 + tap] = v;
+  } else if (col == 27) {
+    db[co] = v;
   }
 }
 
@@ -1588,15 +1681,19 @@ int launch_fwd(const float* x, const float* wp, const float* bias, const float* 
 
 template <int EPI>
 int launch_wino2(const float* x, const float* up, const float* bias, const unsigned* bits_in, float* y, unsigned* bits_out,
-                 const dd_conv_desc* d, hipStream_t st) {
+                 const dd_conv_desc* d, hipStream_t st, const float* x4 = nullptr, float* w1part = nullptr, int* nw_out = nullptr) {
   using C = StripCfg<32, 1>;
+  using C4 = StripCfg<4, 1>;
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
-  const size_t lds = (size_t)WINO2_UFLOATS * 4 + (size_t)WPB * (4 * C::SLOTB + C::SPILLB);
+  const size_t lds = (size_t)WINO2_UFLOATS * 4 + (size_t)WPB * (4 * C::SLOTB + C::SPILLB) +
+                     (EPI == EPI_RELU_BITS_W1 ? (size_t)WPB * (4 * C4::SLOTB + C4::SPILLB) + 128 : 0);
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
+  if (nw_out) *nw_out = grid * WPB;
   auto k = conv_wino2_fwd<EPI, WPB>;
   if (int rc = allow_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips,
+                     x4, w1part);
   DD_LAUNCH_CHECK("conv_wino2_fwd");
   return 0;
 }
@@ -1871,6 +1968,28 @@ int dd_conv_wino2_dgrad_relu_bits(const float* dy, const float* packed, const ui
   DD_REQUIRE(dy && packed && relu_bits && dx, DD_ERR_BAD_ARG, "conv_wino2_dgrad_relu_bits: NULL pointer");
   DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
   return launch_wino2<EPI_RELU_BITS>(dy, packed, nullptr, relu_bits, dx, nullptr, d, (hipStream_t)stream);
+}
+
+int64_t dd_conv_wino2_dgrad_w1_workspace_bytes(const dd_conv_desc* d) {
+  if (check_desc(d)) return -1;
+  if (d->cin_real != 32 || d->stride != 1) return -1;
+  return (int64_t)4 * DD_NUM_CU * 1024 * 4;      // one 32 x 32 partial per wave
+}
+
+int dd_conv_wino2_dgrad_w1(const float* dy, const float* packed, const uint32_t* relu_bits, const float* x_nhwc4, float* dw1_oihw,
+                           float* dbias1, void* workspace, int64_t workspace_bytes, const dd_conv_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(dy && packed && relu_bits && x_nhwc4 && dw1_oihw && dbias1 && workspace, DD_ERR_BAD_ARG, "conv_wino2_dgrad_w1: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  DD_REQUIRE(workspace_bytes >= dd_conv_wino2_dgrad_w1_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wino2_dgrad_w1: workspace %ld < %ld bytes",
+             (long)workspace_bytes, (long)dd_conv_wino2_dgrad_w1_workspace_bytes(d));
+  int nw = 0;
+  if (int rc = launch_wino2<EPI_RELU_BITS_W1>(dy, packed, nullptr, relu_bits, nullptr, nullptr, d, (hipStream_t)stream, x_nhwc4,
+                                              (float*)workspace, &nw))
+    return rc;
+  hipLaunchKernelGGL(conv_w1_reduce, dim3(128), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw1_oihw, dbias1, nw);
+  DD_LAUNCH_CHECK("conv_w1_reduce");
+  return 0;
 }
 
 int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d) {

@@ -6,6 +6,7 @@ layers are NHWC fp32 tensors ``[B,H,W,C]``; the module layer (components.py) pre
 callers as NCHW-shaped channels_last views, which is what the reference returns logically.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -248,6 +249,22 @@ def conv_wino2_dgrad_bits(dy, packed, bits, desc):
     return dx
 
 
+def conv_wino2_dgrad_w1(dy, packed, bits, x4, desc):
+    """c2's data gradient consumed in place: returns the 3 -> 32 layer's (dW1 [32,3,3,3], db1 [32]) instead of g1
+    (dd_conv_wino2_dgrad_w1: g1 is never written to or re-read from HBM)."""
+    _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
+    _dev(x4, "x4", (desc.batch, desc.height, desc.width, 4))
+    if not (bits.is_cuda and bits.dtype == torch.int32 and bits.is_contiguous() and tuple(bits.shape) == (desc.batch, desc.height, desc.width)):
+        raise _lib.HotpathError("conv_wino2_dgrad_w1: relu_bits must be a contiguous int32 [B,H,W] device tensor")
+    n = _lib.lib().dd_conv_wino2_dgrad_w1_workspace_bytes(C.byref(desc))
+    ws = torch.empty(n, device=dy.device, dtype=torch.uint8)
+    dw = torch.empty((32, 3, 3, 3), device=dy.device, dtype=torch.float32)
+    db = torch.empty((32,), device=dy.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv_wino2_dgrad_w1(_p(dy), _p(packed), _p(bits), _p(x4), _p(dw), _p(db), _p(ws), n, C.byref(desc),
+                                            _stream()), "dd_conv_wino2_dgrad_w1")
+    return dw, db
+
+
 def conv_wino2_wgrad(x, dy, desc):
     _dev(x, "x", (desc.batch, desc.height, desc.width, 32))
     _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
@@ -372,6 +389,9 @@ def pool4_relu_bwd(dpooled, feat):
 # optimizer pass of already-finished gradients (optim.HipAdam.overlap_with_backward).
 MFMA_PHASE_HOOKS = []
 
+# c1's weight gradient taken from c2's data gradient inside conv_wino2_fwd<EPI_RELU_BITS_W1> (2-D Winograd path only)
+FUSE_C1_WGRAD = os.environ.get("DD_FUSE_C1_WGRAD", "1") != "0"
+
 
 # ------------------------------------------------------------------------------------------------ encoder conv stack
 class EncoderConvStack(torch.autograd.Function):
@@ -467,7 +487,10 @@ class EncoderConvStack(torch.autograd.Function):
                     dw2, db2 = conv_wino_wgrad(a1, g2, d2)
                 else:
                     dw2, db2 = conv_wgrad(a1, g2, d2)
-            if need[1] or need[2]:
+            if (need[1] or need[2]) and wino2 and FUSE_C1_WGRAD:
+                dw1, db1 = conv_wino2_dgrad_w1(g2, p2d, s1, x4, d2)      # g1 never leaves the registers
+                del g2
+            elif need[1] or need[2]:
                 if wino2:
                     g1 = conv_wino2_dgrad_bits(g2, p2d, s1, d2)
                 elif wino:

@@ -348,6 +348,15 @@ int dd_conv_wino2_fwd_relu_bits(const float* x, const float* packed, const float
                                 const dd_conv_desc* d, void* stream);
 int dd_conv_wino2_dgrad_relu_bits(const float* dy, const float* packed, const uint32_t* relu_bits, float* dx,
                                   const dd_conv_desc* d, void* stream);
+/* The same data gradient CONSUMED IN PLACE by the 3 -> 32 layer's weight gradient (components.py:19,41: c1): instead of
+ * writing g1 = dL/d(c1 output) (1.93 GB at bs 32) for dd_conv_wgrad to read back, the kernel multiplies every masked
+ * output tile with the matching patch of the stitched input x_nhwc4 [B,H,W,4] while it is in registers and returns
+ * dW1 [32,3,3,3] (OIHW) and dbias1 [32].  Same arithmetic as dd_conv_wino2_dgrad_relu_bits + dd_conv_wgrad up to the
+ * order of the fp32 sums. */
+int64_t dd_conv_wino2_dgrad_w1_workspace_bytes(const dd_conv_desc* d);
+int dd_conv_wino2_dgrad_w1(const float* dy, const float* packed, const uint32_t* relu_bits, const float* x_nhwc4,
+                           float* dw1_oihw, float* dbias1, void* workspace, int64_t workspace_bytes,
+                           const dd_conv_desc* d, void* stream);
 /* ... and of the weight gradient: F(3x3,2x2), 16 accumulators S[u][v] over tiles, dW = A^T S A in the reduce kernel */
 int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d);
 int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,

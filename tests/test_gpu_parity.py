@@ -136,6 +136,20 @@ def test_conv_winograd_fwd_dgrad_wgrad(dev, b, h, w, rows):
     dw2, db2 = ops.conv_wino2_wgrad(x_nhwc, nhwc(gy.float()).to(dev), desc)
     assert rel_err(dw2, wt64.grad) < KERNEL_TOL
     assert rel_err(db2, bias64.grad) < KERNEL_TOL
+    # the same data gradient consumed in place by the 3 -> 32 layer's weight gradient (g1 never written):
+    # dW1 / db1 of conv2d(img, w1) for the upstream gradient g1 = dx2, against fp64 and against the two-kernel path
+    img = hu((b, 3, h, w), f"wimg{b}{h}{w}", 0.0, 1.0).double()
+    w1 = torch.zeros(32, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    b1 = torch.zeros(32, dtype=torch.float64, requires_grad=True)
+    F.conv2d(img, w1, b1, padding=1).backward(x.grad * (xm > 0))
+    img4 = torch.zeros(b, h, w, 4)
+    img4[..., :3] = img.float().permute(0, 2, 3, 1)
+    img4 = img4.to(dev)
+    dw1, db1 = ops.conv_wino2_dgrad_w1(nhwc(gy.float()).to(dev), ops.conv_wino2_pack(wd, desc, 1), mbits, img4, desc)
+    assert rel_err(dw1, w1.grad) < KERNEL_TOL
+    assert rel_err(db1, b1.grad) < KERNEL_TOL
+    dw1b, db1b = ops.conv_wgrad(img4, dx2, ops.conv_desc(b, h, w, 3, 1, rows))
+    assert rel_err(dw1, dw1b) < KERNEL_TOL and rel_err(db1, db1b) < KERNEL_TOL
     with pytest.raises(_lib.HotpathError):
         ops.conv_wino_pack(wd, ops.conv_desc(b, h, w, 32, 2), 0)           # stride 2 has no Winograd path
 
