@@ -71,7 +71,7 @@ SIGNATURES = {
     "dd_pool4_idx_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "dd_pool4_fwd_idx": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_idx_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
-    "dd_bn_relu_drop_fwd": (_i32, [_p] * 9 + [_i32, _i32, _f32, _f32, _f32, _i32, _p]),
+    "dd_bn_relu_drop_fwd": (_i32, [_p] * 9 + [_i32, _i32, _f32, _f32, _f32, _i32, _p, _p]),
     "dd_bn_relu_drop_bwd": (_i32, [_p] * 12 + [_i32, _i32, _f32, _f32, _i32, _p]),
     "dd_loss_workspace_bytes": (_i64, [_i64]),
     "dd_bce_logits": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),

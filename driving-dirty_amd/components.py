@@ -41,14 +41,13 @@ class DenseBlock(nn.Module):
         bn = self.fc_bn
         p = float(self.drop_p)
         if keep is None and p > 0.0:
-            keep = torch.bernoulli(torch.full_like(lin, 1.0 - p))
+            keep = torch.empty_like(lin).bernoulli_(1.0 - p)      # one kernel (no probability tensor to fill first)
         training = bn.training or bn.running_mean is None
-        if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        nbt = bn.num_batches_tracked if (bn.training and bn.num_batches_tracked is not None) else None      # incremented by the kernel
         momentum = 0.1 if bn.momentum is None else bn.momentum
         scale = 1.0 / (1.0 - p) if p < 1.0 else 0.0
         return ops.BnReluDrop.apply(lin, bn.weight, bn.bias, bn.running_mean, bn.running_var, keep,
-                                    training, bn.eps, momentum, scale)
+                                    training, bn.eps, momentum, scale, nbt)
 
 
 class Decoder(nn.Module):

@@ -21,9 +21,10 @@ __global__ __launch_bounds__(256) void bn_relu_drop_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ rmean, float* __restrict__ rvar, const float* __restrict__ keep, float* __restrict__ y,
     float* __restrict__ smean, float* __restrict__ sinv, int rows, int feat, float eps, float momentum, float scale,
-    int training) {
+    int training, long long* __restrict__ nbt) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= feat) return;
+  if (nbt && f == 0) *nbt += 1;      // BatchNorm's num_batches_tracked.add_(1): no launch of its own
   constexpr int RR = R > 0 ? R : 1;
   float xv[RR];
   if (R > 0) {
@@ -376,14 +377,14 @@ extern "C" {
 
 int dd_bn_relu_drop_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         const float* keep, float* y, float* save_mean, float* save_invstd, int32_t rows, int32_t feat,
-                        float eps, float momentum, float scale, int32_t training, void* stream) {
+                        float eps, float momentum, float scale, int32_t training, int64_t* num_batches_tracked, void* stream) {
   DD_REQUIRE(x && gamma && beta && running_mean && running_var && y, DD_ERR_BAD_ARG, "bn_fwd: NULL pointer");
   DD_REQUIRE(rows > 0 && feat > 0, DD_ERR_BAD_ARG, "bn_fwd: non-positive size");
   DD_REQUIRE(!training || (save_mean && save_invstd), DD_ERR_BAD_ARG, "bn_fwd: training mode needs save buffers");
   DD_REQUIRE(!training || rows > 1, DD_ERR_UNSUPPORTED, "bn_fwd: batch statistics need more than 1 row (torch raises too)");
   auto k = rows <= 32 ? bn_relu_drop_fwd_kernel<32> : rows <= 64 ? bn_relu_drop_fwd_kernel<64> : bn_relu_drop_fwd_kernel<0>;
   hipLaunchKernelGGL(k, dim3((feat + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var, keep, y,
-                     save_mean, save_invstd, rows, feat, eps, momentum, scale, training);
+                     save_mean, save_invstd, rows, feat, eps, momentum, scale, training, (long long*)(training ? num_batches_tracked : nullptr));
   DD_LAUNCH_CHECK("bn_relu_drop_fwd");
   return 0;
 }

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_wide_kernel(const float* __r
 int pick_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 0); }   // 64 KB of static LDS caps the batch tile at 64 rows
 
 int pick_split(int blocks_other, int ntiles) {
+  if (ntiles <= 8) return 1;      // a handful of tiles: one block walks them faster than a second launch can add the splits up
   int want = (2 * DD_NUM_CU + blocks_other - 1) / blocks_other;   // aim at ~2 blocks per CU
   want = max(1, min(want, ntiles));
   return min(want, 512);

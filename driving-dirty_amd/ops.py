@@ -559,15 +559,17 @@ class BnReluDrop(torch.autograd.Function):
     """BatchNorm1d -> ReLU -> dropout(keep mask) in one kernel each way (components.py:105-108)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, keep, training, eps, momentum, scale):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, keep, training, eps, momentum, scale, num_batches_tracked=None):
         rows, feat = x.shape
+        if num_batches_tracked is not None and not (num_batches_tracked.is_cuda and num_batches_tracked.dtype == torch.int64):
+            raise _lib.HotpathError("bn_relu_drop: num_batches_tracked must be an int64 device tensor")
         _dev(x, "x")
         y = torch.empty_like(x)
         save_mean = torch.empty(feat, device=x.device, dtype=torch.float32)
         save_inv = torch.empty(feat, device=x.device, dtype=torch.float32)
         check(_lib.lib().dd_bn_relu_drop_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(keep),
                                              _p(y), _p(save_mean), _p(save_inv), rows, feat, eps, momentum, scale,
-                                             int(training), _stream()), "dd_bn_relu_drop_fwd")
+                                             int(training), _p(num_batches_tracked), _stream()), "dd_bn_relu_drop_fwd")
         ctx.save_for_backward(x, y, gamma, keep, save_mean, save_inv, running_mean, running_var)
         ctx.cfg = (bool(training), eps, scale)
         return y
@@ -584,7 +586,7 @@ class BnReluDrop(torch.autograd.Function):
         check(_lib.lib().dd_bn_relu_drop_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(keep), _p(save_mean), _p(save_inv),
                                              _p(running_mean), _p(running_var), _p(dx), _p(dgamma), _p(dbeta), rows, feat,
                                              eps, scale, int(training), _stream()), "dd_bn_relu_drop_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ losses

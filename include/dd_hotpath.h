@@ -194,11 +194,12 @@ int dd_pool4_idx_relu_bwd(const float* dpooled, const uint16_t* idx, float* dfea
  * dropout with a caller-supplied keep mask (components.py:104-109).  x,y,keep: [rows, feat].
  * keep may be NULL (no dropout); scale = 1/(1-p).  save_mean/save_invstd [feat] are written in
  * training mode and consumed by the backward.  Running stats are updated in place with
- * `momentum` using the unbiased batch variance, as torch.nn.BatchNorm1d does. */
+ * `momentum` using the unbiased batch variance, as torch.nn.BatchNorm1d does; num_batches_tracked (device
+ * int64, may be NULL) is incremented in training mode, as the module's forward does. */
 int dd_bn_relu_drop_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, const float* keep, float* y, float* save_mean,
                         float* save_invstd, int32_t rows, int32_t feat, float eps, float momentum,
-                        float scale, int32_t training, void* stream);
+                        float scale, int32_t training, int64_t* num_batches_tracked, void* stream);
 int dd_bn_relu_drop_bwd(const float* dy, const float* x, const float* y, const float* gamma,
                         const float* keep, const float* save_mean, const float* save_invstd,
                         const float* running_mean, const float* running_var, float* dx, float* dgamma, float* dbeta, int32_t rows,

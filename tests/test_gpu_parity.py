@@ -219,6 +219,23 @@ def test_pool4_routing_codes(dev, b, c, h, w):
         ops.pool4_fwd_idx(torch.zeros(1, 5, 7, 32, device=dev))
 
 
+def test_dense_block_counts_batches(dev):
+    """BatchNorm1d.num_batches_tracked is advanced by the fused kernel (training mode only), as the module's forward does."""
+    from driving_dirty_amd.components import DenseBlock
+    blk = synth.fill_module(DenseBlock(8, 16, drop_p=0.2), seed=5).to(dev)
+    x = hu((4, 8), "nbtx").to(dev)
+    blk.train()
+    blk(x)
+    blk(x)
+    assert int(blk.fc_bn.num_batches_tracked) == 2
+    blk.eval()
+    blk(x)
+    assert int(blk.fc_bn.num_batches_tracked) == 2
+    ref = torch.nn.BatchNorm1d(16).train()
+    ref(torch.randn(4, 16)); ref(torch.randn(4, 16))
+    assert int(ref.num_batches_tracked) == 2
+
+
 @pytest.mark.parametrize("rows,feat,training,drop", [(3, 16, True, 0.0), (32, 128, True, 0.2), (5, 300, False, 0.2)])
 def test_bn_relu_dropout(dev, rows, feat, training, drop):
     from driving_dirty_amd import ops
