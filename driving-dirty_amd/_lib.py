@@ -71,6 +71,9 @@ SIGNATURES = {
     "dd_pool4_idx_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "dd_pool4_fwd_idx": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_idx_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_mlp_tail_supported": (_i32, [_i32] * 4),
+    "dd_mlp_tail_fwd": (_i32, [_p] * 25 + [_i32] * 4 + [_f32] * 6 + [_i32, _p]),
+    "dd_mlp_tail_bwd": (_i32, [_p] * 28 + [_i32] * 4 + [_f32] * 4 + [_i32, _p]),
     "dd_bn_relu_drop_fwd": (_i32, [_p] * 9 + [_i32, _i32, _f32, _f32, _f32, _i32, _p, _p]),
     "dd_bn_relu_drop_bwd": (_i32, [_p] * 12 + [_i32, _i32, _f32, _f32, _i32, _p]),
     "dd_loss_workspace_bytes": (_i64, [_i64]),

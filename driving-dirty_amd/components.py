@@ -104,6 +104,27 @@ class Encoder(nn.Module):
         # activations stored in bf16 (BASELINE config 5); the FC tail and every parameter stay fp32 either way
         self.precision = "fp32"
 
+    def _tail(self, pooled, keeps):
+        """pooled -> DenseBlock fc1 -> DenseBlock fc2 -> fc_z_out.  After the big fc1 GEMM the rest is tiny: one fused launch
+        each way where its sizes allow (ops.EncoderTail), the separate kernels otherwise."""
+        fc1, fc2, fcz = self.fc1, self.fc2, self.fc_z_out
+        m, h1, h2, l = pooled.shape[0], fc1.fc1.out_features, fc2.fc1.out_features, fcz.out_features
+        bn1, bn2 = fc1.fc_bn, fc2.fc_bn
+        same_mode = bn1.training == bn2.training and bn1.running_mean is not None and bn2.running_mean is not None
+        if not (same_mode and ops.mlp_tail_supported(m, h1, h2, l)):
+            h = fc2(fc1(pooled, keeps[0]), keeps[1])
+            return ops.linear(h, fcz.weight, fcz.bias)
+        lin1 = ops.linear(pooled, fc1.fc1.weight, fc1.fc1.bias)
+        ks, scales = [], []
+        for blk, keep, width in ((fc1, keeps[0], h1), (fc2, keeps[1], h2)):
+            p = float(blk.drop_p)
+            if keep is None and p > 0.0:      # F.dropout(training=True): always on (components.py:108)
+                keep = torch.empty((m, width), device=pooled.device, dtype=torch.float32).bernoulli_(1.0 - p)
+            ks.append(keep)
+            scales.append(1.0 / (1.0 - p) if p < 1.0 else 0.0)
+        return ops.EncoderTail.apply(lin1, bn1.weight, bn1.bias, fc2.fc1.weight, fc2.fc1.bias, bn2.weight, bn2.bias, fcz.weight,
+                                     fcz.bias, ks[0], ks[1], bn1, bn2, scales[0], scales[1])
+
     def forward_nhwc4(self, x4, keeps=(None, None)):
         """x4: [B,H,W,4] NHWC image (channel 3 zero), e.g. straight from ``ops.stitch6`` (fp32) or
         ``ops_bf16.stitch6_bf16`` (bf16: selects the mixed-precision conv stack)."""
@@ -112,22 +133,18 @@ class Encoder(nn.Module):
                 raise NotImplementedError("the bf16 conv stack feeds the pooled exit only (c3_only is fp32)")
             from . import ops_bf16
             pooled = ops_bf16.encoder_conv_stack(x4, self.c1, self.c2, self.c3)
-            h = self.fc2(self.fc1(pooled, keeps[0]), keeps[1])
-            return ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
+            return self._tail(pooled, keeps)
         if self.c3_only:
             feat = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, False, self.rows_per_task)
             return feat.permute(0, 3, 1, 2)         # NCHW-shaped view of the NHWC buffer
         pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, True, self.rows_per_task)
-        h = self.fc1(pooled, keeps[0])
-        h = self.fc2(h, keeps[1])
-        return ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
+        return self._tail(pooled, keeps)
 
     def forward_both(self, x4, keeps=(None, None)):
         """One pass of the conv stack feeding BOTH exits the reference's ``c3_only`` switch chooses between
         (components.py:44-45): returns (conv feature [B,32,H/2,W/2], latent z).  Used by the joint roadmap + box model."""
         feat, pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, 2, self.rows_per_task)
-        h = self.fc2(self.fc1(pooled, keeps[0]), keeps[1])
-        return feat.permute(0, 3, 1, 2), ops.linear(h, self.fc_z_out.weight, self.fc_z_out.bias)
+        return feat.permute(0, 3, 1, 2), self._tail(pooled, keeps)
 
     def forward(self, x, keeps=(None, None)):
         _require_gpu(x, "Encoder")

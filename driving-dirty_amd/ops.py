@@ -589,6 +589,69 @@ class BnReluDrop(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------ encoder tail
+FUSE_MLP_TAIL = os.environ.get("DD_FUSE_MLP_TAIL", "1") != "0"
+
+
+def mlp_tail_supported(m, h1, h2, l):
+    return FUSE_MLP_TAIL and bool(_lib.lib().dd_mlp_tail_supported(m, h1, h2, l))
+
+
+class EncoderTail(torch.autograd.Function):
+    """BatchNorm1d -> ReLU -> dropout -> Linear -> BatchNorm1d -> ReLU -> dropout -> Linear as one launch each way
+    (dd_mlp_tail_fwd / dd_mlp_tail_bwd; reference components.py:48-51 + DenseBlock.forward :104-109).
+
+    forward(lin1, gamma1, beta1, w2, bias2, gamma2, beta2, wz, bz, keep1, keep2, bn1, bn2, scale1, scale2) -> z
+    ``bn1`` / ``bn2`` are the BatchNorm1d modules (running statistics, eps, momentum, mode)."""
+
+    @staticmethod
+    def forward(ctx, lin1, gamma1, beta1, w2, bias2, gamma2, beta2, wz, bz, keep1, keep2, bn1, bn2, scale1, scale2):
+        m, h1 = lin1.shape
+        h2, l = w2.shape[0], wz.shape[0]
+        for name, t, shape in (("lin1", lin1, None), ("w2", w2, (h2, h1)), ("wz", wz, (l, h2)), ("bias2", bias2, (h2,)), ("bz", bz, (l,)),
+                               ("gamma1", gamma1, (h1,)), ("beta1", beta1, (h1,)), ("gamma2", gamma2, (h2,)), ("beta2", beta2, (h2,))):
+            _dev(t, name, shape)
+        if keep1 is not None:
+            _dev(keep1, "keep1", (m, h1))
+        if keep2 is not None:
+            _dev(keep2, "keep2", (m, h2))
+        training = bool(bn1.training)
+        dev = lin1.device
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        y1, lin2, y2, z = new(m, h1), new(m, h2), new(m, h2), new(m, l)
+        mean1, inv1, mean2, inv2 = new(h1), new(h1), new(h2), new(h2)
+        mom = lambda bn: 0.1 if bn.momentum is None else bn.momentum
+        nbt = lambda bn: bn.num_batches_tracked if (training and bn.num_batches_tracked is not None) else None
+        check(_lib.lib().dd_mlp_tail_fwd(_p(lin1), _p(gamma1), _p(beta1), _p(bn1.running_mean), _p(bn1.running_var), _p(nbt(bn1)),
+                                         _p(keep1), _p(w2), _p(bias2), _p(gamma2), _p(beta2), _p(bn2.running_mean),
+                                         _p(bn2.running_var), _p(nbt(bn2)), _p(keep2), _p(wz), _p(bz), _p(y1), _p(lin2), _p(y2),
+                                         _p(z), _p(mean1), _p(inv1), _p(mean2), _p(inv2), m, h1, h2, l, bn1.eps, bn2.eps,
+                                         mom(bn1), mom(bn2), scale1, scale2, int(training), _stream()), "dd_mlp_tail_fwd")
+        ctx.save_for_backward(lin1, y1, lin2, y2, gamma1, gamma2, keep1, keep2, w2, wz, mean1, inv1, mean2, inv2,
+                              bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var)
+        ctx.cfg = (training, bn1.eps, bn2.eps, scale1, scale2)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (lin1, y1, lin2, y2, gamma1, gamma2, keep1, keep2, w2, wz, mean1, inv1, mean2, inv2, rm1, rv1, rm2, rv2) = ctx.saved_tensors
+        training, eps1, eps2, scale1, scale2 = ctx.cfg
+        m, h1 = lin1.shape
+        h2, l = w2.shape[0], wz.shape[0]
+        dz = dz.contiguous()
+        dlin1 = torch.empty_like(lin1)
+        dg1, db1, dg2, db2 = torch.empty_like(gamma1), torch.empty_like(gamma1), torch.empty_like(gamma2), torch.empty_like(gamma2)
+        dw2, dwz = torch.empty_like(w2), torch.empty_like(wz)
+        dbias2 = torch.empty(h2, device=dz.device, dtype=torch.float32)
+        dbz = torch.empty(l, device=dz.device, dtype=torch.float32)
+        check(_lib.lib().dd_mlp_tail_bwd(_p(dz), _p(lin1), _p(y1), _p(lin2), _p(y2), _p(gamma1), _p(gamma2), _p(keep1), _p(keep2),
+                                         _p(w2), _p(wz), _p(mean1), _p(inv1), _p(mean2), _p(inv2), _p(rm1), _p(rv1), _p(rm2), _p(rv2),
+                                         _p(dlin1), _p(dg1), _p(db1), _p(dw2), _p(dbias2), _p(dg2), _p(db2), _p(dwz), _p(dbz),
+                                         m, h1, h2, l, eps1, eps2, scale1, scale2, int(training), _stream()), "dd_mlp_tail_bwd")
+        return dlin1, dg1, db1, dw2, dbias2, dg2, db2, dwz, dbz, None, None, None, None, None, None
+
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def _loss_ws(n, device):
     return torch.empty(_lib.lib().dd_loss_workspace_bytes(n), device=device, dtype=torch.uint8)

@@ -205,6 +205,30 @@ int dd_bn_relu_drop_bwd(const float* dy, const float* x, const float* y, const f
                         const float* running_mean, const float* running_var, float* dx, float* dgamma, float* dbeta, int32_t rows,
                         int32_t feat, float eps, float scale, int32_t training, void* stream);
 
+/* ---- the encoder's small tail as ONE launch each way (components.py:48-51 with DenseBlock.forward :104-109):
+ *   lin1 [m,h1] (output of the big fc1 Linear) -> BatchNorm1d -> ReLU -> dropout -> Linear(h1->h2) -> BatchNorm1d ->
+ *   ReLU -> dropout -> Linear(h2->l) -> z [m,l].
+ * Same arithmetic and argument meaning as dd_bn_relu_drop_* and dd_linear_* chained (13 + 8 launches); one 256-thread
+ * workgroup, operands in LDS.  Limits: m <= 32, h1, h2, l <= 128 and multiples of 4
+ * (dd_mlp_tail_supported returns 0 otherwise and the entry points DD_ERR_UNSUPPORTED: chain the separate kernels).
+ * Forward outputs kept for the backward: y1 [m,h1], lin2 [m,h2], y2 [m,h2], save_mean/invstd 1, 2. */
+int dd_mlp_tail_supported(int32_t m, int32_t h1, int32_t h2, int32_t l);
+int dd_mlp_tail_fwd(const float* lin1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                    int64_t* num_batches_tracked1, const float* keep1, const float* w2, const float* bias2,
+                    const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                    int64_t* num_batches_tracked2, const float* keep2, const float* wz, const float* bz, float* y1,
+                    float* lin2, float* y2, float* z, float* save_mean1, float* save_invstd1, float* save_mean2,
+                    float* save_invstd2, int32_t m, int32_t h1, int32_t h2, int32_t l, float eps1, float eps2,
+                    float momentum1, float momentum2, float scale1, float scale2, int32_t training, void* stream);
+int dd_mlp_tail_bwd(const float* dz, const float* lin1, const float* y1, const float* lin2, const float* y2,
+                    const float* gamma1, const float* gamma2, const float* keep1, const float* keep2, const float* w2,
+                    const float* wz, const float* save_mean1, const float* save_invstd1, const float* save_mean2,
+                    const float* save_invstd2, const float* running_mean1, const float* running_var1,
+                    const float* running_mean2, const float* running_var2, float* dlin1, float* dgamma1, float* dbeta1,
+                    float* dw2, float* dbias2, float* dgamma2, float* dbeta2, float* dwz, float* dbz, int32_t m, int32_t h1,
+                    int32_t h2, int32_t l, float eps1, float eps2, float scale1, float scale2, int32_t training,
+                    void* stream);
+
 /* Mean binary cross-entropy with logits over n elements (roadmap_bce_v2.py:106), one pass:
  * loss_out[0] = mean(max(z,0) - z*t + log1p(exp(-|z|))); dlogits (optional) = (sigmoid(z) - t) *
  * grad_scale / n; probs (optional) = sigmoid(z).  target is fp32 0/1.  partials: workspace of

@@ -219,6 +219,63 @@ def test_pool4_routing_codes(dev, b, c, h, w):
         ops.pool4_fwd_idx(torch.zeros(1, 5, 7, 32, device=dev))
 
 
+@pytest.mark.parametrize("m,h1,h2,l,training", [(32, 128, 128, 64, True), (3, 16, 16, 8, True), (5, 24, 16, 8, False)])
+def test_fused_encoder_tail_matches_the_separate_kernels(dev, m, h1, h2, l, training):
+    """ops.EncoderTail (one launch each way) against DenseBlock -> DenseBlock -> Linear run kernel by kernel, and against
+    the fp64 oracle blocks: outputs, every gradient, running statistics, num_batches_tracked."""
+    from driving_dirty_amd import ops
+    from driving_dirty_amd.components import DenseBlock
+    from oracle.ae_parts import FcBlock
+
+    def build():
+        b1 = synth.fill_module(DenseBlock(8, h1, drop_p=0.2), seed=31)
+        b2 = synth.fill_module(DenseBlock(h1, h2, drop_p=0.2), seed=32)
+        fz = synth.fill_module(torch.nn.Linear(h2, l), seed=33)
+        return b1, b2, fz
+    lin1 = hu((m, h1), "tail_lin1")
+    k1 = (hu((m, h1), "tail_k1", 0.0, 1.0) < 0.8).float()
+    k2 = (hu((m, h2), "tail_k2", 0.0, 1.0) < 0.8).float()
+    gz = hu((m, l), "tail_gz")
+    res = []
+    for fused in (True, False):
+        b1, b2, fz = (t.to(dev).train(training) for t in build())
+        x = lin1.clone().to(dev).requires_grad_(True)
+        if fused:
+            assert ops.mlp_tail_supported(m, h1, h2, l)
+            z = ops.EncoderTail.apply(x, b1.fc_bn.weight, b1.fc_bn.bias, b2.fc1.weight, b2.fc1.bias, b2.fc_bn.weight, b2.fc_bn.bias,
+                                      fz.weight, fz.bias, k1.to(dev), k2.to(dev), b1.fc_bn, b2.fc_bn, 1.25, 1.25)
+        else:
+            bn = b1.fc_bn
+            y1 = ops.BnReluDrop.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, k1.to(dev), training, bn.eps, 0.1, 1.25,
+                                      bn.num_batches_tracked if training else None)
+            z = ops.linear(b2(y1, k2.to(dev)), fz.weight, fz.bias)
+        z.backward(gz.to(dev))
+        res.append({"z": z.detach(), "dx": x.grad, "bn1.g": b1.fc_bn.weight.grad, "bn1.b": b1.fc_bn.bias.grad,
+                    "w2": b2.fc1.weight.grad, "b2": b2.fc1.bias.grad, "bn2.g": b2.fc_bn.weight.grad, "bn2.b": b2.fc_bn.bias.grad,
+                    "wz": fz.weight.grad, "bz": fz.bias.grad, "rm1": b1.fc_bn.running_mean, "rv1": b1.fc_bn.running_var,
+                    "rm2": b2.fc_bn.running_mean, "rv2": b2.fc_bn.running_var})
+        assert int(b1.fc_bn.num_batches_tracked) == int(training) and int(b2.fc_bn.num_batches_tracked) == int(training)
+    for k in res[0]:      # a Linear bias in front of a train-mode BatchNorm has a zero gradient: rounding noise of the weight gradient's scale
+        floor = float(res[1]["w2"].abs().max()) if (k == "b2" and training) else 1e-6
+        assert rel_err(res[0][k], res[1][k], floor=floor) < 1e-5, k
+    # fp64 oracle of the same chain
+    b1, b2, fz = build()
+    o2 = FcBlock(h1, h2, drop_p=0.2).double()
+    o2.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in b2.state_dict().items()})
+    bn1 = torch.nn.BatchNorm1d(h1).double()
+    bn1.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in b1.fc_bn.state_dict().items()})
+    bn1.train(training); o2.train(training)
+    x64 = lin1.double().requires_grad_(True)
+    y1 = F.relu(bn1(x64)) * k1.double() * 1.25
+    lin2 = F.linear(y1, o2.fc1.weight, o2.fc1.bias)
+    y2 = F.relu(o2.fc_bn(lin2)) * k2.double() * 1.25
+    z64 = F.linear(y2, fz.weight.double(), fz.bias.double())
+    z64.backward(gz.double())
+    assert rel_err(res[0]["z"], z64) < 1e-4
+    assert rel_err(res[0]["dx"], x64.grad, floor=1e-6) < 1e-3
+    assert not ops.mlp_tail_supported(33, 128, 128, 64) and not ops.mlp_tail_supported(32, 256, 256, 128)
+
+
 def test_dense_block_counts_batches(dev):
     """BatchNorm1d.num_batches_tracked is advanced by the fused kernel (training mode only), as the module's forward does."""
     from driving_dirty_amd.components import DenseBlock
