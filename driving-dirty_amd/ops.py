@@ -684,6 +684,37 @@ class BceWithLogits(torch.autograd.Function):
         return dz * g, None
 
 
+class BceWithLogitsProbs(torch.autograd.Function):
+    """(mean BCE-with-logits, sigmoid(logits)) from ONE pass over the logits: the roadmap step needs both
+    (roadmap_bce_v2.py:81 and :106) and the separate sigmoid kernel would read the 82 MB of logits a second time.
+    The probabilities carry no gradient (the reference takes the loss from the logits)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _dev(logits, "logits")
+        n = logits.numel()
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        probs = torch.empty_like(logits)
+        dz = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        if not target.is_cuda or not target.is_contiguous() or target.shape != logits.shape:
+            raise _lib.HotpathError(f"bce: target must be a contiguous GPU tensor of shape {tuple(logits.shape)}")
+        if target.dtype in (torch.bool, torch.uint8):
+            check(_lib.lib().dd_bce_logits_u8(_p(logits), _p(target), _p(loss), _p(dz), _p(probs), n, 1.0,
+                                              _p(_loss_ws(n, logits.device)), _stream()), "dd_bce_logits_u8")
+        else:
+            _dev(target, "target", logits.shape)
+            check(_lib.lib().dd_bce_logits(_p(logits), _p(target), _p(loss), _p(dz), _p(probs), n, 1.0,
+                                           _p(_loss_ws(n, logits.device)), _stream()), "dd_bce_logits")
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(probs)
+        return loss, probs
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None
+
+
 class MseLoss(torch.autograd.Function):
     """mean((pred - target)^2) (autoencoder.py:91; symmetric in its arguments)."""
 

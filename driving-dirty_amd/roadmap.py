@@ -54,25 +54,31 @@ class RoadMapBCE(LightningModule):
             wide4 = ops.stitch6(sample.contiguous())[0]  # gather + NHWC in one pass, no NCHW intermediate
         return self.ae.encoder.forward_nhwc4(wide4, keeps)
 
-    def forward(self, x, keeps=(None, None)):
-        """-> (logits [B,800,800], sigmoid(logits)).  roadmap_bce_v2.py:66-81."""
+    def _logits(self, x, keeps=(None, None)):
         representations = self._encode(x, keeps)
         y = ops.linear(representations, self.fc1.weight, self.fc1.bias)
-        y = y.reshape(y.size(0), 800, 800)
+        return y.reshape(y.size(0), 800, 800)
+
+    def forward(self, x, keeps=(None, None)):
+        """-> (logits [B,800,800], sigmoid(logits)).  roadmap_bce_v2.py:66-81."""
+        y = self._logits(x, keeps)
         return y, ops.sigmoid(y.detach())
 
     def _run_step(self, batch, batch_idx, step_name, keeps=(None, None)):
         sample, target, road_image = batch
         masks = torch.stack(tuple(road_image), dim=0)     # bool as the dataset hands them over (data_helper.py:137-139)
-        pred_rm, pred_logit_rm = self(sample, keeps)     # (logits, probabilities) -- names as in the reference
+        # self(sample) of the reference = (logits, probabilities); here the probabilities come out of the loss kernel's pass
+        # over the logits (same values as forward()'s), which saves reading the 82 MB of logits a second time
+        pred_rm = self._logits(sample, keeps)            # names as in the reference: pred_rm = logits, pred_logit_rm = probabilities
         logging = self.logger is not None and batch_idx % self.hparams.output_img_freq == 0
         # the loss reads the bool masks as bytes; the fp32 copy (roadmap_bce_v2.py:87) is only made where it is looked at
         target_rm = masks.float() if (logging or step_name != "train" or masks.dtype.is_floating_point) else masks
-        if logging:
-            self._log_rm_images(self.wide_stitch_six_images(sample), target_rm, pred_logit_rm, step_name)
         batch_size = masks.size(0)
         loss_target = masks if masks.dtype in (torch.bool, torch.uint8) else target_rm
-        loss = ops.BceWithLogits.apply(pred_rm.reshape(batch_size, -1), loss_target.reshape(batch_size, -1).contiguous())
+        loss, probs = ops.BceWithLogitsProbs.apply(pred_rm.reshape(batch_size, -1), loss_target.reshape(batch_size, -1).contiguous())
+        pred_logit_rm = probs.reshape(batch_size, 800, 800)
+        if logging:
+            self._log_rm_images(self.wide_stitch_six_images(sample), target_rm, pred_logit_rm, step_name)
         return loss, target_rm, pred_rm, pred_logit_rm
 
     def _log_rm_images(self, x, target_rm, pred_rm, step_name, limit=1):

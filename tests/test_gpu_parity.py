@@ -376,6 +376,12 @@ def test_losses(dev, n):
     assert torch.equal(lb.detach(), loss.detach()) and torch.equal(zb.grad, zd.grad)
     if n % 4 == 0:
         assert torch.equal(ops.sigmoid(zd.detach()), probs)
+    # loss and probabilities from one pass (what the roadmap step uses): the same bits as the two separate kernels
+    zp = z.detach().float().to(dev).requires_grad_(True)
+    lp, pp = ops.BceWithLogitsProbs.apply(zp, t.bool().to(dev))
+    (lp * 2.0).backward()
+    assert torch.equal(lp.detach(), loss.detach()) and torch.equal(zp.grad, zd.grad) and torch.equal(pp, probs)
+    assert not pp.requires_grad
     a = hu((n,), "a").double().requires_grad_(True)
     refm = F.mse_loss(t, a)
     refm.backward()
