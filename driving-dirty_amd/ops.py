@@ -393,6 +393,17 @@ MFMA_PHASE_HOOKS = []
 FUSE_C1_WGRAD = os.environ.get("DD_FUSE_C1_WGRAD", "1") != "0"
 
 
+_PACK_STREAMS = {}
+
+
+def _pack_stream(device):
+    """Side stream for the weight-image packs of EncoderConvStack (one per device)."""
+    key = torch.device(device).index
+    if key not in _PACK_STREAMS:
+        _PACK_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _PACK_STREAMS[key]
+
+
 # ------------------------------------------------------------------------------------------------ encoder conv stack
 class EncoderConvStack(torch.autograd.Function):
     """c1 -> ReLU -> c2 -> ReLU -> c3 (stride 2) -> ReLU [-> NCHW-order max_pool1d(4)] as one autograd node.
@@ -411,29 +422,46 @@ class EncoderConvStack(torch.autograd.Function):
         d1 = conv_desc(b, h, w, 3, 1, rows_per_task)
         d2 = conv_desc(b, h, w, 32, 1, rows_per_task)
         d3 = conv_desc(b, h, w, 32, 2, rows_per_task)
-        # c1 / c2 also emit their ReLU signs as bit planes (60 MB instead of 1.9 GB to re-read in the backward)
-        a1, s1 = conv_fwd_bits(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
-        if WINOGRAD and WINOGRAD_2D:
-            a2, s2 = conv_wino2_fwd_bits(a1, conv_wino2_pack(w2, d2, 0), b2, d2)
-        elif WINOGRAD:
-            a2, s2 = conv_wino_fwd_bits(a1, conv_wino_pack(w2, d2, 0), b2, d2)
-        else:
-            a2, s2 = conv_fwd_bits(a1, conv_pack(w2, d2, PACK_FWD), b2, d2)
-        a3 = conv_fwd(a2, conv_pack(w3, d3, PACK_FWD), b3, d3)
-        # The backward's operand images are packed HERE: the weights do not change before the backward, and in the
-        # backward these tiny kernels sit on the critical path behind the optimizer pass that overlaps it (measured:
-        # 4 us alone, up to 390 us squeezed between Adam's workgroups).
+        # Operand images.  Only c1's is needed at once; the other four (c2 / c3 forward, and the backward's two: the weights do
+        # not change before the backward, where these tiny kernels would sit on the critical path behind the optimizer pass
+        # that overlaps it -- 4 us alone, up to 390 us squeezed between Adam's workgroups) are packed on a side stream
+        # while c1's forward runs: five 5-us launches less on the critical path.
         need = ctx.needs_input_grad               # (x4, w1, b1, w2, b2, w3, b3, ...)
-        p2d = p3d = torch.empty(0, device=x4.device)
-        if need[1] or need[2] or need[3] or need[4]:
-            p3d = conv_pack(w3, d3, PACK_DGRAD_S2)
-        if need[1] or need[2]:
+        p1 = conv_pack(w1, d1, PACK_FWD)
+        main = torch.cuda.current_stream()
+        side = _pack_stream(x4.device)
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
             if WINOGRAD and WINOGRAD_2D:
-                p2d = conv_wino2_pack(w2, d2, 1)
+                p2 = conv_wino2_pack(w2, d2, 0)
             elif WINOGRAD:
-                p2d = conv_wino_pack(w2, d2, 1)
+                p2 = conv_wino_pack(w2, d2, 0)
             else:
-                p2d = conv_pack(w2, d2, PACK_DGRAD_S1)
+                p2 = conv_pack(w2, d2, PACK_FWD)
+            p3 = conv_pack(w3, d3, PACK_FWD)
+            p2d = p3d = torch.empty(0, device=x4.device)
+            if need[1] or need[2] or need[3] or need[4]:
+                p3d = conv_pack(w3, d3, PACK_DGRAD_S2)
+            if need[1] or need[2]:
+                if WINOGRAD and WINOGRAD_2D:
+                    p2d = conv_wino2_pack(w2, d2, 1)
+                elif WINOGRAD:
+                    p2d = conv_wino_pack(w2, d2, 1)
+                else:
+                    p2d = conv_pack(w2, d2, PACK_DGRAD_S1)
+            for t in (p2, p3, p2d, p3d):
+                t.record_stream(main)             # allocated under the side stream, consumed on the main one
+            packed_ready = side.record_event()
+        # c1 / c2 also emit their ReLU signs as bit planes (60 MB instead of 1.9 GB to re-read in the backward)
+        a1, s1 = conv_fwd_bits(x4, p1, b1, d1)
+        main.wait_event(packed_ready)
+        if WINOGRAD and WINOGRAD_2D:
+            a2, s2 = conv_wino2_fwd_bits(a1, p2, b2, d2)
+        elif WINOGRAD:
+            a2, s2 = conv_wino_fwd_bits(a1, p2, b2, d2)
+        else:
+            a2, s2 = conv_fwd_bits(a1, p2, b2, d2)
+        a3 = conv_fwd(a2, p3, b3, d3)
         ctx.wino = (bool(WINOGRAD), bool(WINOGRAD and WINOGRAD_2D))
         ctx.pool = int(pool)                  # 0: conv feature, 1: pooled vector, 2: both (joint roadmap + box model)
         ctx.rows_per_task = rows_per_task
@@ -707,11 +735,14 @@ class BceWithLogitsProbs(torch.autograd.Function):
                                            _p(_loss_ws(n, logits.device)), _stream()), "dd_bce_logits")
         ctx.save_for_backward(dz)
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)      # no 82 MB of zeros for the probabilities' (unused) gradient slot
         return loss, probs
 
     @staticmethod
     def backward(ctx, g, _gp):
         (dz,) = ctx.saved_tensors
+        if g is None:
+            return None, None
         return dz * g, None
 
 
