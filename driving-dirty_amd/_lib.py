@@ -112,6 +112,8 @@ SIGNATURES = {
     "dd_conv_wino2_dgrad_w1": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _DP, _p]),
     "dd_conv_wino2_wgrad_workspace_bytes": (_i64, [_p]),
     "dd_conv_wino2_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
+    "dd_conv_wino2_wgrad_partials": (_i32, [_p, _p, _p, _i64, _DP, _p]),
+    "dd_conv_wino2_wgrad_finish": (_i32, [_p, _i64, _p, _p, _DP, _p]),
     "dd_conv_wino_wgrad_workspace_bytes": (_i64, [_p]),
     "dd_conv_wino_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "dd_stitch6_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _p]),

@@ -2004,31 +2004,56 @@ int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d) {
   return ((int64_t)4 * DD_NUM_CU * ((int64_t)16 * 1024 + 64) + 16 * 16 * 1024) * 4;      // per-wave partials (16 accumulators) + 16 chunk sums
 }
 
-int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,
-                        const dd_conv_desc* d, void* stream) {
+namespace {
+int wino2_wgrad_grid(const dd_conv_desc* d) {
+  return resident_grid(d, (long)d->batch * ((d->width + 31) / 32) * ((d->height + 1) / 2), 4, 1);
+}
+}  // namespace
+
+int dd_conv_wino2_wgrad_partials(const float* x, const float* dy, void* workspace, int64_t workspace_bytes, const dd_conv_desc* d,
+                                 void* stream) {
   if (int rc = check_desc(d)) return rc;
-  DD_REQUIRE(x && dy && dw_oihw && dbias && workspace, DD_ERR_BAD_ARG, "conv_wino2_wgrad: NULL pointer");
+  DD_REQUIRE(x && dy && workspace, DD_ERR_BAD_ARG, "conv_wino2_wgrad: NULL pointer");
   DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
   DD_REQUIRE(workspace_bytes >= dd_conv_wino2_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wino2_wgrad: workspace %ld < %ld bytes",
              (long)workspace_bytes, (long)dd_conv_wino2_wgrad_workspace_bytes(d));
-  hipStream_t st = (hipStream_t)stream;
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
-  const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
-  const int nw = grid;      // one partial per WORKGROUP (its four waves are added in LDS)
+  const int grid = wino2_wgrad_grid(d);      // one partial per WORKGROUP (its four waves are added in LDS)
   float* part = (float*)workspace;
-  float* bpart = part + (size_t)nw * 16 * 1024;
-  float* tsum = bpart + (size_t)nw * 64;
+  float* bpart = part + (size_t)grid * 16 * 1024;
   auto k = conv_wino2_wgrad<WPB>;
   const size_t lds = max((size_t)WPB * (4 * StripCfg<32, 1>::SLOTB + StripCfg<32, 1>::SPILLB), (size_t)2 * W2W_STAGE4 * 16);
   if (int rc = allow_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, (hipStream_t)stream, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
   DD_LAUNCH_CHECK("conv_wino2_wgrad");
+  return 0;
+}
+
+int dd_conv_wino2_wgrad_finish(void* workspace, int64_t workspace_bytes, float* dw_oihw, float* dbias, const dd_conv_desc* d,
+                               void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DD_REQUIRE(workspace && dw_oihw && dbias, DD_ERR_BAD_ARG, "conv_wino2_wgrad_finish: NULL pointer");
+  DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
+  DD_REQUIRE(workspace_bytes >= dd_conv_wino2_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wino2_wgrad_finish: workspace %ld < %ld bytes",
+             (long)workspace_bytes, (long)dd_conv_wino2_wgrad_workspace_bytes(d));
+  hipStream_t st = (hipStream_t)stream;
+  const int nw = wino2_wgrad_grid(d);
+  float* part = (float*)workspace;
+  float* bpart = part + (size_t)nw * 16 * 1024;
+  float* tsum = bpart + (size_t)nw * 64;
   hipLaunchKernelGGL(conv_wino2_wgrad_reduce_a, dim3(256), dim3(1024), 0, st, part, tsum, nw);
   DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce_a");
   hipLaunchKernelGGL(conv_wino2_wgrad_reduce_b, dim3(17), dim3(1024), 0, st, tsum, bpart, dw_oihw, dbias, nw);
   DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce_b");
   return 0;
+}
+
+int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,
+                        const dd_conv_desc* d, void* stream) {
+  DD_REQUIRE(dw_oihw && dbias, DD_ERR_BAD_ARG, "conv_wino2_wgrad: NULL pointer");
+  if (int rc = dd_conv_wino2_wgrad_partials(x, dy, workspace, workspace_bytes, d, stream)) return rc;
+  return dd_conv_wino2_wgrad_finish(workspace, workspace_bytes, dw_oihw, dbias, d, stream);
 }
 
 int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace, int64_t workspace_bytes,

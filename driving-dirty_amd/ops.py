@@ -265,7 +265,7 @@ def conv_wino2_dgrad_w1(dy, packed, bits, x4, desc):
     return dw, db
 
 
-def conv_wino2_wgrad(x, dy, desc):
+def conv_wino2_wgrad(x, dy, desc, finish_stream=None):
     _dev(x, "x", (desc.batch, desc.height, desc.width, 32))
     _dev(dy, "dy", (desc.batch, desc.height, desc.width, 32))
     nbytes = _lib.lib().dd_conv_wino2_wgrad_workspace_bytes(C.byref(desc))
@@ -274,8 +274,20 @@ def conv_wino2_wgrad(x, dy, desc):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     dw = torch.empty((32, 32, 3, 3), device=x.device, dtype=torch.float32)
     db = torch.empty(32, device=x.device, dtype=torch.float32)
-    check(_lib.lib().dd_conv_wino2_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, C.byref(desc), _stream()), "dd_conv_wino2_wgrad")
-    return dw, db
+    if finish_stream is None:
+        check(_lib.lib().dd_conv_wino2_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, C.byref(desc), _stream()), "dd_conv_wino2_wgrad")
+        return dw, db
+    # the two reduce kernels go to `finish_stream` (beside whatever the caller launches next); the caller's stream has to
+    # wait for the returned event before it reads dw / db
+    main = torch.cuda.current_stream()
+    check(_lib.lib().dd_conv_wino2_wgrad_partials(_p(x), _p(dy), _p(ws), nbytes, C.byref(desc), _stream()), "dd_conv_wino2_wgrad_partials")
+    finish_stream.wait_event(main.record_event())
+    with torch.cuda.stream(finish_stream):
+        for t in (ws, dw, db):
+            t.record_stream(finish_stream)
+        check(_lib.lib().dd_conv_wino2_wgrad_finish(_p(ws), nbytes, _p(dw), _p(db), C.byref(desc), _stream()), "dd_conv_wino2_wgrad_finish")
+        done = finish_stream.record_event()
+    return dw, db, done
 
 
 def conv_wino_wgrad(x, dy, desc):
@@ -508,9 +520,10 @@ class EncoderConvStack(torch.autograd.Function):
             del g3
             for hook in MFMA_PHASE_HOOKS:
                 hook()
+            reduced = None
             if need[3] or need[4]:
-                if wino2:
-                    dw2, db2 = conv_wino2_wgrad(a1, g2, d2)
+                if wino2:      # the reduce of the partials runs on the side stream, beside c2's data gradient
+                    dw2, db2, reduced = conv_wino2_wgrad(a1, g2, d2, finish_stream=_pack_stream(g2.device))
                 elif wino:
                     dw2, db2 = conv_wino_wgrad(a1, g2, d2)
                 else:
@@ -527,6 +540,8 @@ class EncoderConvStack(torch.autograd.Function):
                     g1 = conv_dgrad_bits(g2, p2d, s1, d2)
                 del g2
                 dw1, db1 = conv_wgrad(x4, g1, d1)
+            if reduced is not None:
+                torch.cuda.current_stream().wait_event(reduced)
         return None, dw1, db1, dw2, db2, dw3, db3, None, None
 
 

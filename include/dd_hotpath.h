@@ -386,6 +386,12 @@ int dd_conv_wino2_dgrad_w1(const float* dy, const float* packed, const uint32_t*
 int64_t dd_conv_wino2_wgrad_workspace_bytes(const dd_conv_desc* d);
 int dd_conv_wino2_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
                         int64_t workspace_bytes, const dd_conv_desc* d, void* stream);
+/* The same in two calls, so that the second (two small reduce kernels over the per-workgroup partials in `workspace`) can
+ * run on another stream beside whatever follows the first: nothing in the backward waits for dW. */
+int dd_conv_wino2_wgrad_partials(const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
+                                 const dd_conv_desc* d, void* stream);
+int dd_conv_wino2_wgrad_finish(void* workspace, int64_t workspace_bytes, float* dw_oihw, float* dbias,
+                               const dd_conv_desc* d, void* stream);
 /* weight + bias gradient of the same layer by F(3,2) along x (as dd_conv_wgrad: deterministic two-stage reduction) */
 int64_t dd_conv_wino_wgrad_workspace_bytes(const dd_conv_desc* d);
 int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, void* workspace,
