@@ -8,7 +8,10 @@ loss), long before the conv data/weight-gradient kernels where the FLOPs are.  S
 
   * a gradient of >= ``big_numel`` elements is all-reduced by itself, asynchronously, the moment autograd
     has accumulated it (post-accumulate-grad hook): no flat copy, no bucket fill, and the collective runs
-    on RCCL's stream underneath the remaining backward kernels;
+    on RCCL's stream underneath the remaining backward kernels.  It goes out in pieces of ``chunk_numel``
+    elements (128 MB), in order, so that the optimizer pass of piece k (HipAdam waits per piece on its side
+    stream) runs while piece k+1 is still on the links: only the last piece's update is left after the
+    last byte has arrived, not the whole tensor's;
   * everything else (a few hundred KB) is flattened into one buffer and reduced once at ``finish()``;
   * the sum is NOT divided here: ``HipAdam.step(grad_scale=1/world)`` folds the average into its pass.
 
@@ -20,10 +23,11 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, module, process_group=None, big_numel=1 << 20):
+    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.big_numel = big_numel
+        self.chunk_numel = max(4, chunk_numel - chunk_numel % 4)      # pieces start on 16-byte boundaries
         self.params = [p for p in module.parameters()]
         self._handles = []
         self._by_param = {}
@@ -40,17 +44,29 @@ class GradSync:
     def _on_grad(self, p):
         if p.grad is None:
             return
-        if p.grad.numel() >= self.big_numel:
+        if p.grad.numel() >= self.big_numel and p.grad.is_contiguous():
+            flat = p.grad.view(-1)
+            pieces = []
+            for off in range(0, flat.numel(), self.chunk_numel):
+                n = min(self.chunk_numel, flat.numel() - off)
+                work = dist.all_reduce(flat[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._handles.append(work)
+                pieces.append((work, off, n))
+            self._by_param[p] = pieces
+        elif p.grad.numel() >= self.big_numel:
             work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._handles.append(work)
-            self._by_param[p] = work
+            self._by_param[p] = [(work, 0, p.grad.numel())]
         else:
             self._small.append(p)
 
+    def pieces(self, p):
+        """[(work, offset, numel), ...] of the in-flight all-reduce of ``p`` in issue order (None: p went the small-tensor way)."""
+        return self._by_param.get(p)
+
     def wait_param(self, p):
-        """Make the CURRENT stream wait for the all-reduce of ``p`` (no-op when p went the small-tensor way)."""
-        work = self._by_param.get(p)
-        if work is not None:
+        """Make the CURRENT stream wait for the whole all-reduce of ``p`` (no-op when p went the small-tensor way)."""
+        for work, _, _ in self._by_param.get(p) or ():
             work.wait()
 
     def finish(self):

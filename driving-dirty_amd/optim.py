@@ -31,6 +31,23 @@ class HipAdam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
 
+    def _update_pieces(self, p, group, grad_scale, pieces):
+        """The update of a tensor whose all-reduce travels in pieces: wait (on the current stream) for piece k, update that
+        slice, go on -- the pass over piece k runs while piece k+1 is still on the links."""
+        st = self._state_of(p)
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        if not (p.grad.is_contiguous() and p.data.is_contiguous()):
+            for work, _, _ in pieces:
+                work.wait()
+            st["step"] -= 1
+            return self._update(p, group, grad_scale)
+        pf, gf, mf, vf = p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1)
+        for work, off, n in pieces:
+            work.wait()
+            ops.adam_step_flat(pf[off:off + n], gf[off:off + n], mf[off:off + n], vf[off:off + n], group["lr"], b1, b2,
+                               group["eps"], st["step"], grad_scale)
+
     def _update(self, p, group, grad_scale):
         st = self._state_of(p)
         st["step"] += 1
@@ -71,9 +88,11 @@ class HipAdam(torch.optim.Optimizer):
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
             for p, group in self._pending:
-                if self._sync is not None:
-                    self._sync.wait_param(p)      # the side stream (not the host) waits for this tensor's all-reduce
-                self._update(p, group, self._scale)
+                pieces = self._sync.pieces(p) if self._sync is not None else None
+                if pieces:                        # the side stream (not the host) waits for the all-reduce, piece by piece
+                    self._update_pieces(p, group, self._scale, pieces)
+                else:
+                    self._update(p, group, self._scale)
                 self._early.add(p)
         self._pending = []
 

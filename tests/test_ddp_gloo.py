@@ -21,7 +21,7 @@ def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     net = _net()
-    sync = GradSync(net, big_numel=4096)          # Linear(12,2048).weight goes the "big tensor" way
+    sync = GradSync(net, big_numel=4096, chunk_numel=10000)   # Linear(12,2048).weight goes the "big tensor" way, in 3 pieces
     torch.manual_seed(100)
     x, y = torch.randn(8, 12), torch.randn(8, 3)
     xs, ys = x[rank::world], y[rank::world]
@@ -29,6 +29,8 @@ def _worker(rank, world, port, out):
         net.zero_grad(set_to_none=True)
         loss = torch.nn.functional.mse_loss(net(xs), ys, reduction="sum") / x.shape[0] * world
         loss.backward()
+        pieces = sync.pieces(net[0].weight)
+        assert [(o, n) for _, o, n in pieces] == [(0, 10000), (10000, 10000), (20000, 4576)] and sync.pieces(net[0].bias) is None
         sync.finish()
     grads = [p.grad * sync.grad_scale for p in net.parameters()]
     if rank == 0:

@@ -535,6 +535,19 @@ def test_adam_overlapped_with_backward_is_identical(dev):
     from driving_dirty_amd.optim import HipAdam
     from driving_dirty_amd.roadmap import RoadMapBCE
 
+    class Pieces:
+        """Stands in for ddp.GradSync on one process: every big gradient 'arrives' in pieces of 1000 elements."""
+        class Work:
+            def wait(self):
+                pass
+
+        def pieces(self, p):
+            n = p.numel()
+            return [(self.Work(), o, min(1000, n - o)) for o in range(0, n, 1000)] if n >= 1000 else None
+
+        def wait_param(self, p):
+            pass
+
     def run(overlap):
         ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132, output_height=16, output_width=22))
         m = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500))
@@ -542,8 +555,8 @@ def test_adam_overlapped_with_backward_is_identical(dev):
         m = m.to(dev)
         m.ae.encoder.fc1.drop_p = m.ae.encoder.fc2.drop_p = 0.0
         opt = HipAdam(m.parameters(), lr=1e-2)
-        if overlap:
-            opt.overlap_with_backward(big_numel=1000)
+        if overlap:      # 2: the per-piece path the data-parallel run takes (update of piece k while piece k+1 is on the links)
+            opt.overlap_with_backward(big_numel=1000, grad_sync=Pieces() if overlap == 2 else None)
         views = synth.camera_batch(3, 16, 22, seed=23).to(dev)
         road = synth.road_maps(3, seed=23).to(dev)
         for i in range(3):
@@ -553,9 +566,10 @@ def test_adam_overlapped_with_backward_is_identical(dev):
         torch.cuda.synchronize()
         return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
-    a, b = run(False), run(True)
+    a, b, c = run(0), run(1), run(2)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
 
 
 def test_threat_score_and_validation_step(dev):
