@@ -188,12 +188,10 @@ def main():
     from driving_dirty_amd.ddp import GradSync
     from driving_dirty_amd.optim import HipAdam
     _lib.lib()                                            # fail loudly if the HIP library is missing
-    if world > 1:
-        # RCCL's all-reduce workgroups run for milliseconds beside the conv backward and need LDS the conv workgroups
-        # do not leave free: give them their own compute units (and cap RCCL at as many channels) so the conv grids
-        # stay one resident round.  DD_RESERVED_CUS overrides.
-        reserve = int(os.environ.get("DD_RESERVED_CUS", "16"))
-        _lib.check(_lib.lib().dd_set_cu_budget(256 - reserve), "dd_set_cu_budget")
+    # RCCL's all-reduce workgroups run for milliseconds beside the conv backward and need LDS the conv workgroups do not
+    # leave free: GradSync gives them their own compute units (and RCCL is capped at as many channels) from the first big
+    # gradient to the end of the step, so the conv grids stay one resident round.  DD_RESERVED_CUS overrides.
+    reserve = int(os.environ.get("DD_RESERVED_CUS", "16")) if world > 1 else 0
     if a.cu_budget:
         _lib.check(_lib.lib().dd_set_cu_budget(a.cu_budget), "dd_set_cu_budget")
 
@@ -209,7 +207,7 @@ def main():
     model.training_step(synthetic_batch(dev, 2, rank), 0)["loss"].backward()   # unfreezes the AE (epoch 0 >= 0)
     model.zero_grad(set_to_none=True)
     opt = HipAdam(model.parameters(), lr=1e-3)
-    sync = GradSync(model)
+    sync = GradSync(model, reserve_cus=reserve)
     if not a.no_adam_overlap:
         opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if world > 1 else None)
     batch = synthetic_batch(dev, BATCH, rank)

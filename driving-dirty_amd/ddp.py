@@ -23,11 +23,16 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25):
+    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25, reserve_cus=0):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.big_numel = big_numel
         self.chunk_numel = max(4, chunk_numel - chunk_numel % 4)      # pieces start on 16-byte boundaries
+        # RCCL's workgroups need compute units the resident conv grids do not leave: while collectives are in flight (from
+        # the first big gradient to finish()) the conv kernels are launched on 256 - reserve_cus units; the forward, which
+        # runs beside no collective, keeps the whole GPU.
+        self.reserve_cus = int(reserve_cus) if self.world > 1 else 0
+        self._reserved = False
         self.params = [p for p in module.parameters()]
         self._handles = []
         self._by_param = {}
@@ -44,6 +49,9 @@ class GradSync:
     def _on_grad(self, p):
         if p.grad is None:
             return
+        if p.grad.numel() >= self.big_numel and self.reserve_cus and not self._reserved:
+            self._set_budget(256 - self.reserve_cus)
+            self._reserved = True
         if p.grad.numel() >= self.big_numel and p.grad.is_contiguous():
             flat = p.grad.view(-1)
             pieces = []
@@ -82,6 +90,14 @@ class GradSync:
         for h in self._handles:
             h.wait()
         self._handles, self._small, self._by_param = [], [], {}
+        if self._reserved:
+            self._set_budget(256)
+            self._reserved = False
+
+    @staticmethod
+    def _set_budget(cus):
+        from . import _lib
+        _lib.check(_lib.lib().dd_set_cu_budget(cus), "dd_set_cu_budget")
 
     def remove(self):
         for h in self._hooks:
