@@ -1486,47 +1486,43 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
 //     row per wave, 64 KB apart: 0.57 TB/s) -> tsum[c][p][r][64]
 //  b) one block per register row r (+ one for the bias): sum of the 16 chunks, output transform A^T S A, scatter to OIHW.
 constexpr int W2R_CHUNKS = 16;
-__global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_a(const float* __restrict__ part, float* __restrict__ tsum, int nw) {
-  __shared__ f32x4 red[4][256];
-  const int f = threadIdx.x & 255, sub = threadIdx.x >> 8;
+// 256-thread blocks (and 64-thread ones in reduce_b): these run on a side stream beside resident kernels that hold most wave
+// slots of every CU -- a 1024-thread block then waits for a whole CU's worth of them (measured: 1.3 ms in the queue).
+__global__ __launch_bounds__(256) void conv_wino2_wgrad_reduce_a(const float* __restrict__ part, float* __restrict__ tsum, int nw) {
+  const int f = threadIdx.x;
   const int p = blockIdx.x & 15, c = blockIdx.x >> 4;
   const int per = (nw + W2R_CHUNKS - 1) / W2R_CHUNKS;
   const int w0 = c * per, w1 = min(nw, w0 + per);
   const f32x4* src = (const f32x4*)part + (long)p * 256 + f;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-  int w = w0 + sub;
-  for (; w + 4 < w1; w += 8) {
-    const f32x4 a0 = src[(long)w * 4096], a1 = src[(long)(w + 4) * 4096];
-    s0 += a0;
-    s1 += a1;
+  f32x4 s[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int w = w0;
+  for (; w + 3 < w1; w += 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] += src[(long)(w + i) * 4096];
   }
-  if (w < w1) s0 += src[(long)w * 4096];
-  red[sub][f] = s0 + s1;
-  __syncthreads();
-  if (sub != 0) return;
-  ((f32x4*)tsum)[((long)c * 16 + p) * 256 + f] = (red[0][f] + red[1][f]) + (red[2][f] + red[3][f]);
+  for (int i = 0; w < w1; ++w, ++i) s[i] += src[(long)w * 4096];
+  ((f32x4*)tsum)[((long)c * 16 + p) * 256 + f] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
-__global__ __launch_bounds__(1024) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
-                                                                  float* __restrict__ dw, float* __restrict__ db, int nw) {
-  constexpr int G = 16;
-  __shared__ float red[G][64];
-  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+__global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
+                                                                float* __restrict__ dw, float* __restrict__ db, int nw) {
+  const int l = threadIdx.x;
   const int r = blockIdx.x;   // accumulator register row, or 16 for the bias
   if (r == 16) {
-    float s0 = 0.f;
-    for (int w = g; w < nw; w += G) s0 += bpart[(long)w * 64 + l];
-    red[g][l] = s0;
-    __syncthreads();
-    if (g != 0) return;
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 3 < nw; w += 4) {
 #pragma unroll
-    for (int i = 0; i < G; ++i) s += red[i][l];
-    const float other = __shfl_xor(s, 32);
-    if (l < 32) db[l] = s + other;
+      for (int i = 0; i < 4; ++i) s[i] += bpart[(long)(w + i) * 64 + l];
+    }
+    for (int i = 0; w < nw; ++w, ++i) s[i] += bpart[(long)w * 64 + l];
+    const float t = (s[0] + s[1]) + (s[2] + s[3]);
+    const float other = __shfl_xor(t, 32);
+    if (l < 32) db[l] = t + other;
     return;
   }
-  if (g != 0) return;
   float t[4][4];
 #pragma unroll
   for (int p = 0; p < 16; ++p)      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
@@ -2042,9 +2038,9 @@ int dd_conv_wino2_wgrad_finish(void* workspace, int64_t workspace_bytes, float* 
   float* part = (float*)workspace;
   float* bpart = part + (size_t)nw * 16 * 1024;
   float* tsum = bpart + (size_t)nw * 64;
-  hipLaunchKernelGGL(conv_wino2_wgrad_reduce_a, dim3(256), dim3(1024), 0, st, part, tsum, nw);
+  hipLaunchKernelGGL(conv_wino2_wgrad_reduce_a, dim3(256), dim3(256), 0, st, part, tsum, nw);
   DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce_a");
-  hipLaunchKernelGGL(conv_wino2_wgrad_reduce_b, dim3(17), dim3(1024), 0, st, tsum, bpart, dw_oihw, dbias, nw);
+  hipLaunchKernelGGL(conv_wino2_wgrad_reduce_b, dim3(17), dim3(64), 0, st, tsum, bpart, dw_oihw, dbias, nw);
   DD_LAUNCH_CHECK("conv_wino2_wgrad_reduce_b");
   return 0;
 }
