@@ -179,6 +179,12 @@ __device__ __forceinline__ void sigmoid_softplus(float z, float& sig, float& l1p
   l1p = d == 0.f ? e : (__builtin_amdgcn_logf(u) * 0.6931471805599453f) * (e * __builtin_amdgcn_rcpf(d));
 }
 
+// The road masks as the collate hands them over: a TUPLE of per-sample bool tensors (helper.py:22-23), which the reference
+// stacks (and casts) first (roadmap_bce_v2.py:87).  Reading through a table of per-sample pointers skips that copy.
+struct MaskPtrs {
+  const unsigned char* p[64];      // by value in the kernel arguments
+  long per;                        // elements per sample (a multiple of 4)
+};
 template <typename TT>
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const TT* __restrict__ t,
                                                          float* __restrict__ dz, float* __restrict__ probs,
@@ -207,6 +213,32 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
     s += fmaxf(z[i], 0.f) - z[i] * ti + l1p;
     if (dz) dz[i] = (sig - ti) * gscale;
     if (probs) probs[i] = sig;
+  }
+  const double tot = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void bce_logits_ptrs_kernel(const float* __restrict__ z, const MaskPtrs tab, float* __restrict__ dz,
+                                                              float* __restrict__ probs, double* __restrict__ partial, long n,
+                                                              float gscale) {
+  float s = 0.f;
+  const long n4 = n / 4;      // n = batch * tab.per, per % 4 == 0: no tail, a float4 never straddles two samples
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long e = 4 * i, b = e / tab.per;
+    const unsigned w = *(const unsigned*)(tab.p[b] + (e - b * tab.per));
+    const f32x4 zv = ((const f32x4*)z)[i];
+    const f32x4 tv = {(float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24)};
+    f32x4 g, p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float sig, l1p;
+      sigmoid_softplus(zv[k], sig, l1p);
+      s += fmaxf(zv[k], 0.f) - zv[k] * tv[k] + l1p;
+      p[k] = sig;
+      g[k] = (sig - tv[k]) * gscale;
+    }
+    if (dz) ((f32x4*)dz)[i] = g;
+    if (probs) ((f32x4*)probs)[i] = p;
   }
   const double tot = block_sum(s);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -434,6 +466,27 @@ int dd_bce_logits_u8(const float* logits, const unsigned char* target, float* lo
   DD_LAUNCH_CHECK("bce_logits_u8");
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid,
                      1.0 / (double)n, loss_out);
+  DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_bce_logits_u8_ptrs(const float* logits, const unsigned char* const* target_ptrs, int32_t batch, int64_t per_sample,
+                          float* loss_out, float* dlogits, float* probs, float grad_scale, void* workspace, void* stream) {
+  DD_REQUIRE(logits && target_ptrs && loss_out && workspace && batch > 0 && per_sample > 0, DD_ERR_BAD_ARG, "bce_logits_u8_ptrs: bad argument");
+  DD_REQUIRE(batch <= 64 && per_sample % 4 == 0, DD_ERR_UNSUPPORTED, "bce_logits_u8_ptrs: up to 64 samples of a multiple of 4 elements (got %d x %ld)",
+             batch, (long)per_sample);
+  DD_REQUIRE(((uintptr_t)logits | (uintptr_t)dlogits | (uintptr_t)probs) % 16 == 0, DD_ERR_BAD_ARG, "bce_logits_u8_ptrs: misaligned buffer");
+  MaskPtrs tab;
+  tab.per = per_sample;
+  for (int i = 0; i < 64; ++i) tab.p[i] = i < batch ? target_ptrs[i] : nullptr;
+  for (int i = 0; i < batch; ++i)
+    DD_REQUIRE(tab.p[i] && (uintptr_t)tab.p[i] % 4 == 0, DD_ERR_BAD_ARG, "bce_logits_u8_ptrs: sample %d: NULL or misaligned mask", i);
+  const int64_t n = (int64_t)batch * per_sample;
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)kLossBlocks);
+  hipLaunchKernelGGL(bce_logits_ptrs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, tab, dlogits, probs, (double*)workspace,
+                     (long)n, grad_scale / (float)n);
+  DD_LAUNCH_CHECK("bce_logits_u8_ptrs");
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid, 1.0 / (double)n, loss_out);
   DD_LAUNCH_CHECK("loss_final");
   return 0;
 }

@@ -734,11 +734,25 @@ class BceWithLogitsProbs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, target):
+        """``target``: a tensor of the logits' shape, or the collate's TUPLE of per-sample bool / uint8 masks (read through
+        a pointer table: no torch.stack copy)."""
         _dev(logits, "logits")
         n = logits.numel()
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         probs = torch.empty_like(logits)
         dz = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        if isinstance(target, (tuple, list)):
+            b, per = len(target), n // max(len(target), 1)
+            for t in target:
+                if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.bool, torch.uint8) and t.numel() == per):
+                    raise _lib.HotpathError("bce: per-sample masks must be contiguous bool / uint8 GPU tensors of logits.numel() / batch elements")
+            table = (C.c_void_p * b)(*[t.data_ptr() for t in target])
+            check(_lib.lib().dd_bce_logits_u8_ptrs(_p(logits), table, b, per, _p(loss), _p(dz), _p(probs), 1.0,
+                                                   _p(_loss_ws(n, logits.device)), _stream()), "dd_bce_logits_u8_ptrs")
+            ctx.save_for_backward(dz)
+            ctx.mark_non_differentiable(probs)
+            ctx.set_materialize_grads(False)
+            return loss, probs
         if not target.is_cuda or not target.is_contiguous() or target.shape != logits.shape:
             raise _lib.HotpathError(f"bce: target must be a contiguous GPU tensor of shape {tuple(logits.shape)}")
         if target.dtype in (torch.bool, torch.uint8):

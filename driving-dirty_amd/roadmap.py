@@ -66,11 +66,20 @@ class RoadMapBCE(LightningModule):
 
     def _run_step(self, batch, batch_idx, step_name, keeps=(None, None)):
         sample, target, road_image = batch
-        masks = torch.stack(tuple(road_image), dim=0)     # bool as the dataset hands them over (data_helper.py:137-139)
+        logging = self.logger is not None and batch_idx % self.hparams.output_img_freq == 0
+        per_sample = tuple(road_image)
+        if (step_name == "train" and not logging and 0 < len(per_sample) <= 64 and
+                all(t.is_cuda and t.is_contiguous() and t.dtype in (torch.bool, torch.uint8) and t.numel() % 4 == 0 for t in per_sample)):
+            # the training step only needs the masks inside the loss: the kernel reads them where the collate left them
+            # (a pointer table) instead of torch.stack-ing them first (roadmap_bce_v2.py:87)
+            pred_rm = self._logits(sample, keeps)
+            b = len(per_sample)
+            loss, probs = ops.BceWithLogitsProbs.apply(pred_rm.reshape(b, -1), per_sample)
+            return loss, None, pred_rm, probs.reshape(b, 800, 800)
+        masks = torch.stack(per_sample, dim=0)            # bool as the dataset hands them over (data_helper.py:137-139)
         # self(sample) of the reference = (logits, probabilities); here the probabilities come out of the loss kernel's pass
         # over the logits (same values as forward()'s), which saves reading the 82 MB of logits a second time
         pred_rm = self._logits(sample, keeps)            # names as in the reference: pred_rm = logits, pred_logit_rm = probabilities
-        logging = self.logger is not None and batch_idx % self.hparams.output_img_freq == 0
         # the loss reads the bool masks as bytes; the fp32 copy (roadmap_bce_v2.py:87) is only made where it is looked at
         target_rm = masks.float() if (logging or step_name != "train" or masks.dtype.is_floating_point) else masks
         batch_size = masks.size(0)

@@ -240,6 +240,11 @@ int dd_bce_logits(const float* logits, const float* target, float* loss_out, flo
  * handled): skips the .float() pass of roadmap_bce_v2.py:87. */
 int dd_bce_logits_u8(const float* logits, const unsigned char* target, float* loss_out, float* dlogits, float* probs,
                      int64_t n, float grad_scale, void* workspace, void* stream);
+/* The same with the masks as the collate hands them over -- a tuple of per-sample bool tensors (helper.py:22-23), which the
+ * reference stacks first (roadmap_bce_v2.py:87): target_ptrs is a HOST array of `batch` (<= 64) device pointers to
+ * per_sample bytes each (per_sample % 4 == 0); logits / dlogits / probs are [batch * per_sample]. */
+int dd_bce_logits_u8_ptrs(const float* logits, const unsigned char* const* target_ptrs, int32_t batch, int64_t per_sample,
+                          float* loss_out, float* dlogits, float* probs, float grad_scale, void* workspace, void* stream);
 /* probs = sigmoid(logits) (roadmap_bce_v2.py:81), n % 4 == 0 */
 int dd_sigmoid(const float* z, float* p, int64_t n, void* stream);
 /* Mean squared error mean((a-b)^2) with optional da = 2(a-b)*grad_scale/n (autoencoder.py:91). */

@@ -382,6 +382,12 @@ def test_losses(dev, n):
     (lp * 2.0).backward()
     assert torch.equal(lp.detach(), loss.detach()) and torch.equal(zp.grad, zd.grad) and torch.equal(pp, probs)
     assert not pp.requires_grad
+    if n % 8 == 0:      # the masks as the collate's tuple of per-sample tensors (no stack copy): the same bits again
+        zq = z.detach().float().to(dev).requires_grad_(True)
+        halves = tuple(h.contiguous() for h in t.bool().to(dev).reshape(2, -1))
+        lq, pq = ops.BceWithLogitsProbs.apply(zq.reshape(2, -1), halves)
+        (lq * 2.0).backward()
+        assert torch.equal(lq.detach(), loss.detach()) and torch.equal(zq.grad, zd.grad) and torch.equal(pq.reshape(-1), probs)
     a = hu((n,), "a").double().requires_grad_(True)
     refm = F.mse_loss(t, a)
     refm.backward()
