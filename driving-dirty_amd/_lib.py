@@ -80,6 +80,7 @@ SIGNATURES = {
     "dd_bce_logits": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_bce_logits_u8": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_bce_logits_u8_ptrs": (_i32, [_p, _p, _i32, _i64, _p, _p, _p, _f32, _p, _p]),
+    "dd_scale_by_device_scalar": (_i32, [_p, _p, _i64, _p]),
     "dd_sigmoid": (_i32, [_p, _p, _i64, _p]),
     "dd_mse": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_gconv_packed_floats": (_i64, [_GP]),

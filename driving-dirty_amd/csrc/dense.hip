@@ -244,6 +244,17 @@ __global__ __launch_bounds__(256) void bce_logits_ptrs_kernel(const float* __res
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// x *= *s, unless *s == 1 (then nothing is touched).  The losses write their gradient already scaled by 1/n in the forward
+// pass; autograd hands the upstream gradient of the scalar loss over as a device scalar, 1.0 for a plain loss.backward() --
+// which a host-side multiply cannot know without a sync, and so pays a full read-modify-write pass for.
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(f32x4* __restrict__ x, const float* __restrict__ s, long n4, float* __restrict__ tail,
+                                                              int ntail) {
+  const float g = *s;
+  if (g == 1.f) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) x[i] = x[i] * g;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] *= g;
+}
+
 __global__ __launch_bounds__(256) void sigmoid_kernel(const f32x4* __restrict__ z, f32x4* __restrict__ p, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = z[i];
@@ -488,6 +499,16 @@ int dd_bce_logits_u8_ptrs(const float* logits, const unsigned char* const* targe
   DD_LAUNCH_CHECK("bce_logits_u8_ptrs");
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, grid, 1.0 / (double)n, loss_out);
   DD_LAUNCH_CHECK("loss_final");
+  return 0;
+}
+
+int dd_scale_by_device_scalar(float* x, const float* scalar, int64_t n, void* stream) {
+  DD_REQUIRE(x && scalar && n > 0, DD_ERR_BAD_ARG, "scale_by_device_scalar: bad argument");
+  DD_REQUIRE((uintptr_t)x % 16 == 0, DD_ERR_BAD_ARG, "scale_by_device_scalar: buffer must be 16-byte aligned");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)max(1L, min((n4 + 255) / 256, (long)kLossBlocks))), dim3(256), 0, (hipStream_t)stream,
+                     (f32x4*)x, scalar, n4, x + 4 * n4, (int)(n - 4 * n4));
+  DD_LAUNCH_CHECK("scale_by_device_scalar");
   return 0;
 }
 

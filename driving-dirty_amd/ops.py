@@ -700,6 +700,16 @@ def _loss_ws(n, device):
     return torch.empty(_lib.lib().dd_loss_workspace_bytes(n), device=device, dtype=torch.uint8)
 
 
+def _scaled_loss_grad(dz, g):
+    """dz * g for the 0-dim upstream gradient ``g`` of a scalar loss -- in place and skipped on the device when g == 1
+    (dd_scale_by_device_scalar); anything else takes autograd's generic multiply."""
+    if (g.numel() == 1 and g.is_cuda and g.dtype == torch.float32 and dz.is_contiguous() and dz.dtype == torch.float32
+            and dz.data_ptr() % 16 == 0 and not torch.is_grad_enabled()):
+        check(_lib.lib().dd_scale_by_device_scalar(_p(dz), _p(g), dz.numel(), _stream()), "dd_scale_by_device_scalar")
+        return dz
+    return dz * g
+
+
 class BceWithLogits(torch.autograd.Function):
     """mean BCE-with-logits; the gradient is produced by the forward's single pass (roadmap_bce_v2.py:106)."""
 
@@ -724,7 +734,7 @@ class BceWithLogits(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
-        return dz * g, None
+        return _scaled_loss_grad(dz, g), None
 
 
 class BceWithLogitsProbs(torch.autograd.Function):
@@ -772,7 +782,7 @@ class BceWithLogitsProbs(torch.autograd.Function):
         (dz,) = ctx.saved_tensors
         if g is None:
             return None, None
-        return dz * g, None
+        return _scaled_loss_grad(dz, g), None
 
 
 class MseLoss(torch.autograd.Function):
@@ -792,7 +802,7 @@ class MseLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (da,) = ctx.saved_tensors
-        return da * g, None
+        return _scaled_loss_grad(da, g), None
 
 
 class BceProbs(torch.autograd.Function):
@@ -813,7 +823,7 @@ class BceProbs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return dp * g, None
+        return _scaled_loss_grad(dp, g), None
 
 
 def sigmoid(z):

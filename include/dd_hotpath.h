@@ -245,6 +245,11 @@ int dd_bce_logits_u8(const float* logits, const unsigned char* target, float* lo
  * per_sample bytes each (per_sample % 4 == 0); logits / dlogits / probs are [batch * per_sample]. */
 int dd_bce_logits_u8_ptrs(const float* logits, const unsigned char* const* target_ptrs, int32_t batch, int64_t per_sample,
                           float* loss_out, float* dlogits, float* probs, float grad_scale, void* workspace, void* stream);
+/* x[0..n) *= *scalar (a DEVICE float), skipped entirely on the device when *scalar == 1: the upstream gradient of the scalar
+ * loss in `loss.backward()` (roadmap_bce_v2.py:106 / Lightning's backward) is 1, and the loss kernels above have already
+ * written d(loss)/d(input); autograd's generic `grad * dz` would spend a full pass on multiplying by one. */
+int dd_scale_by_device_scalar(float* x, const float* scalar, int64_t n, void* stream);
+
 /* probs = sigmoid(logits) (roadmap_bce_v2.py:81), n % 4 == 0 */
 int dd_sigmoid(const float* z, float* p, int64_t n, void* stream);
 /* Mean squared error mean((a-b)^2) with optional da = 2(a-b)*grad_scale/n (autoencoder.py:91). */

@@ -367,6 +367,10 @@ def test_losses(dev, n):
     (loss * 2.0).backward()
     assert abs(float(loss.detach()) - float(ref.detach())) / float(ref.detach()) < 1e-6
     assert rel_err(zd.grad, 2.0 * z.grad) < KERNEL_TOL
+    # plain loss.backward(): the upstream gradient is 1 and the device-side scaling is skipped -- same numbers, unscaled
+    zu = z.detach().float().to(dev).requires_grad_(True)
+    ops.BceWithLogits.apply(zu, t.float().to(dev)).backward()
+    assert torch.equal(zu.grad * 2.0, zd.grad)
     l2, probs = ops.sigmoid_and_loss(zd.detach(), t.float().to(dev))
     assert rel_err(probs, torch.sigmoid(z)) < KERNEL_TOL
     # bool masks read as bytes: the same arithmetic, so the same bits
