@@ -7,7 +7,7 @@
 //
 // At the roadmap model's sizes (M = 32, H1 = H2 = 128, L = 64) this is ~1 MFLOP, but as separate kernels it is 13
 // launches forward and 8 backward, every one of them bounded below by the ~5.6 us a dependent launch costs: 90 + 144 us
-// of an 8 ms step.  Here one 256-thread workgroup keeps every operand in LDS and walks the chain: plain fp32 FMAs on 4 x 4 register tiles, both GEMM operands
+// of an 8 ms step.  Here one 1024-thread workgroup keeps every operand in LDS and walks the chain: plain fp32 FMAs on 4 x 4 register tiles, both GEMM operands
 // contraction-major in LDS so that 16 FMAs cost two ds_read_b128 (the matrix cores would not notice this much work).  Sums over the batch run in row order, as the stand-alone
 // dd_bn_relu_drop kernels do.  Limits: M <= 32, H1, H2, L <= 128 (the caller falls back to the separate kernels).
 #include <hip/hip_runtime.h>
@@ -18,6 +18,7 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 32, TH = 128;
+constexpr int TAIL_THREADS = 1024;      // one workgroup: the more waves, the more loads in flight per memory round trip
 constexpr int LDF = TH + 4;      // pitch of a row-major tile  [row m][feature]   (float4 along the features)
 constexpr int LDM = TM + 4;      // pitch of a feature-major tile [feature][row m] (float4 along the rows)
 
@@ -44,16 +45,16 @@ struct TailBwd {
 template <bool TR>
 __device__ __forceinline__ void load_tile(float* dst, int ld, const float* src, int rows, int cols, int pad_rows) {
   const int total = pad_rows * cols, valid = rows * cols;
-  for (int base = threadIdx.x * 4; base < total; base += 256 * 4 * 8) {
+  for (int base = threadIdx.x * 4; base < total; base += TAIL_THREADS * 4 * 8) {
     f4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = base + u * 1024;
+      const int i = base + u * TAIL_THREADS * 4;
       v[u] = (i < valid) ? *(const f4*)(src + i) : f4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = base + u * 1024;
+      const int i = base + u * TAIL_THREADS * 4;
       if (i < total) {
         const int r = i / cols, c = i % cols;
         if (TR) {
@@ -78,7 +79,7 @@ __device__ __forceinline__ void load_cols(float* dst, int ld, const float* src, 
 template <typename Emit>
 __device__ __forceinline__ void gemm_kmajor(const float* A, int lda, const float* B, int ldb, int I, int J, int K, Emit emit) {
   const int tj = J / 4, tiles = (I / 4) * tj;
-  for (int t = threadIdx.x; t < tiles; t += 256) {
+  for (int t = threadIdx.x; t < tiles; t += TAIL_THREADS) {
     const int i0 = 4 * (t / tj), j0 = 4 * (t % tj);
     f4 acc[4];
 #pragma unroll
@@ -139,7 +140,7 @@ __device__ __forceinline__ void bn_relu_drop(const float* Xt, float* Yt, float* 
   }
 }
 
-__global__ __launch_bounds__(256) void mlp_tail_fwd_kernel(TailFwd a) {
+__global__ __launch_bounds__(TAIL_THREADS) void mlp_tail_fwd_kernel(TailFwd a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *At = sm, *Bt = sm + TH * LDM, *Wt = sm + 2 * TH * LDM;      // activations feature-major [F][LDM]; weight k-major [K][LDF]
   float* Kp = Wt + TH * LDF;                                           // dropout keep mask of the current block, row-major [m][LDF]
@@ -215,7 +216,7 @@ __device__ __forceinline__ void bn_relu_drop_bwd(float* dY, float* dXt, const fl
   }
 }
 
-__global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(TailBwd a) {
+__global__ __launch_bounds__(TAIL_THREADS) void mlp_tail_bwd_kernel(TailBwd a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *G = sm, *P = sm + TM * LDF, *R = sm + 2 * TM * LDF, *Q = sm + 3 * TM * LDF, *Gt = sm + 4 * TM * LDF, *W = Gt + TH * LDM;
   const int Mp = (a.M + 3) & ~3;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(TailBwd a) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) *(f4*)(a.dwz + (l0 + ii) * a.H2 + k0) = acc[ii];
   });
-  for (int l = threadIdx.x; l < a.L; l += 256) {
+  for (int l = threadIdx.x; l < a.L; l += TAIL_THREADS) {
     float s = 0.f;
     for (int m = 0; m < a.M; ++m) s += G[m * LDF + l];
     a.dbz[l] = s;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(TailBwd a) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) *(f4*)(a.dw2 + (n0 + ii) * a.H1 + k0) = acc[ii];
   });
-  for (int n = threadIdx.x; n < a.H2; n += 256) {
+  for (int n = threadIdx.x; n < a.H2; n += TAIL_THREADS) {
     float s = 0.f;
     for (int m = 0; m < a.M; ++m) s += R[m * LDF + n];
     a.dbias2[n] = s;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(TailBwd a) {
   bn_relu_drop_bwd(G, nullptr, P, Q, a.M, a.H1, a.g1, a.keep1, a.mean1, a.inv1, a.rm1, a.rv1, a.dg1, a.db1, a.eps1,
                    a.scale1, a.training);
   __syncthreads();
-  for (int i = threadIdx.x; i < a.M * a.H1; i += 256) a.dlin1[i] = G[(i / a.H1) * LDF + (i % a.H1)];
+  for (int i = threadIdx.x; i < a.M * a.H1; i += TAIL_THREADS) a.dlin1[i] = G[(i / a.H1) * LDF + (i % a.H1)];
 }
 
 int check_dims(const char* who, int M, int H1, int H2, int L) {
@@ -310,7 +311,7 @@ int dd_mlp_tail_fwd(const float* lin1, const float* gamma1, const float* beta1, 
   a.eps1 = eps1; a.eps2 = eps2; a.mom1 = momentum1; a.mom2 = momentum2; a.scale1 = scale1; a.scale2 = scale2;
   const size_t lds = ((size_t)2 * TH * LDM + (size_t)TH * LDF + (size_t)TM * LDF) * 4;
   if (int rc = allow(mlp_tail_fwd_kernel, lds)) return rc;
-  hipLaunchKernelGGL(mlp_tail_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_tail_fwd_kernel, dim3(1), dim3(TAIL_THREADS), lds, (hipStream_t)stream, a);
   DD_LAUNCH_CHECK("mlp_tail_fwd");
   return 0;
 }
@@ -337,7 +338,7 @@ int dd_mlp_tail_bwd(const float* dz, const float* lin1, const float* y1, const f
   a.M = m; a.H1 = h1; a.H2 = h2; a.L = l; a.training = training; a.eps1 = eps1; a.eps2 = eps2; a.scale1 = scale1; a.scale2 = scale2;
   const size_t lds = ((size_t)4 * TM * LDF + (size_t)TH * LDM + (size_t)TH * LDF) * 4;
   if (int rc = allow(mlp_tail_bwd_kernel, lds)) return rc;
-  hipLaunchKernelGGL(mlp_tail_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_tail_bwd_kernel, dim3(1), dim3(TAIL_THREADS), lds, (hipStream_t)stream, a);
   DD_LAUNCH_CHECK("mlp_tail_bwd");
   return 0;
 }
