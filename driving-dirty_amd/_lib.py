@@ -24,7 +24,7 @@ class GConvDesc(C.Structure):
     _fields_ = [(n, _i32) for n in ("batch", "in_h", "in_w", "in_cstore", "in_coff", "cin", "out_h", "out_w",
                                     "omem_h", "omem_w", "out_cstore", "out_coff", "cout", "kh", "kw", "stride_h",
                                     "stride_w", "dil_h", "dil_w", "pad_h", "pad_w", "div_h", "div_w", "ostride_h",
-                                    "ostride_w", "ooff_h", "ooff_w")]
+                                    "ostride_w", "ooff_h", "ooff_w", "mask_pass_lo", "mask_pass_hi")]
 
 
 class AdamTensor(C.Structure):
@@ -55,6 +55,7 @@ SIGNATURES = {
     "dd_conv_stats_floats": (_i64, []),
     "dd_conv_fwd_stats": (_i32, [_p, _p, _p, _p, _p, _p, _DP, _p]),
     "dd_bn2d_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _i32, _p, _p, _p, _p]),
+    "dd_bn2d_stats": (_i32, [_p, _p, _i64, _p]),
     "dd_bn2d_apply_relu": (_i32, [_p, _p, _p, _i64, _p]),
     "dd_bn2d_workspace_bytes": (_i64, []),
     "dd_bn2d_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "dd_bce_logits_u8_ptrs": (_i32, [_p, _p, _i32, _i64, _p, _p, _p, _f32, _p, _p]),
     "dd_scale_by_device_scalar": (_i32, [_p, _p, _i64, _p]),
     "dd_sigmoid": (_i32, [_p, _p, _i64, _p]),
+    "dd_sigmoid_bwd": (_i32, [_p, _p, _p, _i64, _p]),
     "dd_mse": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_gconv_packed_floats": (_i64, [_GP]),
     "dd_gconv_pack": (_i32, [_p, _p, _GP, _i64, _i64, _i64, _i32, _i32, _i32, _p]),
@@ -133,6 +135,7 @@ SIGNATURES = {
     "dd_adam_step_multi": (_i32, [C.POINTER(AdamTensor), _i32, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 
+ABI_VERSION = 2      # include/dd_hotpath.h: DD_ABI_VERSION
 _lib = None
 
 
@@ -152,7 +155,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.dd_abi_version() != 1:
+        if handle.dd_abi_version() != ABI_VERSION:
             raise HotpathError("libdd_hotpath.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -3,32 +3,55 @@
     python -m driving_dirty_amd.build          # or __graft_entry__.build()
 
 hipcc cross-compiles without a GPU.  The library is built IN-TREE so that it travels with the
-repository snapshot to the GPU box (a JIT cache under ~/.cache would not).
+repository snapshot to the GPU box (a JIT cache under ~/.cache would not).  Each source is compiled
+to its own object (in parallel, re-done only when the source or a header is newer) and the objects
+are linked into the one library.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdd_hotpath.so")
-SOURCES = ["runtime.hip", "conv3x3.hip", "layout_pool.hip", "dense.hip", "linear.hip", "gconv.hip", "bn2d.hip", "raster.hip", "conv3x3_bf16.hip", "mlp_tail.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+OBJ = os.path.join(CSRC, "build")
+SOURCES = ["runtime.hip", "conv3x3.hip", "layout_pool.hip", "dense.hip", "linear.hip", "gconv.hip", "bn2d.hip", "raster.hip",
+           "conv3x3_bf16.hip", "mlp_tail.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+HEADERS = [os.path.join(CSRC, "dd_common.h"), os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "dd_hotpath.h")]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dd_common.h"),
-            os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "dd_hotpath.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [s for s in SOURCES if force or _stale(_obj(s), [os.path.join(CSRC, s)] + HEADERS)]
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,4 +1,5 @@
-"""Conv -> BatchNorm2d -> ReLU encoder variant (reference src/autoencoder/components_v2.py:6-57) on the HIP hot path.
+"""Conv -> BatchNorm2d -> ReLU encoder variant (reference src/autoencoder/components_v2.py:6-57) and its
+ConvTranspose2d -> BatchNorm2d -> ReLU decoder (components_v2.py:59-98) on the HIP hot path.
 
 The reference file is broken as committed: ``self.bn3 = nn.Conv2d(32)`` (components_v2.py:24) raises at construction
 and nothing imports the module.  This build reads it as the evident ``nn.BatchNorm2d(32)``; everything else (layer
@@ -6,7 +7,10 @@ order, names ``bn1/bn2/bn3``, the pooled FC tail, ``c3_only``) follows the file.
 constructed, the oracle for this variant is a hand-composed ``F.conv2d -> F.batch_norm -> relu`` chain
 (``oracle.ae_parts.EncoderNetV2``), not an import.
 
-Fusion: each conv kernel writes the pre-normalisation tensor and gathers the batch statistics in its epilogue (lane =
+The v2 ``Decoder`` of the reference file DOES construct, so it is pinned by fixtures generated from the reference class
+(``tests/golden/tiny_decoder_v2.npz``, ``full_decoder_v2.npz``).
+
+Fusion (encoder): each conv kernel writes the pre-normalisation tensor and gathers the batch statistics in its epilogue (lane =
 channel: no cross-lane traffic); ``relu(u*scale + shift)`` is applied by the kernels that READ the tensor (next conv's
 row loader, pool, ReLU mask of the data gradient, weight-gradient input), so the normalised activation is never
 written; the BN backward reductions use wavefront shuffles.
@@ -153,3 +157,109 @@ class Encoder(nn.Module):
     def forward(self, x, keeps=(None, None)):
         _require_gpu(x, "Encoder (v2)")
         return self.forward_nhwc4(ops.nchw_to_nhwc(x.contiguous(), 4), keeps)
+
+
+# ------------------------------------------------------------------------------------------------ v2 decoder
+def _stats(u):
+    stats = torch.empty(_lib.lib().dd_conv_stats_floats(), device=u.device, dtype=torch.float32)
+    check(_lib.lib().dd_bn2d_stats(_p(u), _p(stats), u.numel() // 32, _stream()), "dd_bn2d_stats")
+    return stats
+
+
+def _apply_relu(u, aff):
+    y = torch.empty_like(u)
+    check(_lib.lib().dd_bn2d_apply_relu(_p(u), _p(aff), _p(y), u.numel() // 32, _stream()), "dd_bn2d_apply_relu")
+    return y
+
+
+class DecoderV2ConvStack(torch.autograd.Function):
+    """[B, 64*dh*dw] (NCHW-flat, as fc2 emits it) -> [B,3,2dh,2dw]: (dc1 k3 p1, dc2 k3 p1, dc3 k2 s2) each followed by
+    BatchNorm2d + ReLU, then dc4 k1 (components_v2.py:93-98).  The transposed convs run on the generic NHWC kernels
+    (heads.DecoderConvStack's layers), the batch statistics on ``dd_bn2d_stats`` (wavefront-shuffle reductions), the
+    BatchNorm backward on ``dd_bn2d_bwd``; each ReLU backward is the mask epilogue of the following layer's data gradient."""
+
+    @staticmethod
+    def forward(ctx, h, dec, training, dh, dw, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w4, b4):
+        from .gconv import EPI_BIAS, View
+        from .heads import DecoderConvStack as D
+        b, dev = h.shape[0], h.device
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)      # noqa: E731
+        x0 = ops.nchw_to_nhwc(h.contiguous().view(b, 64, dh, dw), 64)
+        us, ys, stats = [], [x0], []
+        for layer, w, bias, bn, shape in ((D.L1, w1, b1, dec.bn1, (b, dh, dw, 32)), (D.L2, w2, b2, dec.bn2, (b, dh, dw, 32)),
+                                          (D.L3, w3, b3, dec.bn3, (b, 2 * dh, 2 * dw, 32))):
+            u = new(*shape)
+            layer.forward(w, bias, View(ys[-1]), View(u), EPI_BIAS)
+            aff, mean, inv = _finalize(_stats(u) if training else None, u.numel() // 32, bn, training)
+            us.append(u)
+            stats.append((mean, inv))
+            ys.append(_apply_relu(u, aff))
+        y4 = torch.zeros((b, 2 * dh, 2 * dw, 4), device=dev, dtype=torch.float32)
+        D.L4.forward(w4, b4, View(ys[3]), View(y4, 0, 3), EPI_BIAS)
+        ctx.save_for_backward(*ys, *us, *[t for pair in stats for t in pair], w1, w2, w3, w4, g1, g2, g3)
+        ctx.training = bool(training)
+        return ops.nhwc_to_nchw(y4, 3)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .gconv import View
+        from .heads import DecoderConvStack as D
+        sv = ctx.saved_tensors
+        ys, us, st = sv[0:4], sv[4:7], sv[7:13]
+        w1, w2, w3, w4, g1, g2, g3 = sv[13:]
+        dev = gy.device
+        g4 = ops.nchw_to_nhwc(gy.contiguous(), 4)
+        dw4, db4 = D.L4.backward_weight(View(ys[3]), View(g4, 0, 3))
+        g = torch.empty_like(ys[3])
+        D.L4.backward_data(w4, View(g4), View(g), relu_src=ys[3])            # dL/d(BN3 output), ReLU applied
+        grads = []
+        for i, (layer, w, gamma) in reversed(list(enumerate(((D.L1, w1, g1), (D.L2, w2, g2), (D.L3, w3, g3))))):
+            du, dgamma, dbeta = _bn_bwd(g, us[i], gamma, st[2 * i], st[2 * i + 1], ctx.training)
+            dw, db = layer.backward_weight(View(ys[i]), View(du))
+            grads.append((dw, db, dgamma, dbeta))
+            if i > 0:
+                g = torch.empty_like(ys[i])
+                layer.backward_data(w, View(du), View(g), relu_src=ys[i])
+            elif ctx.needs_input_grad[0]:
+                g = torch.empty_like(ys[0])
+                layer.backward_data(w, View(du), View(g))
+        grads.reverse()
+        gh = ops.nhwc_to_nchw(g, 64).view(g.shape[0], -1) if ctx.needs_input_grad[0] else None
+        flat = [t for quad in grads for t in quad]
+        return (gh, None, None, None, None, *flat, dw4, db4)
+
+
+class Decoder(nn.Module):
+    """components_v2.Decoder (components_v2.py:59-98): same constructor signature, parameter names and RNG consumption."""
+
+    def __init__(self, hidden_dim, latent_dim, in_channels, output_height, output_width):
+        super().__init__()
+        if in_channels != 3:
+            raise ValueError("the MI355X decoder is built for 3-channel images")
+        # RNG parity with the sizing dry run (components_v2.py:80-87): one rand + four throw-away convs
+        torch.rand(1, in_channels, output_height, output_width)
+        nn.Conv2d(in_channels, 32, 1)
+        nn.Conv2d(32, 32, 2, stride=2)
+        nn.Conv2d(32, 32, 3, padding=1)
+        nn.Conv2d(32, 64, 3, padding=1)
+        self.deconv_dim_h = (output_height - 2) // 2 + 1
+        self.deconv_dim_w = (output_width - 2) // 2 + 1
+        self.latent_dim = latent_dim
+        self.fc1 = DenseBlock(latent_dim, hidden_dim)
+        self.fc2 = DenseBlock(hidden_dim, self.deconv_dim_h * self.deconv_dim_w * 64)
+        self.dc1 = nn.ConvTranspose2d(64, 32, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.dc2 = nn.ConvTranspose2d(32, 32, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm2d(32)
+        self.dc3 = nn.ConvTranspose2d(32, 32, kernel_size=2, stride=2)
+        self.bn3 = nn.BatchNorm2d(32)
+        self.dc4 = nn.ConvTranspose2d(32, in_channels, kernel_size=1, stride=1)
+
+    def forward(self, z, keeps=(None, None)):
+        _require_gpu(z, "Decoder (v2)")
+        h = self.fc2(self.fc1(z, keeps[0]), keeps[1])
+        return DecoderV2ConvStack.apply(h, self, self.bn1.training, self.deconv_dim_h, self.deconv_dim_w,
+                                        self.dc1.weight, self.dc1.bias, self.bn1.weight, self.bn1.bias,
+                                        self.dc2.weight, self.dc2.bias, self.bn2.weight, self.bn2.bias,
+                                        self.dc3.weight, self.dc3.bias, self.bn3.weight, self.bn3.bias,
+                                        self.dc4.weight, self.dc4.bias)

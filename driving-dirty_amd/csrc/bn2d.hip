@@ -63,6 +63,47 @@ __global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float* __restr
   save_invstd[c] = invstd;
 }
 
+// Stand-alone batch statistics of a 32-channel NHWC tensor (the v2 DECODER's ConvTranspose2d outputs come from the generic
+// conv kernels, which have no statistics epilogue): per-thread sums over a grid-stride loop, lanes with equal channel group
+// combined by wavefront shuffles, the four waves through LDS; one row of the finalize kernel's table per block, rows past
+// the grid zeroed.  Row layout: [2c] = sum, [2c+1] = sum of squares of channel c; the entries of lanes 32..63 stay zero.
+__global__ __launch_bounds__(256) void bn2d_stats_kernel(const f32x4* __restrict__ u, float* __restrict__ stats, long n4) {
+  __shared__ float red[4][8][8];
+  const int cg = threadIdx.x & 7;
+  f32x4 ss = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {   // stride % 8 == 0
+    const f32x4 v = u[i];
+    ss += v;
+    sq += v * v;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      ss[k] += __shfl_xor(ss[k], o);
+      sq[k] += __shfl_xor(sq[k], o);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[wave][lane][k] = ss[k];
+      red[wave][lane][4 + k] = sq[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float v = 0.f;
+    if (threadIdx.x < 64) {      // entry 2c + j of the row: channel c = 4*grp + k, j = 0 sum / 1 sum of squares
+      const int c = threadIdx.x >> 1, j = threadIdx.x & 1, grp = c >> 2, k = (c & 3) + 4 * j;
+      v = (red[0][grp][k] + red[1][grp][k]) + (red[2][grp][k] + red[3][grp][k]);
+    }
+    stats[(long)blockIdx.x * 128 + threadIdx.x] = v;
+    for (int r = blockIdx.x + gridDim.x; r < kStatRows; r += gridDim.x) stats[(long)r * 128 + threadIdx.x] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn2d_apply_relu_kernel(const f32x4* __restrict__ u, const float* __restrict__ affine,
                                                               f32x4* __restrict__ y, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -219,6 +260,16 @@ int dd_bn2d_finalize(const float* stats, int64_t count, const float* gamma, cons
   hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, (double)count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, affine, save_mean, save_invstd);
   DD_LAUNCH_CHECK("bn2d_finalize");
+  return 0;
+}
+
+int dd_bn2d_stats(const float* u, float* stats, int64_t npix, void* stream) {
+  DD_REQUIRE(u && stats && npix > 0, DD_ERR_BAD_ARG, "bn2d_stats: bad argument");
+  DD_REQUIRE((uintptr_t)u % 16 == 0, DD_ERR_BAD_ARG, "bn2d_stats: buffer must be 16-byte aligned");
+  const long n4 = npix * 8;
+  const int grid = (int)min((long)grid_for(n4), (long)kStatRows);
+  hipLaunchKernelGGL(bn2d_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)u, stats, n4);
+  DD_LAUNCH_CHECK("bn2d_stats");
   return 0;
 }
 

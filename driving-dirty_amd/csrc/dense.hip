@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256) void sigmoid_kernel(const f32x4* __restrict__ 
   }
 }
 
+// dz = dp * p * (1 - p): backward of p = sigmoid(z) from the saved probabilities (RoadMap.forward, roadmap_pretrain_ae.py:76).
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const f32x4* __restrict__ dp, const f32x4* __restrict__ p, f32x4* __restrict__ dz,
+                                                          long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g = dp[i], s = p[i];
+    dz[i] = g * s * (1.f - s);
+  }
+}
+
 // BCE on probabilities with torch's clamp of the logs at -100 (F.binary_cross_entropy, spatial_w_rm.py:131).
 __global__ __launch_bounds__(256) void bce_probs_kernel(const float* __restrict__ p, const float* __restrict__ t,
                                                         float* __restrict__ dp, double* __restrict__ partial, long n,
@@ -518,6 +527,16 @@ int dd_sigmoid(const float* z, float* p, int64_t n, void* stream) {
   hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)kLossBlocks)), dim3(256), 0, (hipStream_t)stream,
                      (const f32x4*)z, (f32x4*)p, n4);
   DD_LAUNCH_CHECK("sigmoid");
+  return 0;
+}
+
+int dd_sigmoid_bwd(const float* dprobs, const float* probs, float* dlogits, int64_t n, void* stream) {
+  DD_REQUIRE(dprobs && probs && dlogits && n > 0 && n % 4 == 0, DD_ERR_BAD_ARG, "sigmoid_bwd: bad argument (n must be a multiple of 4)");
+  DD_REQUIRE(((uintptr_t)dprobs | (uintptr_t)probs | (uintptr_t)dlogits) % 16 == 0, DD_ERR_BAD_ARG, "sigmoid_bwd: buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)kLossBlocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)dprobs, (const f32x4*)probs, (f32x4*)dlogits, n4);
+  DD_LAUNCH_CHECK("sigmoid_bwd");
   return 0;
 }
 

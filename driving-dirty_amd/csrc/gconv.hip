@@ -218,7 +218,11 @@ __global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict_
         float v = acc[nt][r] + bv[nt];
         if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == DD_EPI_BIAS_SIGMOID) v = 1.f / (1.f + expf(-v));
-        if (epi == DD_EPI_RELU_MASK) v = (dd_bload1(ms, off) > 0.f) ? v : 0.f;
+        if (epi == DD_EPI_RELU_MASK) {
+          const int ch = d.out_coff + nt * 32 + n;      // channels [mask_pass_lo, mask_pass_hi) of the buffer are not ReLU outputs
+          const bool pass = ch >= d.mask_pass_lo && ch < d.mask_pass_hi;
+          v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
+        }
         dd_bstore1(ys, off, v);
       }
     }

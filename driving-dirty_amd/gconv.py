@@ -60,7 +60,7 @@ class View:
 
 
 def _desc(batch, src, dst, cin, cout, k, stride=(1, 1), dil=(1, 1), pad=(0, 0), div=(1, 1), out_hw=None,
-          ostride=(1, 1), ooff=(0, 0)):
+          ostride=(1, 1), ooff=(0, 0), mask_pass=(0, 0)):
     """src/dst: View.  src window offsets are folded into the padding (a shifted origin)."""
     _, imh, imw, ics = src.buf.shape
     _, omh, omw, ocs = dst.buf.shape
@@ -68,7 +68,7 @@ def _desc(batch, src, dst, cin, cout, k, stride=(1, 1), dil=(1, 1), pad=(0, 0), 
     oh, ow = out_hw if out_hw is not None else (dst.h, dst.w)
     return GConvDesc(batch, imh, imw, ics, src.coff, cin, oh, ow, omh, omw, ocs, dst.coff, cout, k[0], k[1],
                      stride[0], stride[1], dil[0], dil[1], pad[0], pad[1], div[0], div[1], ostride[0], ostride[1],
-                     dst.off_h + ooff[0], dst.off_w + ooff[1])
+                     dst.off_h + ooff[0], dst.off_w + ooff[1], mask_pass[0], mask_pass[1])
 
 
 def _pack(w, d, w_off, sn, sc, flip, n_real, c_real):
@@ -138,8 +138,9 @@ class Layer:
             _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
 
     # ---- data gradient: dsrc (View with the input's geometry, >= 4-aligned channels) from ddst (View of dy)
-    def backward_data(self, weight, ddst, dsrc, relu_src=None):
-        """dsrc.buf[..., dsrc.coff : +cin] = dL/dx (x masked by ``relu_src > 0`` when given)."""
+    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0)):
+        """dsrc.buf[..., dsrc.coff : +cin] = dL/dx (x masked by ``relu_src > 0`` when given; channels
+        [mask_pass[0], mask_pass[1]) of the dsrc buffer are exempt: a concat slice that is not a ReLU output)."""
         b = ddst.buf.shape[0]
         epi = EPI_RELU_MASK if relu_src is not None else EPI_NONE
         cin_out = self.cin
@@ -149,14 +150,15 @@ class Layer:
             msk = relu_src
             if not self.transposed:
                 d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, self.k, (1, 1),
-                          self.dil, self._flip_pad(), div=self.stride)
+                          self.dil, self._flip_pad(), div=self.stride, mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.T, self.T, self.cin * self.T, True, nn, self.cout)
             elif self.k2s2:
-                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, (2, 2), (2, 2))
+                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, (2, 2), (2, 2),
+                          mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.cout * 4, self.cout * 4, 4, False, nn, self.cout)
             else:
                 d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, self.k, (1, 1),
-                          self.dil, self.pad)
+                          self.dil, self.pad, mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.cout * self.T, self.cout * self.T, self.T, False, nn, self.cout)
             _fwd(ddst.buf, pk, None, msk, out.buf, d, epi)
 

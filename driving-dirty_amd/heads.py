@@ -224,13 +224,13 @@ class MergeFn(torch.autograd.Function):
             layer, src = ups[i], acts[i]
             g_up.append(layer.backward_weight(View(src), View(g)))
             gsrc = _empty(src.shape, dev)
-            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src)     # masks with the producer's ReLU output
+            # masks with the producer's ReLU output; in the concat buffer (i == 0) only the slices this node's own ReLUs
+            # wrote (ss_deconv 0:32, rm_conv_2 64:96): the spatial-map slice 32:64 is an external input
+            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0))
             g = gsrc
         g_up.reverse()
-        gcat = g                                                                 # [B,256,256,64|96], already ReLU-masked
-        g_space = gcat[..., 32:64].contiguous() if ctx.needs_input_grad[1] else None
-        # NOTE: the spatial map slice was masked with (space > 0): that IS the backward of SpatialMapFn's final ReLU,
-        # which SpatialMapFn.backward applies again (idempotent).
+        gcat = g                                                                 # [B,256,256,64|96]; slices 0:32 / 64:96 ReLU-masked
+        g_space = gcat[..., 32:64].contiguous() if ctx.needs_input_grad[1] else None      # plain dL/d(spatial_map): no mask
         g_rm2 = g_rm1 = (None, None)
         if with_rm:
             g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))
@@ -244,7 +244,7 @@ class MergeFn(torch.autograd.Function):
         g_ssr = None
         if ctx.needs_input_grad[0]:
             g_ssr = _empty(ssr.shape, dev)
-            cls.SS_CONV.backward_data(w_ssc, View(gs1), View(g_ssr), relu_src=ssr)   # ssr is the encoder's ReLU output
+            cls.SS_CONV.backward_data(w_ssc, View(gs1), View(g_ssr))     # plain dL/d(ssr): the encoder's ReLU backward is the encoder's
         flat = [*g_ssc, *g_ssd]
         if with_rm:
             flat += [*g_rm1, *g_rm2]

@@ -12,7 +12,7 @@ from torch import nn
 
 from . import ops
 from .autoencoder import BasicAE
-from .lightning import LightningModule, hparam
+from .lightning import LightningModule, hparam, pretrained_ae
 from .spatial import RoadMapBoxesMergingCNN, SpatialMappingCNN, bb_coord_to_map
 
 
@@ -20,8 +20,7 @@ class JointRoadMapBBox(LightningModule):
     def __init__(self, hparams):
         super().__init__()
         self.hparams = hparams
-        pre = hparam(hparams, "pretrained_ae", None)
-        self.ae = pre if pre is not None else BasicAE.load_from_checkpoint(self.hparams.pretrained_path)
+        self.ae = pretrained_ae(hparams)
         self.ae.decoder = None
         self.ae.encoder.c3_only = False
         self.fc1 = nn.Linear(self.ae.latent_dim, 800 * 800)          # roadmap head, roadmap_bce_v2.py:50

@@ -42,9 +42,36 @@ class LightningModule(nn.Module):
         return model
 
     def save_checkpoint(self, path):
+        """``{'state_dict', 'hparams', 'epoch'}`` as Lightning 0.7.5's ModelCheckpoint writes it.  ``hparams`` keeps the
+        plain argparse values only: an in-memory ``pretrained_ae`` module or a ``rasterizer`` callable handed in through the
+        Namespace is not a hyper-parameter (its weights are in the ``state_dict`` under ``ae.*``)."""
         hp = getattr(self, "hparams", None)
-        torch.save({"state_dict": self.state_dict(), "hparams": dict(vars(hp)) if hp is not None else {},
-                    "epoch": self.current_epoch}, path)
+        plain = (bool, int, float, str, type(None), list, tuple, dict)
+        hp = {k: v for k, v in vars(hp).items() if isinstance(v, plain)} if hp is not None else {}
+        ae = getattr(self, "ae", None)
+        if ae is not None and not hp.get("pretrained_path"):
+            # the feature extractor was handed in as a module (no checkpoint file to name): keep what is needed to rebuild
+            # its skeleton, the weights themselves are in the state_dict under 'ae.*'
+            hp["ae_hparams"] = {k: getattr(ae, k) for k in ("hidden_dim", "latent_dim", "input_width", "input_height",
+                                                           "output_width", "output_height", "in_channels")}
+        torch.save({"state_dict": self.state_dict(), "hparams": hp, "epoch": self.current_epoch}, path)
+
+
+def pretrained_ae(hparams):
+    """The pretrained ``BasicAE`` of a fine-tuning module: ``BasicAE.load_from_checkpoint(hparams.pretrained_path)`` as in the
+    reference (roadmap_bce_v2.py:43, spatial_w_rm.py:43), an in-memory module handed in as ``hparams.pretrained_ae``, or --
+    when a checkpoint of THIS module is being re-loaded -- a skeleton from ``hparams.ae_hparams`` that the state_dict fills."""
+    from .autoencoder import BasicAE
+    pre = hparam(hparams, "pretrained_ae", None)
+    if pre is not None:
+        return pre
+    path = hparam(hparams, "pretrained_path", "")
+    if path:
+        return BasicAE.load_from_checkpoint(path)
+    skeleton = hparam(hparams, "ae_hparams", None)
+    if skeleton:
+        return BasicAE(Namespace(**skeleton))
+    raise ValueError("no pretrained autoencoder: set hparams.pretrained_path (a BasicAE checkpoint) or hparams.pretrained_ae")
 
 
 def hparam(hparams, name, default):

@@ -700,12 +700,22 @@ def _loss_ws(n, device):
     return torch.empty(_lib.lib().dd_loss_workspace_bytes(n), device=device, dtype=torch.uint8)
 
 
-def _scaled_loss_grad(dz, g):
-    """dz * g for the 0-dim upstream gradient ``g`` of a scalar loss -- in place and skipped on the device when g == 1
-    (dd_scale_by_device_scalar); anything else takes autograd's generic multiply."""
+def _scaled_loss_grad(ctx, dz, g):
+    """dz * g for the 0-dim upstream gradient ``g`` of a scalar loss.  The forward already wrote d(loss)/d(input), so for a
+    plain ``loss.backward()`` (g == 1, known only on the device) nothing needs to move: ``dd_scale_by_device_scalar`` scales
+    the saved buffer in place and is skipped on the device when g == 1.  The in-place pass is remembered on ``ctx``: a
+    repeated backward through a retained graph (``retain_graph=True``) finds the buffer already carrying the previous factor
+    and takes the generic out-of-place route with the ratio of the two factors."""
+    prev = getattr(ctx, "applied_scale", None)
+    if prev is not None:
+        if float(prev) == 0.0:
+            raise RuntimeError("loss backward: the retained graph was first back-propagated with a zero upstream gradient; "
+                               "its saved loss gradient cannot be rescaled (run the forward again)")
+        return dz * (g / prev)
     if (g.numel() == 1 and g.is_cuda and g.dtype == torch.float32 and dz.is_contiguous() and dz.dtype == torch.float32
             and dz.data_ptr() % 16 == 0 and not torch.is_grad_enabled()):
         check(_lib.lib().dd_scale_by_device_scalar(_p(dz), _p(g), dz.numel(), _stream()), "dd_scale_by_device_scalar")
+        ctx.applied_scale = g.detach()
         return dz
     return dz * g
 
@@ -734,7 +744,7 @@ class BceWithLogits(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
-        return _scaled_loss_grad(dz, g), None
+        return _scaled_loss_grad(ctx, dz, g), None
 
 
 class BceWithLogitsProbs(torch.autograd.Function):
@@ -782,7 +792,7 @@ class BceWithLogitsProbs(torch.autograd.Function):
         (dz,) = ctx.saved_tensors
         if g is None:
             return None, None
-        return _scaled_loss_grad(dz, g), None
+        return _scaled_loss_grad(ctx, dz, g), None
 
 
 class MseLoss(torch.autograd.Function):
@@ -802,7 +812,7 @@ class MseLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (da,) = ctx.saved_tensors
-        return _scaled_loss_grad(da, g), None
+        return _scaled_loss_grad(ctx, da, g), None
 
 
 class BceProbs(torch.autograd.Function):
@@ -823,7 +833,7 @@ class BceProbs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return _scaled_loss_grad(dp, g), None
+        return _scaled_loss_grad(ctx, dp, g), None
 
 
 def sigmoid(z):
@@ -834,6 +844,26 @@ def sigmoid(z):
     p = torch.empty_like(z)
     check(_lib.lib().dd_sigmoid(_p(z), _p(p), z.numel(), _stream()), "dd_sigmoid")
     return p
+
+
+class Sigmoid(torch.autograd.Function):
+    """p = sigmoid(z) with its autograd on the device (dd_sigmoid / dd_sigmoid_bwd): the sigmoid INSIDE ``RoadMap.forward``
+    of the MSE twin (roadmap_pretrain_ae.py:76), whose loss is taken from the probabilities."""
+
+    @staticmethod
+    def forward(ctx, z):
+        p = sigmoid(z.contiguous())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        dp = dp.contiguous()
+        _dev(dp, "dp", p.shape)
+        dz = torch.empty_like(p)
+        check(_lib.lib().dd_sigmoid_bwd(_p(dp), _p(p), _p(dz), p.numel(), _stream()), "dd_sigmoid_bwd")
+        return dz
 
 
 def sigmoid_and_loss(logits, target):

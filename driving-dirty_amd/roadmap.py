@@ -13,7 +13,7 @@ from torch.nn import functional as F
 
 from . import ops
 from .autoencoder import BasicAE
-from .lightning import LightningModule, hparam
+from .lightning import LightningModule, hparam, pretrained_ae
 
 
 def compute_ts_road_map(road_map1, road_map2):
@@ -28,8 +28,7 @@ class RoadMapBCE(LightningModule):
         self.output_dim = 800 * 800
         # pretrained feature extractor (roadmap_bce_v2.py:43-47); ``pretrained_ae`` lets callers hand in
         # an already-built BasicAE when no checkpoint file exists (the reference's paths are NYU-local)
-        pre = hparam(hparams, "pretrained_ae", None)
-        self.ae = pre if pre is not None else BasicAE.load_from_checkpoint(self.hparams.pretrained_path)
+        self.ae = pretrained_ae(hparams)
         self.frozen = True
         self.ae.freeze()
         self.ae.decoder = None
@@ -136,14 +135,15 @@ class RoadMap(RoadMapBCE):
     """MSE twin (roadmap_pretrain_ae.py): sigmoid inside ``forward``, ``mse_loss(target, pred)``, unfreeze at epoch 30."""
 
     def forward(self, x, keeps=(None, None)):
-        y = torch.sigmoid(ops.linear(self._encode(x, keeps), self.fc1.weight, self.fc1.bias))
+        """-> sigmoid(Linear(z)) [B,800,800], differentiable (roadmap_pretrain_ae.py:67-82)."""
+        y = ops.Sigmoid.apply(ops.linear(self._encode(x, keeps), self.fc1.weight, self.fc1.bias))
         return y.reshape(y.size(0), 800, 800)
 
     def _run_step(self, batch, batch_idx, step_name, keeps=(None, None)):
         sample, target, road_image = batch
         target_rm = torch.stack(tuple(road_image), dim=0).float()
         pred_rm = self(sample, keeps)
-        loss = ops.MseLoss.apply(pred_rm.contiguous(), target_rm)
+        loss = ops.MseLoss.apply(pred_rm.contiguous(), target_rm)      # F.mse_loss(target_rm, pred_rm), roadmap_pretrain_ae.py:100
         return loss, target_rm, pred_rm
 
     def training_step(self, batch, batch_idx):

@@ -12,7 +12,7 @@ from torch import nn
 from . import ops
 from .autoencoder import BasicAE
 from .heads import MergeFn, SpatialMapFn, _ORDER, as_nhwc
-from .lightning import LightningModule, hparam
+from .lightning import LightningModule, hparam, pretrained_ae
 
 
 def _gpu(t, who):
@@ -114,8 +114,7 @@ class BBSpatialRoadMap(LightningModule):
         super().__init__()
         self.hparams = hparams
         self.output_dim = 800 * 800
-        pre = hparam(hparams, "pretrained_ae", None)
-        self.ae = pre if pre is not None else BasicAE.load_from_checkpoint(self.hparams.pretrained_path)
+        self.ae = pretrained_ae(hparams)
         self.frozen = True
         self.ae.freeze()
         self.ae.encoder.c3_only = True

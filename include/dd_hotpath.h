@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 1
+#define DD_ABI_VERSION 2
 
 enum {
   DD_OK = 0,
@@ -143,6 +143,10 @@ int dd_conv_fwd_stats(const float* x, const float* packed_fwd, const float* bias
 int dd_bn2d_finalize(const float* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, int32_t training, float* affine, float* save_mean,
                      float* save_invstd, void* stream);
+/* Stand-alone batch statistics of a 32-channel NHWC tensor u [npix, 32] into the same `stats` table (the v2 Decoder's
+ * ConvTranspose2d -> BatchNorm2d, components_v2.py:73-78,96-98: its convs run on the generic kernels, which have no
+ * statistics epilogue); wavefront-shuffle reductions, deterministic. */
+int dd_bn2d_stats(const float* u, float* stats, int64_t npix, void* stream);
 /* y = relu(u*scale + shift), u/y [npix, 32] (only when a caller wants the activation itself, e.g. the c3_only exit) */
 int dd_bn2d_apply_relu(const float* u, const float* affine, float* y, int64_t npix, void* stream);
 /* BatchNorm2d backward on g = dL/d(BN output) (already ReLU-masked): dgamma, dbeta (wavefront-shuffle reduction) and
@@ -252,6 +256,9 @@ int dd_scale_by_device_scalar(float* x, const float* scalar, int64_t n, void* st
 
 /* probs = sigmoid(logits) (roadmap_bce_v2.py:81), n % 4 == 0 */
 int dd_sigmoid(const float* z, float* p, int64_t n, void* stream);
+/* dlogits = dprobs * probs * (1 - probs): autograd of the sigmoid INSIDE RoadMap.forward (roadmap_pretrain_ae.py:76,
+ * the MSE twin takes its loss from the probabilities), n % 4 == 0 */
+int dd_sigmoid_bwd(const float* dprobs, const float* probs, float* dlogits, int64_t n, void* stream);
 /* Mean squared error mean((a-b)^2) with optional da = 2(a-b)*grad_scale/n (autoencoder.py:91). */
 int dd_mse(const float* a, const float* b, float* loss_out, float* da, int64_t n, float grad_scale,
            void* workspace, void* stream);
@@ -279,6 +286,8 @@ typedef struct dd_gconv_desc {
   int32_t kh, kw, stride_h, stride_w, dil_h, dil_w, pad_h, pad_w;
   int32_t div_h, div_w;                                 /* 1 = ordinary convolution */
   int32_t ostride_h, ostride_w, ooff_h, ooff_w;         /* output pixel (yo,xo) lands at (yo*ostride_h+ooff_h, xo*ostride_w+ooff_w) */
+  int32_t mask_pass_lo, mask_pass_hi;                   /* DD_EPI_RELU_MASK: output-BUFFER channels [lo,hi) are written unmasked (a channel
+                                                           slice of a concat buffer that did not come out of a ReLU; 0,0 = mask everything) */
 } dd_gconv_desc;
 
 /* Weight image for the kernels: element (n, c, tap) is read from w[w_off + n*sn + c*sc + (flip ? T-1-tap : tap)];

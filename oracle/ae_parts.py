@@ -4,6 +4,8 @@ Follows reference ``src/autoencoder/components.py``:
   * ``FcBlock``      <- ``DenseBlock``  (components.py:96-109)
   * ``EncoderNet``   <- ``Encoder``     (components.py:6-52)
   * ``DecoderNet``   <- ``Decoder``     (components.py:55-93)
+and ``src/autoencoder/components_v2.py`` (``EncoderNetV2``: hand-composed, the class cannot construct;
+``DecoderNetV2`` <- ``Decoder`` :59-98, which can).
 
 The classes register their parameters under the SAME attribute names as the
 reference so ``state_dict()`` keys are interchangeable, and they draw from the
@@ -125,6 +127,40 @@ class DecoderNet(nn.Module):
         h = F.relu(F.conv_transpose2d(h, self.dc2.weight, self.dc2.bias, padding=1))
         h = F.relu(F.conv_transpose2d(h, self.dc3.weight, self.dc3.bias, stride=2))
         return F.conv_transpose2d(h, self.dc4.weight, self.dc4.bias)      # no activation (components.py:92)
+
+
+class DecoderNetV2(nn.Module):
+    """ConvTranspose2d -> BatchNorm2d -> ReLU decoder, reference src/autoencoder/components_v2.py:59-98 (this class of
+    the v2 file constructs; pinned by tests/golden/tiny_decoder_v2.npz, generated from it)."""
+
+    def __init__(self, hidden_dim, latent_dim, in_channels, output_height, output_width):
+        super().__init__()
+        # RNG parity with components_v2.py:80-87: rand input, then four throw-away convs
+        torch.rand(1, in_channels, output_height, output_width)
+        nn.Conv2d(in_channels, 32, 1)
+        nn.Conv2d(32, 32, 2, stride=2)
+        nn.Conv2d(32, 32, 3, padding=1)
+        nn.Conv2d(32, 64, 3, padding=1)
+        self.deconv_dim_h = (output_height - 2) // 2 + 1
+        self.deconv_dim_w = (output_width - 2) // 2 + 1
+        self.latent_dim = latent_dim
+        self.fc1 = FcBlock(latent_dim, hidden_dim)
+        self.fc2 = FcBlock(hidden_dim, self.deconv_dim_h * self.deconv_dim_w * 64)
+        self.dc1 = nn.ConvTranspose2d(64, 32, 3, padding=1)        # construction order = components_v2.py:71-78
+        self.bn1 = nn.BatchNorm2d(32)
+        self.dc2 = nn.ConvTranspose2d(32, 32, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(32)
+        self.dc3 = nn.ConvTranspose2d(32, 32, 2, stride=2)
+        self.bn3 = nn.BatchNorm2d(32)
+        self.dc4 = nn.ConvTranspose2d(32, in_channels, 1)
+
+    def forward(self, z, masks=(None, None)):
+        h = self.fc2(self.fc1(z, masks[0]), masks[1])
+        h = h.reshape(h.size(0), 64, self.deconv_dim_h, self.deconv_dim_w)
+        h = F.relu(self.bn1(F.conv_transpose2d(h, self.dc1.weight, self.dc1.bias, padding=1)))
+        h = F.relu(self.bn2(F.conv_transpose2d(h, self.dc2.weight, self.dc2.bias, padding=1)))
+        h = F.relu(self.bn3(F.conv_transpose2d(h, self.dc3.weight, self.dc3.bias, stride=2)))
+        return F.conv_transpose2d(h, self.dc4.weight, self.dc4.bias)      # no activation (components_v2.py:99)
 
 
 class EncoderNetV2(nn.Module):

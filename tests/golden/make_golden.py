@@ -125,14 +125,15 @@ def default_init(out):
     np.savez_compressed(out, **res)
 
 
-def full_roadmap(out):
-    """Config-2 shapes at B = 2: Encoder(128, 64, 3, 256, 1836) + Linear(64, 640000) + BCE-with-logits.
+def full_roadmap(out, b=2):
+    """Config-2 shapes at B = 2 (``full_roadmap``: the ill-conditioned edge case, train-mode BatchNorm1d over two rows) and
+    at B = 32 (``full_roadmap_b32``: the headline batch): Encoder(128, 64, 3, 256, 1836) + Linear(64, 640000) +
+    BCE-with-logits.
 
     Only the component modules come from the reference; the stitch / head / loss lines are the
     obvious torch calls of roadmap_bce_v2.py:58-62,75-81,106 written inline.
     """
     res = {}
-    b = 2
     views = synth.camera_batch(b, seed=3)
     road = synth.road_maps(b, seed=3)
     for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
@@ -159,13 +160,199 @@ def full_roadmap(out):
         for k, v in enc.named_buffers():
             if v.numel() > 1:
                 res[f"buf.{k}_{tag}"] = _np(v)
-        # conv feature (c3_only) statistics at full size
+        del loss, logits, z
+        # conv feature (c3_only) statistics at full size (the first two samples: per-sample independent)
         enc.c3_only = True
         with torch.no_grad():
-            feat = enc(x)
+            feat = enc(x[:2])
         res[f"feat_samp_{tag}"], res["feat_idx"] = _sample(feat, 512)
         res[f"feat_sum_{tag}"] = np.array([feat.double().sum().item(), feat.double().abs().sum().item()])
-        del enc, head
+        del enc, head, feat
+    np.savez_compressed(out, **res)
+
+
+def full_roadmap_b32(out):
+    full_roadmap(out, b=32)
+
+
+def full_decoder(out):
+    """Decoder(128, 64, 3, 256, 306) at B = 2 (components.py:55-93): the 128 -> 1,253,376 DenseBlock with its BatchNorm1d,
+    the [B,64,128,153] view and the four ConvTranspose2d at 128x153 / 256x306.  Output and every gradient."""
+    res = {}
+    b = 2
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        dec = synth.fill_module(Decoder(128, 64, 3, 256, 306), seed=8).to(dt)
+        _set_drop(dec, 0.0)
+        z = synth.hash_uniform((b, 64), synth.key_salt("full_z"), -1.0, 1.0).to(dt).requires_grad_(True)
+        dec.train()
+        y = dec(z)
+        wy = synth.hash_uniform(tuple(y.shape), synth.key_salt("full_wy")).to(dt)
+        (y * wy).sum().backward()
+        res[f"y_samp_{tag}"], res["y_idx"] = _sample(y, 1024)
+        res[f"y_sum_{tag}"] = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+        res[f"grad.z_{tag}"] = _np(z.grad)
+        for k, g in _grads(dec).items():
+            if g.numel() <= 40000:
+                res[f"grad.{k}_{tag}"] = _np(g)
+            else:
+                res[f"gradsamp.{k}_{tag}"], res[f"gradidx.{k}"] = _sample(g, 512)
+            res[f"gradsum.{k}_{tag}"] = np.array([g.double().sum().item(), g.double().abs().sum().item()])
+        for k, v in dec.named_buffers():
+            if v.numel() > 1:
+                res[f"bufsamp.{k}_{tag}"], res[f"bufidx.{k}"] = _sample(v, 512)
+        del dec
+    np.savez_compressed(out, **res)
+
+
+def full_ae_step(out):
+    """Config 1's step at full size, B = 4 (the config's batch): masked-view task -> Encoder(128,64,3,256,1836) ->
+    Decoder(128,64,3,256,306) -> mse_loss(y, y_hat).  The component modules are the reference's; the task lines are
+    autoencoder.py:55-67,91 written inline with the masked view fixed to slot 2."""
+    res = {}
+    b, t = 4, 2
+    views = synth.camera_batch(b, seed=9)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        enc = synth.fill_module(Encoder(128, 64, 3, 256, 1836), seed=9).to(dt)
+        dec = synth.fill_module(Decoder(128, 64, 3, 256, 306), seed=10).to(dt)
+        _set_drop(enc, 0.0)
+        _set_drop(dec, 0.0)
+        enc.train()
+        dec.train()
+        x = views.to(dt)[:, [0, 1, 2, 5, 4, 3]]
+        x = x.permute(0, 2, 3, 1, 4).reshape(b, 3, 256, -1).clone()
+        y = x[:, :, :, t * 306:(t + 1) * 306].clone()
+        x[:, :, :, t * 306:(t + 1) * 306] = 0.0
+        y_hat = dec(enc(x))
+        loss = torch.nn.functional.mse_loss(y, y_hat)
+        loss.backward()
+        res[f"loss_{tag}"] = np.array(loss.item())
+        res[f"yhat_samp_{tag}"], res["yhat_idx"] = _sample(y_hat, 1024)
+        for name, m in (("encoder", enc), ("decoder", dec)):
+            for k, g in _grads(m).items():
+                if g.numel() <= 40000:
+                    res[f"grad.{name}.{k}_{tag}"] = _np(g)
+                else:
+                    res[f"gradsamp.{name}.{k}_{tag}"], res[f"gradidx.{name}.{k}"] = _sample(g, 512)
+                res[f"gradsum.{name}.{k}_{tag}"] = np.array([g.double().sum().item(), g.double().abs().sum().item()])
+        del enc, dec, loss, y_hat
+    res["mask_slot"] = np.array(t)
+    np.savez_compressed(out, **res)
+
+
+def merge_signed(out):
+    """Both merging heads as stand-alone modules with SIGNED inputs (the reference applies no ReLU to its inputs,
+    spatial_bb/components.py:95-119,141-170): outputs, input gradients and every parameter gradient, B = 1."""
+    res = {}
+    b = 1
+    rm = synth.road_maps(b, seed=11).float().unsqueeze(1)
+    ssr0 = synth.hash_uniform((b, 32, 128, 918), synth.key_salt("ssr_signed"), -1.0, 1.0)
+    space0 = synth.hash_uniform((b, 32, 256, 256), synth.key_salt("space_signed"), -1.0, 1.0)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        rb = synth.fill_module(RoadMapBoxesMergingCNN(), seed=12).to(dt)
+        bm = synth.fill_module(BoxesMergingCNN(), seed=13).to(dt)
+        for name, m, args in (("rboxm", rb, (rm.to(dt),)), ("boxm", bm, ())):
+            ssr = ssr0.clone().to(dt).requires_grad_(True)
+            space = space0.clone().to(dt).requires_grad_(True)
+            pred = m(ssr, space, *args)
+            wy = synth.hash_uniform(tuple(pred.shape), synth.key_salt("ms_wy")).to(dt)
+            (pred * wy).sum().backward()
+            res[f"{name}.pred_samp_{tag}"], res[f"{name}.pred_idx"] = _sample(pred, 512)
+            res[f"{name}.pred_sum_{tag}"] = np.array([pred.double().sum().item(), pred.double().abs().sum().item()])
+            for iname, t in (("ssr", ssr), ("space", space)):
+                res[f"{name}.{iname}grad_samp_{tag}"], res[f"{name}.{iname}grad_idx"] = _sample(t.grad, 2048)
+                res[f"{name}.{iname}grad_sum_{tag}"] = np.array([t.grad.double().sum().item(), t.grad.double().abs().sum().item()])
+            for k, g in _grads(m).items():
+                if g.numel() <= 40000:
+                    res[f"grad.{name}.{k}_{tag}"] = _np(g)
+                else:
+                    res[f"gradsamp.{name}.{k}_{tag}"], res[f"gradidx.{name}.{k}"] = _sample(g, 512)
+    np.savez_compressed(out, **res)
+
+
+def tiny_decoder_v2(out):
+    """components_v2.Decoder(16, 8, 3, 16, 22) (ConvTranspose2d -> BatchNorm2d -> ReLU x3 + ConvTranspose2d,
+    components_v2.py:59-98; this class of the v2 file DOES construct): train mode (batch statistics, running-stat update,
+    all gradients) and eval mode."""
+    from src.autoencoder.components_v2 import Decoder as DecoderV2, DenseBlock as DenseBlockV2  # reference
+    res = {}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        dec = synth.fill_module(DecoderV2(16, 8, 3, 16, 22), seed=14).to(dt)
+        for m in dec.modules():
+            if isinstance(m, DenseBlockV2):
+                m.drop_p = 0.0
+        z = synth.hash_uniform((3, 8), synth.key_salt("v2_z"), -1.0, 1.0).to(dt).requires_grad_(True)
+        dec.train()
+        y = dec(z)
+        wy = synth.hash_uniform(tuple(y.shape), synth.key_salt("v2_wy")).to(dt)
+        (y * wy).sum().backward()
+        res[f"y_{tag}"] = _np(y)
+        res[f"grad.z_{tag}"] = _np(z.grad)
+        for k, g in _grads(dec).items():
+            res[f"grad.{k}_{tag}"] = _np(g)
+        for k, v in dec.named_buffers():
+            res[f"buf.{k}_{tag}"] = _np(v)
+        dec.eval()
+        with torch.no_grad():
+            res[f"y_eval_{tag}"] = _np(dec(z))
+    np.savez_compressed(out, **res)
+
+
+def full_decoder_v2(out):
+    """components_v2.Decoder(128, 64, 3, 256, 306) at B = 2: the BatchNorm2d reductions at 128x153 / 256x306."""
+    from src.autoencoder.components_v2 import Decoder as DecoderV2, DenseBlock as DenseBlockV2  # reference
+    res = {}
+    b = 2
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        dec = synth.fill_module(DecoderV2(128, 64, 3, 256, 306), seed=15).to(dt)
+        for m in dec.modules():
+            if isinstance(m, DenseBlockV2):
+                m.drop_p = 0.0
+        z = synth.hash_uniform((b, 64), synth.key_salt("v2_full_z"), -1.0, 1.0).to(dt).requires_grad_(True)
+        dec.train()
+        y = dec(z)
+        wy = synth.hash_uniform(tuple(y.shape), synth.key_salt("v2_full_wy")).to(dt)
+        (y * wy).sum().backward()
+        res[f"y_samp_{tag}"], res["y_idx"] = _sample(y, 1024)
+        res[f"y_sum_{tag}"] = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+        res[f"grad.z_{tag}"] = _np(z.grad)
+        for k, g in _grads(dec).items():
+            if g.numel() <= 40000:
+                res[f"grad.{k}_{tag}"] = _np(g)
+            else:
+                res[f"gradsamp.{k}_{tag}"], res[f"gradidx.{k}"] = _sample(g, 512)
+        for k, v in dec.named_buffers():
+            if 1 < v.numel() <= 64:
+                res[f"buf.{k}_{tag}"] = _np(v)
+        del dec
+    np.savez_compressed(out, **res)
+
+
+def tiny_ae_ckpt(out):
+    """A checkpoint in the layout Lightning 0.7.5 writes for ``BasicAE`` -- ``{'state_dict': {'encoder.*', 'decoder.*'},
+    'hparams': {...}}`` -- holding the REFERENCE modules' default init under the reference's seed
+    (autoencoder.py:16-18: Encoder first, then Decoder, as BasicAE.__init__ builds them, :26-30), plus the outputs the
+    reference modules compute from it.  ``BasicAE.load_from_checkpoint`` must load the file and reproduce them."""
+    hp = dict(hidden_dim=16, latent_dim=8, input_height=16, input_width=6 * 22, output_height=16, output_width=22,
+              in_channels=3, batch_size=3, learning_rate=1e-3, output_img_freq=500)
+    torch.manual_seed(20200505)
+    enc = Encoder(hp["hidden_dim"], hp["latent_dim"], 3, hp["input_height"], hp["input_width"])
+    dec = Decoder(hp["hidden_dim"], hp["latent_dim"], 3, hp["output_height"], hp["output_width"])
+    sd = {f"encoder.{k}": v.clone() for k, v in enc.state_dict().items()}
+    sd.update({f"decoder.{k}": v.clone() for k, v in dec.state_dict().items()})
+    torch.save({"state_dict": sd, "hparams": hp, "epoch": 0}, os.path.join(HERE, "tiny_ae.ckpt"))
+    res = {"keys": np.array(sorted(sd))}
+    x = synth.hash_uniform((3, 3, 16, 6 * 22), synth.key_salt("ckpt_x"), 0.0, 1.0)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        e, d = Encoder(16, 8, 3, 16, 6 * 22).to(dt), Decoder(16, 8, 3, 16, 22).to(dt)
+        e.load_state_dict({k: v.to(dt) for k, v in enc.state_dict().items()})
+        d.load_state_dict({k: v.to(dt) for k, v in dec.state_dict().items()})
+        _set_drop(e, 0.0)
+        _set_drop(d, 0.0)
+        e.train()
+        d.train()
+        z = e(x.to(dt))
+        res[f"z_{tag}"] = _np(z)
+        res[f"y_{tag}"] = _np(d(z))
     np.savez_compressed(out, **res)
 
 
@@ -232,6 +419,13 @@ CASES = {
     "tiny_decoder": tiny_decoder,
     "default_init": default_init,
     "full_roadmap": full_roadmap,
+    "full_roadmap_b32": full_roadmap_b32,
+    "full_decoder": full_decoder,
+    "full_ae_step": full_ae_step,
+    "merge_signed": merge_signed,
+    "tiny_decoder_v2": tiny_decoder_v2,
+    "full_decoder_v2": full_decoder_v2,
+    "tiny_ae_ckpt": tiny_ae_ckpt,
     "spatial_heads": spatial_heads,
     "box_raster": box_raster,
 }

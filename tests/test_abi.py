@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), f"{n} is declared in include/dd_hotpath.h but not exported by the library"
     # the ctypes signature table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().dd_abi_version() == 1
+    assert _lib.lib().dd_abi_version() == _lib.ABI_VERSION
 
 
 def test_descriptor_structs_match_the_header():
