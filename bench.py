@@ -5,11 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One process per GPU; ranks shard the batch (weak scaling: 32 scenes per GPU), gradients are all-reduced
-over RCCL (driving_dirty_amd.ddp.GradSync) overlapped with the conv backward.  A "step" is one pass of the
-hot path over one synthetic batch: 6-view stitch -> conv encoder -> pool -> dense blocks -> Linear(64, 640000)
--> BCE-with-logits, backward through everything, Adam on all 162 M parameters.  Inputs are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line (fields: see the task contract / DESIGN.md section 6).
+One process per GPU.  Started WITHOUT a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the
+parent process starts its N ranks itself -- N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before
+anything touches a GPU -- waits for them and exits with their status; started by torch.distributed.run it is a rank.
+Ranks shard the batch (weak scaling: 32 scenes per GPU); gradients are all-reduced over RCCL
+(driving_dirty_amd.ddp.GradSync) overlapped with the conv backward.  A "step" is one pass of the hot path over one
+synthetic batch: 6-view stitch -> conv encoder -> pool -> dense blocks -> Linear(64, 640000) -> BCE-with-logits,
+backward through everything, Adam on all 162 M parameters.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (fields: see the task contract / DESIGN.md section 5).
 
 Workload = BASELINE.json configs[1] (reference src/roadmap_model/roadmap_bce_v2.py with the report's best AE:
 hidden 128 / latent 64, FinalReport Table 1), synthetic 6x3x256x306 images and 800x800 road masks, default
@@ -18,12 +21,11 @@ PyTorch init under the reference's seed 20200505.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from argparse import Namespace
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,12 +34,60 @@ SEED = 20200505                     # reference autoencoder.py:16-18
 BATCH, H, W = 32, 256, 306
 HIDDEN, LATENT = 128, 64
 PEAK_F32_MFMA_TF = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
-# algorithmic work per scene, fwd+bwd: roadmap step 35.080 GFLOP; the dominant kernel is the
-# c2 forward convolution: 2 * 256*1836 pixels * 32 * (9*32) flop per scene
+PEAK_HBM_GBS = 8000.0               # same guide: HBM3E peak
+# algorithmic work per scene: the 32 -> 32 stride-1 layer, one pass = 2 * 256*1836 pixels * 32 * (9*32) flop;
+# the 3 -> 32 layer's weight gradient = 2 * 256*1836 * 32 * 27
 C2_FLOP_PER_SCENE = 2.0 * 256 * 1836 * 32 * 288
-STEP_FLOP_PER_SCENE = 35.080e9            # hidden 128 / latent 64; step_flop_per_scene() for other widths
+C1_WGRAD_FLOP_PER_SCENE = 2.0 * 256 * 1836 * 32 * 27
+PIXELS_PER_SCENE = 256 * 1836
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the config-1 / config-3 / config-5 step timings after the headline")
+    ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
+    ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
+    ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
+    ap.add_argument("--latent", type=int, default=LATENT, help="latent width (64; with --hidden 256: 128)")
+    ap.add_argument("--wino-1d", action="store_true", help="c2 forward / data gradient by F(2,3) along x instead of F(2x2,3x3)")
+    ap.add_argument("--direct-conv", action="store_true", help="c2 forward / data gradient on the direct kernels instead of Winograd")
+    ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ self-launch
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (this process never touches a GPU) and exit
+    with their status.  A failed rank is not restarted; the others are terminated."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:              # a rank died: the collective would hang the others
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ rank body
 def step_flop_per_scene():
     """Conv stack fwd+bwd (34.112 GF, no data gradient for c1) + 3 passes x 2 flop x MACs of the four Linear layers."""
     pooled = 32 * 128 * 918 // 4
@@ -45,6 +95,7 @@ def step_flop_per_scene():
 
 
 def build_model(dev):
+    import torch
     from driving_dirty_amd.autoencoder import BasicAE
     from driving_dirty_amd.roadmap import RoadMapBCE
     torch.manual_seed(SEED)
@@ -54,6 +105,7 @@ def build_model(dev):
 
 
 def synthetic_batch(dev, batch, rank):
+    import torch
     g = torch.Generator(device=dev).manual_seed(SEED + rank)
     views = torch.rand(batch, 6, 3, H, W, generator=g, device=dev)
     road = torch.rand(batch, 800, 800, generator=g, device=dev) < 0.3
@@ -61,47 +113,50 @@ def synthetic_batch(dev, batch, rank):
 
 
 class KernelTimer:
-    """HIP events around every launch of the dominant kernel (c2 forward conv) on its launch stream."""
+    """HIP events around every launch of the two c2 kernels that dominate the step, recorded on their launch stream (the
+    current torch stream): the data gradient with the fused c1 weight gradient (the longest kernel of the step) and the forward."""
 
     def __init__(self):
-        self.pairs = []
+        self.pairs = {"c2_dgrad_w1": [], "c2_fwd": []}
         self.enabled = False
 
     def install(self):
+        import torch
         from driving_dirty_amd import ops
-        # the encoder stack runs c2 forward through conv_wino_fwd_bits (Winograd, default) or conv_fwd_bits (direct)
-        def wrap(inner):
-            def timed(x, packed, bias, desc):
-                hot = self.enabled and desc.cin_real == 32 and desc.stride == 1
-                if not hot:
-                    return inner(x, packed, bias, desc)
+
+        def wrap(inner, key, hot):
+            def timed(*a, **kw):
+                if not (self.enabled and hot(*a)):
+                    return inner(*a, **kw)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                out = inner(x, packed, bias, desc)
+                out = inner(*a, **kw)
                 e.record()
-                self.pairs.append((s, e))
+                self.pairs[key].append((s, e))
                 return out
             return timed
-        ops.conv_fwd_bits = wrap(ops.conv_fwd_bits)
-        ops.conv_wino_fwd_bits = wrap(ops.conv_wino_fwd_bits)
-        ops.conv_wino2_fwd_bits = wrap(ops.conv_wino2_fwd_bits)
+        is_c2 = lambda x, packed, bias, desc: desc.cin_real == 32 and desc.stride == 1      # noqa: E731
+        ops.conv_fwd_bits = wrap(ops.conv_fwd_bits, "c2_fwd", is_c2)
+        ops.conv_wino_fwd_bits = wrap(ops.conv_wino_fwd_bits, "c2_fwd", is_c2)
+        ops.conv_wino2_fwd_bits = wrap(ops.conv_wino2_fwd_bits, "c2_fwd", is_c2)
+        ops.conv_wino2_dgrad_w1 = wrap(ops.conv_wino2_dgrad_w1, "c2_dgrad_w1", lambda *a: True)
 
-    def mean_ms(self):
-        return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
+    def mean_ms(self, key):
+        p = self.pairs[key]
+        return sum(s.elapsed_time(e) for s, e in p) / len(p) if p else None
 
 
-def measured_traffic():
-    """HBM bytes per c2-forward launch from the committed rocprofv3 PMC passes (profiles/*_c2_fwd_traffic.json,
-    written by tools/pmc_traffic.py); None when no such profile exists.  PMC collection needs the profiler, so it
-    cannot be live inside this process."""
+def measured_traffic(pattern):
+    """HBM bytes per launch from a committed rocprofv3 PMC profile (tools/pmc_traffic.py writes these files; PMC collection
+    needs the profiler, so it cannot be live inside this process) -> (bytes, "profiles/<file>") or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c2_fwd_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def host_cores():
@@ -117,14 +172,22 @@ def host_cores():
     return int(os.environ.get("DD_CPU_THREADS", min(n, 16)))
 
 
-def cpu_baseline(sample_batch=4, steps=2):
-    """The CPU oracle (oracle/: pure-torch restatement of the reference path) timed on this host's cores.
-
-    Bounded sample: the same step (stitch -> encoder -> head -> BCE -> backward -> torch Adam) at bs = 4,
-    one warm-up + ``steps`` timed steps (~10-30 s)."""
+def cpu_baseline(sample_batch=4, steps=5):
+    """The CPU oracle (oracle/: pure-torch restatement of the reference path) timed on this host's cores: the headline
+    config-2 step and the config-1 autoencoder step, each on a bounded sample (bs = 4, 1 warm-up + ``steps`` timed steps)."""
+    import numpy as np
+    import torch
     from oracle import ae_parts, steps as osteps
     cores = host_cores()
     torch.set_num_threads(cores)
+
+    def timed(step):
+        step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        return (time.perf_counter() - t0) / steps
+
     torch.manual_seed(SEED)
     enc = ae_parts.EncoderNet(HIDDEN, LATENT, 3, H, 6 * W)
     head = torch.nn.Linear(LATENT, 800 * 800)
@@ -134,41 +197,124 @@ def cpu_baseline(sample_batch=4, steps=2):
     road = torch.rand(sample_batch, 800, 800, generator=g) < 0.3
     batch = (tuple(views), None, tuple(road))
 
-    def step():
+    def roadmap_step():
         opt.zero_grad(set_to_none=True)
-        loss = osteps.roadmap_bce_loss(enc, head, batch)[0]
-        loss.backward()
+        osteps.roadmap_bce_loss(enc, head, batch)[0].backward()
         opt.step()
-    step()
+    dt = timed(roadmap_step)
+    out = {"value": round(sample_batch / dt, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
+           "sample": f"oracle roadmap step (config 2) fwd+bwd+Adam, bs={sample_batch}, {steps} timed steps after 1 warm-up, "
+                     f"{dt:.2f} s/step, torch {torch.__version__} CPU"}
+    del opt, head
+    # config 1 (BASELINE.json configs[0]: the reference's own CPU-runnable case): masked-view autoencoder step, bs = 4
+    dec = ae_parts.DecoderNet(HIDDEN, LATENT, 3, H, W)
+    opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=1e-3)
+    rng = np.random.RandomState(SEED)
+
+    def ae_step():
+        opt.zero_grad(set_to_none=True)
+        osteps.ae_loss(enc, dec, views, rng)[0].backward()
+        opt.step()
+    dt1 = timed(ae_step)
+    out["config1_ae"] = {"value": round(sample_batch / dt1, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
+                         "sample": f"oracle BasicAE step (config 1: src/autoencoder/autoencoder.py, bs={sample_batch}) fwd+bwd+Adam, "
+                                   f"{steps} timed steps after 1 warm-up, {dt1:.2f} s/step"}
+    return out
+
+
+def time_steps(step, steps, warmup):
+    import torch
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(sample_batch / dt, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"oracle roadmap step fwd+bwd+Adam, bs={sample_batch}, {steps} timed steps after 1 warm-up, "
-                      f"{dt:.2f} s/step, torch {torch.__version__} CPU"}
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
-    ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
-    ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
-    ap.add_argument("--latent", type=int, default=LATENT, help="latent width (64; with --hidden 256: 128)")
-    ap.add_argument("--wino-1d", action="store_true", help="c2 forward / data gradient by F(2,3) along x instead of F(2x2,3x3)")
-    ap.add_argument("--direct-conv", action="store_true", help="c2 forward / data gradient on the direct kernels instead of Winograd F(2,3)")
-    ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
-    a = ap.parse_args()
+def other_configs(dev, steps=5, warmup=2):
+    """Per-GPU step rates of the other BASELINE configurations, measured in this process after the headline timing (same
+    synthetic-data conventions; diagnostic numbers, not `value`)."""
+    import torch
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.optim import HipAdam
+    from driving_dirty_amd.roadmap import RoadMapBCE
+    from driving_dirty_amd.spatial import BBSpatialRoadMap
+    res = {}
+
+    def finish(name, dt, batch, extra=None):
+        res[name] = dict({"ms_per_step": round(dt * 1e3, 3), "scenes_per_s": round(batch / dt, 1), "batch": batch}, **(extra or {}))
+
+    # config 1's GPU twin: BasicAE masked-view pre-training step (autoencoder.py:78-93), fwd+bwd+Adam
+    for b in (4, BATCH):
+        torch.manual_seed(SEED)
+        ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, learning_rate=1e-3, output_img_freq=500)).to(dev)
+        opt = HipAdam(ae.parameters(), lr=1e-3)
+        opt.overlap_with_backward()
+        views = torch.rand(b, 6, 3, H, W, device=dev)
+
+        def ae_step(i):
+            ae.zero_grad(set_to_none=True)
+            ae.training_step(views, i)["loss"].backward()
+            opt.step()
+        finish(f"config1_ae_pretrain_bs{b}", time_steps(ae_step, steps, warmup), b, {"dtype": "f32"})
+        opt.close()
+        del ae, opt, views
+        torch.cuda.empty_cache()
+    # config 3: BBSpatialRoadMap, frozen AE encoder (spatial_w_rm.py), bs = 32, fwd+bwd+Adam on the heads
+    torch.manual_seed(SEED)
+    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT))
+    m = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=10 ** 9, learning_rate=1e-3, output_img_freq=500, mse_loss=False)).to(dev)
+    opt = HipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    views = torch.rand(BATCH, 6, 3, H, W, device=dev)
+    road = torch.rand(BATCH, 800, 800, device=dev) < 0.3
+    tgt = tuple({"bb_map": (torch.rand(800, 800, device=dev) < 0.02).float()} for _ in range(BATCH))
+    batch = (tuple(views), tgt, tuple(road))
+
+    def bbox_step(i):
+        m.zero_grad(set_to_none=True)
+        m.training_step(batch, i)["loss"].backward()
+        opt.step()
+    dt = time_steps(bbox_step, steps, warmup)
+    gf = (69.14 + 138.28 + 11.64) * BATCH       # head fwd + head bwd + frozen encoder fwd, GFLOP per step (SURVEY.md 8d)
+    finish("config3_bbox_frozen_encoder_bs32", dt, BATCH, {"dtype": "f32", "algorithmic_TFLOPs": round(gf / dt / 1e3, 1),
+                                                           "frac_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_F32_MFMA_TF, 3)})
+    del m, ae, opt, batch, views, road, tgt
+    torch.cuda.empty_cache()
+    # config 5, per GPU: bf16 mixed precision at 2x resolution (6x3x512x612), bs = 16, roadmap step fwd+bwd+Adam
+    torch.manual_seed(SEED)
+    h2, w2, b5 = 2 * H, 2 * W, 16
+    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, input_height=h2, input_width=6 * w2, output_height=h2, output_width=w2))
+    m = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
+    batch = (tuple(torch.rand(b5, 6, 3, h2, w2, device=dev)), None, tuple(torch.rand(b5, 800, 800, device=dev) < 0.3))
+    m.training_step(batch, 0)["loss"].backward()
+    m.zero_grad(set_to_none=True)
+    opt = HipAdam(m.parameters(), lr=1e-3)
+    opt.overlap_with_backward()
+
+    def bf16_step(i):
+        m.zero_grad(set_to_none=True)
+        m.training_step(batch, i)["loss"].backward()
+        opt.step()
+    finish("config5_bf16_2x_resolution_bs16", time_steps(bf16_step, steps, warmup), b5, {"dtype": "bf16 (fp32 master weights, accumulate, tail)"})
+    opt.close()
+    return res
+
+
+def run_rank(a):
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("DD_RESERVED_CUS", "16"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE {world}: start either `python bench.py --gpus N` (self-launching) or "
+                         f"torch.distributed.run with --nproc-per-node equal to --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # one process per GPU; DD_DIST_BACKEND=gloo + several ranks on ONE card is only a rehearsal of the N > 1
@@ -182,9 +328,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run for N > 1"
 
     from driving_dirty_amd import _lib
+    from driving_dirty_amd import ops as _ops
     from driving_dirty_amd.ddp import GradSync
     from driving_dirty_amd.optim import HipAdam
     _lib.lib()                                            # fail loudly if the HIP library is missing
@@ -197,17 +343,15 @@ def main():
 
     globals().update(HIDDEN=a.hidden, LATENT=a.latent)
     if a.direct_conv:
-        from driving_dirty_amd import ops as _o
-        _o.WINOGRAD = False
+        _ops.WINOGRAD = False
     if a.wino_1d:
-        from driving_dirty_amd import ops as _o
-        _o.WINOGRAD_2D = False
+        _ops.WINOGRAD_2D = False
     model = build_model(dev)
     model.ae.encoder.rows_per_task = a.rows_per_task
     model.training_step(synthetic_batch(dev, 2, rank), 0)["loss"].backward()   # unfreezes the AE (epoch 0 >= 0)
     model.zero_grad(set_to_none=True)
     opt = HipAdam(model.parameters(), lr=1e-3)
-    sync = GradSync(model, reserve_cus=reserve)
+    sync = GradSync(model, reserve_cus=reserve)          # broadcasts rank 0's parameters and buffers
     if not a.no_adam_overlap:
         opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if world > 1 else None)
     batch = synthetic_batch(dev, BATCH, rank)
@@ -238,44 +382,85 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    n_ranks_seen = 1
     if world > 1:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, device=cdev, dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # every rank that took part in the timed region counts itself
+        n_ranks_seen = int(round(float(ones.item())))
     loss_val = float(loss.detach())
 
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * BATCH * a.steps / dt
-        k_ms = timer.mean_ms()
-        assert timer.pairs, "the dominant kernel was never launched through the timed entry point"
-        achieved = C2_FLOP_PER_SCENE * BATCH / (k_ms * 1e-3) / 1e12      # ALGORITHMIC flops (direct-convolution count)
-        from driving_dirty_amd import ops as _ops
         wino = bool(_ops.WINOGRAD)
         wino2 = wino and bool(_ops.WINOGRAD_2D)
+        issue = 4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0      # share of the direct form's multiplies a Winograd kernel issues
+        fwd_ms, dg_ms = timer.mean_ms("c2_fwd"), timer.mean_ms("c2_dgrad_w1")
+        assert fwd_ms is not None, "the c2 forward kernel was never launched through the timed entry point"
+        kernels = {}
+        algo = C2_FLOP_PER_SCENE * BATCH
+        kernels["c2_forward"] = {
+            "kernel": "conv_wino2_fwd<BIAS_RELU_BITS>" if wino2 else "conv_wino_fwd" if wino else "conv_strip_fwd<32,1>",
+            "launch_ms": round(fwd_ms, 4), "launches_timed": len(timer.pairs["c2_fwd"]),
+            "issued_TFLOPs": round(algo * issue / (fwd_ms * 1e-3) / 1e12, 2), "algorithmic_equiv_TFLOPs": round(algo / (fwd_ms * 1e-3) / 1e12, 2),
+            "mfma_frac": round(algo * issue / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
+            # reads a1 (128 B/pixel), writes a2 (128 B/pixel) + one sign word per pixel
+            "hbm_frac": round(PIXELS_PER_SCENE * BATCH * 260.0 / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        if dg_ms is not None:
+            # c2's data gradient by F(2x2,3x3) (4/9 of the direct multiplies) + c1's weight gradient taken from the masked outputs in
+            # registers: 64 more MFMAs on every 256.  Reads g2 (128 B/pixel), one sign word and 16 B of image per pixel.
+            issued = algo * issue * (320.0 / 256.0)
+            kernels["c2_dgrad_w1"] = {
+                "kernel": "conv_wino2_fwd<RELU_BITS_W1> (c2 data gradient + fused c1 weight gradient)",
+                "launch_ms": round(dg_ms, 4), "launches_timed": len(timer.pairs["c2_dgrad_w1"]),
+                "issued_TFLOPs": round(issued / (dg_ms * 1e-3) / 1e12, 2),
+                "algorithmic_equiv_TFLOPs": round((algo + C1_WGRAD_FLOP_PER_SCENE * BATCH) / (dg_ms * 1e-3) / 1e12, 2),
+                "mfma_frac": round(issued / (dg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
+                "hbm_frac": round(PIXELS_PER_SCENE * BATCH * 148.0 / (dg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])          # the kernel with the largest in-step time
+        traffic, source = measured_traffic("*_c2_dgrad_w1_traffic.json" if dom == "c2_dgrad_w1" else "*_c2_fwd_traffic.json")
+        k = kernels[dom]
         line = {
             "metric": "6-view scenes/sec fwd+bwd, roadmap model bs=32",
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "n_ranks_seen": n_ranks_seen,
             "config": {"workload": "BASELINE configs[1]: roadmap segmentation 6x3x256x306 -> 800x800 mask, "
                                    "bs=32 per GPU, fp32, hidden %d / latent %d, encoder unfrozen, fwd+bwd+Adam" % (HIDDEN, LATENT),
                        "global_batch": world * BATCH, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
-            "step_frac_of_fp32_mfma_peak": round(step_flop_per_scene() * BATCH * world / (ms * 1e-3) / 1e12
-                                                 / (PEAK_F32_MFMA_TF * world), 4),
-            "roofline": {"kernel": ("conv_wino2_fwd (c2 forward, Winograd F(2x2,3x3): issues 4/9 of the algorithmic flops)" if wino2 else
-                                    "conv_wino_fwd (c2 forward, Winograd F(2,3) along x: issues 2/3 of the algorithmic flops)"
-                                    if wino else "conv_strip_fwd<CIN=32,S=1> (c2 forward, direct)") + ", 74% of encoder FLOPs fwd",
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": measured_traffic(),
-                         "launch_ms": round(k_ms, 4), "launches_timed": len(timer.pairs),
-                         "issued_frac": round(achieved * (4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TF, 4)},
+            "step_algorithmic_frac_of_fp32_mfma_peak": round(step_flop_per_scene() * BATCH * world / (ms * 1e-3) / 1e12
+                                                             / (PEAK_F32_MFMA_TF * world), 4),
+            # the kernel that takes the most time in the step.  achieved = MFMA flops the kernel ISSUES per launch (a Winograd kernel
+            # issues 4/9 of the direct form's) / its mean launch duration from HIP events inside the timed region: frac <= 1 is the
+            # share of the fp32 matrix pipe in use.  `algorithmic_equiv` is the direct-convolution flop count over the same time.
+            "roofline": {"kernel": k["kernel"], "bound": "mfma", "achieved": k["issued_TFLOPs"], "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                         "frac": k["mfma_frac"], "algorithmic_equiv": k["algorithmic_equiv_TFLOPs"], "hbm_frac": k["hbm_frac"],
+                         "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"],
+                         "traffic": traffic, "traffic_source": source,
+                         "kernels": kernels},
         }
+        if world == 1 and not a.no_others:
+            opt.close()
+            del model, opt, sync, batch
+            torch.cuda.empty_cache()
+            line["others"] = other_configs(dev)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))          # the parent: no torch import, no GPU call
+    run_rank(a)
 
 
 if __name__ == "__main__":

@@ -542,26 +542,29 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce(const float* __restric
                                                           float* __restrict__ db, int nw) {
   constexpr int NT = (CIN == 32) ? 9 : 1;
   constexpr int G = 16;
-  __shared__ float red[G][64];
+  __shared__ double red[G][64];
   const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int row = blockIdx.x;   // (t*16 + r), or NT*16 for the bias
   const float* src = (row < NT * 16) ? part + (long)row * 64 + l : bpart + l;
   const long stride = (row < NT * 16) ? (long)NT * 16 * 64 : 64;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // The partials of different images largely CANCEL in these sums (the upstream gradient has zero batch mean behind a
+  // train-mode BatchNorm, the activations a large common mean), so the second stage runs in fp64: a few thousand adds.
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int w = g;
   for (; w + 3 * G < nw; w += 4 * G) {
-    s0 += src[(long)w * stride];
-    s1 += src[(long)(w + G) * stride];
-    s2 += src[(long)(w + 2 * G) * stride];
-    s3 += src[(long)(w + 3 * G) * stride];
+    s0 += (double)src[(long)w * stride];
+    s1 += (double)src[(long)(w + G) * stride];
+    s2 += (double)src[(long)(w + 2 * G) * stride];
+    s3 += (double)src[(long)(w + 3 * G) * stride];
   }
-  for (; w < nw; w += G) s0 += src[(long)w * stride];
+  for (; w < nw; w += G) s0 += (double)src[(long)w * stride];
   red[g][l] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g != 0) return;
-  float s = 0.f;
+  double sd = 0.0;
 #pragma unroll
-  for (int i = 0; i < G; ++i) s += red[i][l];
+  for (int i = 0; i < G; ++i) sd += red[i][l];
+  const float s = (float)sd;
   if (row < NT * 16) {
     const int t = row >> 4, r = row & 15;
     const int o = dd_acc_row(r, l), j = l & 31;
@@ -571,8 +574,8 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce(const float* __restric
       dw[((long)o * 3 + (j % 3)) * 9 + (j / 3)] = s;
     }
   } else {
-    const float other = __shfl_xor(s, 32);   // lanes l and l+32 hold the two pixel parities of channel l&31
-    if (l < 32) db[l] = s + other;
+    const double other = __shfl_xor(sd, 32);   // lanes l and l+32 hold the two pixel parities of channel l&31
+    if (l < 32) db[l] = (float)(sd + other);
   }
 }
 

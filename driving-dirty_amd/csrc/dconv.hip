@@ -1,0 +1,354 @@
+// Dilated stride-1 convolutions of the box heads on the fp32 matrix cores, phase-decomposed and LDS-staged:
+//
+//   RoadMapBoxesMergingCNN  up_conv_1..4  ConvTranspose2d 96->64, 64->32, 32->16 (k7 d7), 16->8 (k7 d3)   spatial_bb/components.py:135-138
+//   BoxesMergingCNN         up_conv_1..3  ConvTranspose2d 64->32, 32->16 (k8 d8), 16->8 (k6 d6, output_padding 2)      :90-92
+//
+// forward (flipped-tap gather, pad d(k-1)) and data gradient (plain gather, pad 0) of each: 31.5 of the 33.6 G MAC of
+// the head.  The generic engine (gconv.hip) gathers the A operand of every MFMA from L1/L2 and streams the weight image
+// per 32-pixel row tile: 256 B of operand traffic per MFMA, 46-55 % of the matrix peak.  Here:
+//
+//   * rows of equal residue  oy mod d  share their input rows (taps are d rows apart): a workgroup owns RA output rows of
+//     ONE residue class ("phase rows") x XT output columns and needs only RA + k - 1 input rows for all k tap rows;
+//   * the input patch of one 8-channel chunk -- (RA + k - 1) rows x (XT + d(k-1)) columns x 32 B -- sits in LDS (double
+//     buffered: chunk q + 1 is fetched while chunk q is multiplied); every tap of every wave reads it with one
+//     ds_read_b128 per 4 MFMAs at an address = per-lane constant + tap offset (1 KB contiguous per wave: conflict-free);
+//   * a wave owns 64 pixels (two 32-pixel m-tiles) of one phase row x all Cout (NT column tiles): the weight fragment of a
+//     (chunk, tap) is loaded once per 8*NT MFMAs with lane-linear 16-byte loads at a SCALAR offset (no address VALU);
+//   * taps that touch no input pixel for the whole wave (border rows / columns of the flipped form) are skipped.
+//
+// GEMM per (wave, chunk, tap): M = 64 pixels, N = Cout, K = 8 channels; k index pairing of v_mfma_f32_32x32x2_f32:
+// lane (h = l >> 5, n = l & 31) holds channels 4h..4h+3 of pixel n (A) and of output column n (B); MFMA i multiplies
+// channels (i, 4 + i).
+#include "dd_common.h"
+
+namespace {
+
+constexpr int DC_THREADS = 512;
+
+template <int K, int D>
+struct DcGeom {
+  static constexpr int HALO = D * (K - 1);
+  static constexpr int TWA = 128 + HALO, THA = 4 + K - 1;      // shape A: 4 phase rows x 128 columns
+  static constexpr int TWB = 64 + HALO, THB = 8 + K - 1;       // shape B: 8 phase rows x 64 columns
+  static constexpr int PXA = TWA * THA, PXB = TWB * THB;
+  static constexpr int PX = PXA > PXB ? PXA : PXB;              // pixels of one LDS buffer (32 B each)
+  static constexpr int NP = (2 * PX + DC_THREADS - 1) / DC_THREADS;      // 16-byte pieces per thread and fill
+};
+
+struct DcTile {
+  int b, r, a0, x0, ra, xt;      // image, residue, first phase row, first column, rows and columns of the tile
+};
+
+// Tiles are numbered image-major, then residue, then shape-A tiles (x tile, row group), then shape-B tiles.
+struct DcPlan {
+  int rows_max;          // phase rows of the longest residue class: ceil(out_h / D)
+  int nxa, nxb;          // x tiles of shape A (128 wide) and of shape B (64 wide, at most one, the last)
+  int ga, gb;            // row groups of 4 / of 8
+  int per_res, total;
+};
+
+__host__ __device__ inline DcPlan dc_plan(const dd_gconv_desc& d, int D) {
+  DcPlan p;
+  p.rows_max = (d.out_h + D - 1) / D;
+  p.nxa = d.out_w / 128;
+  const int rem = d.out_w - p.nxa * 128;
+  p.nxb = 0;
+  if (rem > 64) p.nxa += 1; else if (rem > 0) p.nxb = 1;
+  p.ga = (p.rows_max + 3) / 4;
+  p.gb = (p.rows_max + 7) / 8;
+  p.per_res = p.nxa * p.ga + p.nxb * p.gb;
+  p.total = p.per_res * D * d.batch;
+  return p;
+}
+
+__device__ __forceinline__ DcTile dc_tile(const DcPlan& p, int D, int t) {
+  DcTile o;
+  const int per_img = p.per_res * D;
+  o.b = t / per_img;
+  t -= o.b * per_img;
+  o.r = t / p.per_res;
+  t -= o.r * p.per_res;
+  if (t < p.nxa * p.ga) {
+    const int xt = t / p.ga;
+    o.ra = 4; o.xt = 128; o.x0 = xt * 128; o.a0 = (t - xt * p.ga) * 4;
+  } else {
+    t -= p.nxa * p.ga;
+    o.ra = 8; o.xt = 64; o.x0 = p.nxa * 128; o.a0 = t * 8;
+  }
+  return o;
+}
+
+template <int K, int D, int NT>
+__global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, const float* __restrict__ msk,
+                                                               float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
+  using G = DcGeom<K, D>;
+  constexpr int T = K * K;
+  __shared__ __attribute__((aligned(16))) float lds[2][G::PX * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, n = lane & 31;
+  const DcPlan plan = dc_plan(d, D);
+  const int NC = d.cin >> 3;
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+  const __amdgpu_buffer_rsrc_t ws = dd_rsrc(wp, wp_bytes);
+
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && nt * 32 + n < d.cout) ? bias[nt * 32 + n] : 0.f;
+
+  // ---- fill state: the 16-byte pieces this thread fetches for a tile (piece p = pixel p >> 1, channel half p & 1)
+  int voff[G::NP];
+  auto plan_fill = [&](const DcTile& tl) {
+    const int tw = tl.xt + G::HALO, npc = (tl.ra + K - 1) * tw * 2;
+    const int iy0 = tl.r + D * tl.a0 - d.pad_h, ix0 = tl.x0 - d.pad_w;
+#pragma unroll
+    for (int i = 0; i < G::NP; ++i) {
+      const int p = tid + DC_THREADS * i, px = p >> 1;
+      const int l = px / tw, lam = px - l * tw;
+      const int iy = iy0 + D * l, ix = ix0 + lam;
+      const bool ok = p < npc && (unsigned)iy < (unsigned)d.in_h && (unsigned)ix < (unsigned)d.in_w;
+      voff[i] = ok ? ((iy * d.in_w + ix) * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : -16;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= plan.total) return;
+  DcTile tile = dc_tile(plan, D, t);
+  plan_fill(tile);
+  {   // first chunk of the first tile
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)tile.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+#pragma unroll
+    for (int i = 0; i < G::NP; ++i) {
+      const f32x4 v = dd_bload4(xs, voff[i]);
+      if (tid + DC_THREADS * i < 2 * G::PX) *(f32x4*)&lds[0][(tid + DC_THREADS * i) * 4] = v;      // pieces past the tile: zeros into the slack
+    }
+  }
+  __syncthreads();
+  int par = 0;
+  for (; t < plan.total; t += gridDim.x) {
+    const int tnext = t + gridDim.x;
+    // ---- this wave's share of the tile
+    const int tw = tile.xt + G::HALO;
+    const int row = tile.ra == 4 ? (wave & 3) : wave, xh = tile.ra == 4 ? (wave >> 2) : 0;
+    const int a = tile.a0 + row, oy = tile.r + D * a;
+    const int xw = tile.x0 + 64 * xh;
+    const bool row_ok = oy < d.out_h && xw < d.out_w;
+    const bool mt1 = xw + 32 < d.out_w;
+    // valid tap rows / columns (the whole wave): input row oy + D*ky - pad_h in [0, in_h), some column of the wave's
+    // 64 pixels xw + [0, 63] + D*kx - pad_w in [0, in_w)
+    int ky0 = 0, ky1 = -1, kx0 = 0, kx1 = -1;
+    if (row_ok) {
+      const int ry = oy - d.pad_h;
+      ky0 = ry >= 0 ? 0 : (-ry + D - 1) / D;
+      ky1 = min(K - 1, (d.in_h - 1 - ry) >= 0 ? (d.in_h - 1 - ry) / D : -1);
+      const int xlo = xw - d.pad_w, xhi = min(xw + 63, d.out_w - 1) - d.pad_w;
+      kx0 = xhi >= 0 ? 0 : (-xhi + D - 1) / D;
+      kx1 = min(K - 1, (d.in_w - 1 - xlo) >= 0 ? (d.in_w - 1 - xlo) / D : -1);
+    }
+    const int nky = max(ky1 - ky0 + 1, 0), nkx = max(kx1 - kx0 + 1, 0), ntaps = nky * nkx;
+    const int abase = ((row * tw + 64 * xh + n) * 8 + 4 * h) * 4;      // byte offset of this lane's pixel in an LDS buffer
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+
+    DcTile next = tile;
+    for (int q = 0; q < NC; ++q) {
+      // ---- request the next fill (next chunk of this tile, or chunk 0 of the workgroup's next tile)
+      const bool last = q + 1 == NC;
+      bool have_next = true;
+      if (last) {
+        have_next = tnext < plan.total;
+        if (have_next) {
+          next = dc_tile(plan, D, tnext);
+          plan_fill(next);
+        }
+      }
+      f32x4 stage[G::NP];
+      if (have_next) {
+        const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)next.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+        const int soff = last ? 0 : 32 * (q + 1);
+#pragma unroll
+        for (int i = 0; i < G::NP; ++i)
+          stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, voff[i], soff, 0));
+      }
+      // ---- multiply chunk q out of lds[par]
+      if (ntaps > 0) {
+        const char* lbase = (const char*)&lds[par][0] + abase;
+        int ky = ky0, kx = kx0;
+        f32x4 A0[2], A1[2], B[2][NT];
+        auto load_tap = [&](int slot, int cky, int ckx) {
+          const char* p = lbase + (cky * tw + ckx * D) * 32;
+          A0[slot] = *(const f32x4*)p;
+          A1[slot] = *(const f32x4*)(p + 1024);
+          const int soff = ((q * T + cky * K + ckx) * NT) * 1024;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            B[slot][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff + nt * 1024, 0));
+        };
+        auto mul_tap = [&](int slot) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[0][nt] = DD_MFMA(A0[slot].x, B[slot][nt].x, acc[0][nt]);
+            acc[0][nt] = DD_MFMA(A0[slot].y, B[slot][nt].y, acc[0][nt]);
+            acc[0][nt] = DD_MFMA(A0[slot].z, B[slot][nt].z, acc[0][nt]);
+            acc[0][nt] = DD_MFMA(A0[slot].w, B[slot][nt].w, acc[0][nt]);
+          }
+          if (mt1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[1][nt] = DD_MFMA(A1[slot].x, B[slot][nt].x, acc[1][nt]);
+              acc[1][nt] = DD_MFMA(A1[slot].y, B[slot][nt].y, acc[1][nt]);
+              acc[1][nt] = DD_MFMA(A1[slot].z, B[slot][nt].z, acc[1][nt]);
+              acc[1][nt] = DD_MFMA(A1[slot].w, B[slot][nt].w, acc[1][nt]);
+            }
+          }
+        };
+        auto advance = [&]() { if (++kx > kx1) { kx = kx0; ++ky; } };
+        load_tap(0, ky, kx);
+        advance();
+        for (int i = 0; i < ntaps; i += 2) {
+          if (i + 1 < ntaps) { load_tap(1, ky, kx); advance(); }
+          __builtin_amdgcn_sched_barrier(0);          // tap i+1 is requested before tap i is multiplied
+          mul_tap(0);
+          if (i + 2 < ntaps) { load_tap(0, ky, kx); advance(); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < ntaps) mul_tap(1);
+        }
+      }
+      // ---- retire the staged pieces into the other buffer (read last one step ago, a barrier since)
+      if (have_next) {
+#pragma unroll
+        for (int i = 0; i < G::NP; ++i)
+          if (tid + DC_THREADS * i < 2 * G::PX) *(f32x4*)&lds[par ^ 1][(tid + DC_THREADS * i) * 4] = stage[i];
+      }
+      __syncthreads();
+      par ^= 1;
+    }
+
+    // ---- epilogue of the tile
+    if (row_ok) {
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)tile.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)tile.b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !mt1) break;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ch = nt * 32 + n;
+          const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int xo = xw + 32 * j + dd_acc_row(r, lane);
+            const bool ok = xo < d.out_w && ch < d.cout;
+            const int off = ok ? (((oy + d.ooff_h) * d.omem_w + xo + d.ooff_w) * d.out_cstore + d.out_coff + ch) * 4 : -16;
+            float v = acc[j][nt][r] + bv[nt];
+            if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            if (epi == DD_EPI_RELU_MASK) v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
+            dd_bstore1(ys, off, v);
+          }
+        }
+      }
+    }
+    tile = next;
+  }
+}
+
+// packed[(((q*T + tap)*NT + nt)*64 + lane)*4 + i] = W(n = nt*32 + (lane & 31), c = 8q + 4*(lane >> 5) + i, tap)
+__global__ void dconv_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int nchunks, int nt_count, int T, long w_off,
+                                  long sn, long sc, int flip, int n_real, int c_real) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)nchunks * T * nt_count * 256;
+  if (idx >= total) return;
+  const int i = idx & 3, lane = (idx >> 2) & 63;
+  long g = idx >> 8;
+  const int nt = (int)(g % nt_count);
+  g /= nt_count;
+  const int tap = (int)(g % T), q = (int)(g / T);
+  const int c = 8 * q + 4 * (lane >> 5) + i, n = nt * 32 + (lane & 31);
+  float v = 0.f;
+  if (n < n_real && c < c_real) v = w[w_off + n * sn + c * sc + (flip ? T - 1 - tap : tap)];
+  p[idx] = v;
+}
+
+int dc_variant(const dd_gconv_desc* d) {      // index of the (K, D) instantiation, -1 if this is not one of the box heads' layers
+  if (d->kh != d->kw || d->dil_h != d->dil_w) return -1;
+  const int k = d->kh, dl = d->dil_h;
+  if (k == 7 && dl == 7) return 0;
+  if (k == 7 && dl == 3) return 1;
+  if (k == 8 && dl == 8) return 2;
+  if (k == 6 && dl == 6) return 3;
+  return -1;
+}
+
+bool dc_supported(const dd_gconv_desc* d) {
+  return d && dc_variant(d) >= 0 && d->stride_h == 1 && d->stride_w == 1 && d->div_h == 1 && d->div_w == 1 && d->ostride_h == 1 &&
+         d->ostride_w == 1 && d->cin > 0 && d->cin % 8 == 0 && d->in_coff % 4 == 0 && d->in_cstore % 4 == 0 &&
+         d->in_coff + d->cin <= d->in_cstore && d->cout > 0 && d->cout <= 96 && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_cstore &&
+         d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->out_h > 0 && d->out_w > 0 && d->pad_h >= 0 && d->pad_w >= 0 &&
+         d->ooff_h >= 0 && d->ooff_w >= 0 && d->out_h + d->ooff_h <= d->omem_h && d->out_w + d->ooff_w <= d->omem_w &&
+         (long)d->in_h * d->in_w * d->in_cstore * 4 < (1L << 31) && (long)d->omem_h * d->omem_w * d->out_cstore * 4 < (1L << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dd_dconv_supported(const dd_gconv_desc* d) { return dc_supported(d) ? 1 : 0; }
+
+int64_t dd_dconv_packed_floats(const dd_gconv_desc* d) {
+  if (!dc_supported(d)) {
+    dd_fail(DD_ERR_UNSUPPORTED, "dconv: not a stride-1 k7d7 / k7d3 / k8d8 / k6d6 layer with Cin %% 8 == 0 and Cout <= 96");
+    return -1;
+  }
+  return (int64_t)(d->cin / 8) * d->kh * d->kw * ((d->cout + 31) / 32) * 256;
+}
+
+int dd_dconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc, int32_t flip,
+                  int32_t n_real, int32_t c_real, void* stream) {
+  DD_REQUIRE(dc_supported(d), DD_ERR_UNSUPPORTED, "dconv_pack: unsupported layer");
+  DD_REQUIRE(w && packed, DD_ERR_BAD_ARG, "dconv_pack: NULL pointer");
+  DD_REQUIRE(n_real > 0 && n_real <= d->cout && c_real > 0 && c_real <= d->cin, DD_ERR_BAD_ARG, "dconv_pack: n_real/c_real");
+  const int nt = (d->cout + 31) / 32, T = d->kh * d->kw;
+  const long total = (long)(d->cin / 8) * T * nt * 256;
+  hipLaunchKernelGGL(dconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, d->cin / 8, nt,
+                     T, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real);
+  DD_LAUNCH_CHECK("dconv_pack");
+  return 0;
+}
+
+int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                 int32_t epilogue, void* stream) {
+  DD_REQUIRE(dc_supported(d), DD_ERR_UNSUPPORTED, "dconv_fwd: unsupported layer");
+  DD_REQUIRE(x && packed && y, DD_ERR_BAD_ARG, "dconv_fwd: NULL pointer");
+  DD_REQUIRE(epilogue == DD_EPI_NONE || epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU || epilogue == DD_EPI_RELU_MASK,
+             DD_ERR_BAD_ARG, "dconv_fwd: epilogue %d", epilogue);
+  DD_REQUIRE(epilogue != DD_EPI_RELU_MASK || mask, DD_ERR_BAD_ARG, "dconv_fwd: RELU_MASK needs a mask");
+  DD_REQUIRE(!(epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) || bias, DD_ERR_BAD_ARG, "dconv_fwd: bias epilogue needs a bias");
+  hipStream_t st = (hipStream_t)stream;
+  const int nt = (d->cout + 31) / 32;
+  const int wp_bytes = (int)(dd_dconv_packed_floats(d) * 4);
+  const DcPlan plan = dc_plan(*d, d->dil_h);
+  const int grid = (int)max(1, min(dd_cu_budget_internal(), plan.total));      // one 8-wave workgroup per CU, all resident
+#define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes)
+#define DD_DC_NT(KK, DD_) do { if (nt == 1) DD_DC(KK, DD_, 1); else if (nt == 2) DD_DC(KK, DD_, 2); else DD_DC(KK, DD_, 3); } while (0)
+  switch (dc_variant(d)) {
+    case 0: DD_DC_NT(7, 7); break;
+    case 1: DD_DC_NT(7, 3); break;
+    case 2: DD_DC_NT(8, 8); break;
+    default: DD_DC_NT(6, 6); break;
+  }
+#undef DD_DC_NT
+#undef DD_DC
+  DD_LAUNCH_CHECK("dconv_fwd");
+  return 0;
+}
+
+}  // extern "C"

@@ -15,8 +15,14 @@ loss), long before the conv data/weight-gradient kernels where the FLOPs are.  S
   * everything else (a few hundred KB) is flattened into one buffer and reduced once at ``finish()``;
   * the sum is NOT divided here: ``HipAdam.step(grad_scale=1/world)`` folds the average into its pass.
 
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of 481 MB is per-link bound at
-~5.5 ms, which the ~8 ms of conv backward hides; nothing is gained by chopping it into small buckets.
+Budget at 8 GPUs for the 7.8 ms step of round 1 (forward 2.8 ms, backward 5.0 ms of which the MFMA-bound c2 / c1 kernels
+are the last 3.3 ms): the two big gradients exist 0.5 ms into the backward, so their all-reduce has ~4.5 ms of backward to
+hide under.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): ONE ring moves 2 x 7/8 x 648 MB through a single link
+= 7.4 ms (not hidden: +2.9 ms, 5.8x at 8 GPUs); RCCL's multi-ring / direct algorithms over all seven links need
+2 x 81 MB per link and phase = 1.1 ms at wire speed, ~3 ms at the ~330 GB/s bus bandwidth RCCL typically reaches: hidden.
+What is then left after the last byte is one 128 MB piece's Adam pass (0.35 ms) plus the small tensors: ~8.3 ms per
+step = 7.5x.  >= 6x needs the 8-GPU step <= 10.4 ms, i.e. at most 2.6 ms of exposed communication.  Constructing a
+GradSync broadcasts rank 0's parameters and buffers, so ranks cannot start from different weights.
 """
 import torch
 import torch.distributed as dist
@@ -34,6 +40,10 @@ class GradSync:
         self.reserve_cus = int(reserve_cus) if self.world > 1 else 0
         self._reserved = False
         self.params = [p for p in module.parameters()]
+        if self.world > 1:      # every replica starts from rank 0's weights and BatchNorm statistics (DDP's contract)
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=0, group=self.group)
         self._handles = []
         self._by_param = {}
         self._small = []

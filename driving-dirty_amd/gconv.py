@@ -11,6 +11,7 @@ Buffers are NHWC; a layer may read a channel slice of its input buffer and write
 sub-rectangle of its output buffer (mosaic tiling and channel concat without copies).
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -84,6 +85,27 @@ def _fwd(x, packed, bias, mask, y, d, epi):
     check(_lib.lib().dd_gconv_fwd(_p(x), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_gconv_fwd")
 
 
+# The dilated stride-1 layers (the box heads' up-convs) have their own phase-decomposed, LDS-staged kernel (csrc/dconv.hip);
+# DD_DCONV=0 routes them through the generic gather engine again (A/B knob, same results up to summation order).
+DCONV = os.environ.get("DD_DCONV", "1") != "0"
+
+
+def _dconv_ok(d):
+    return DCONV and bool(_lib.lib().dd_dconv_supported(C.byref(d)))
+
+
+def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real):
+    """pack + launch on the dilated kernel when the descriptor qualifies, on the generic one otherwise"""
+    lib = _lib.lib()
+    if _dconv_ok(d):
+        n = lib.dd_dconv_packed_floats(C.byref(d))
+        packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+        check(lib.dd_dconv_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_pack")
+        check(lib.dd_dconv_fwd(_p(x), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_dconv_fwd")
+    else:
+        _fwd(x, _pack(weight, d, w_off, sn, sc, flip, n_real, c_real), bias, mask, y, d, epi)
+
+
 def _wgrad(x, dy, dw, db, d, w_off, sn, sc, flip, n_real, c_real, accumulate):
     nbytes = _lib.lib().dd_gconv_wgrad_workspace_bytes(C.byref(d))
     if nbytes <= 0:
@@ -134,8 +156,7 @@ class Layer:
                 _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
         else:
             d = _desc(b, src, dst, cs, self.cout, self.k, (1, 1), self.dil, self._flip_pad())
-            pk = _pack(weight, d, 0, self.T, self.cout * self.T, True, self.cout, self.cin)
-            _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
+            _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.T, self.cout * self.T, True, self.cout, self.cin)
 
     # ---- data gradient: dsrc (View with the input's geometry, >= 4-aligned channels) from ddst (View of dy)
     def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0)):
@@ -144,21 +165,25 @@ class Layer:
         b = ddst.buf.shape[0]
         epi = EPI_RELU_MASK if relu_src is not None else EPI_NONE
         cin_out = self.cin
-        for n0 in range(0, cin_out, 64):                    # the kernel writes at most 64 channels per launch
+        cos = self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4
+        if self.transposed and not self.k2s2 and cin_out <= 96:
+            # the dilated kernel takes up to 96 output channels in one launch (three column tiles per wave)
+            d = _desc(b, ddst, dsrc, cos, cin_out, self.k, (1, 1), self.dil, self.pad, mask_pass=mask_pass)
+            if _dconv_ok(d):
+                _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout)
+                return
+        for n0 in range(0, cin_out, 64):                    # the generic kernel writes at most 64 channels per launch
             nn = min(64, cin_out - n0)
             out = View(dsrc.buf, dsrc.coff + n0, nn, dsrc.off_h, dsrc.off_w, dsrc.h, dsrc.w)
             msk = relu_src
             if not self.transposed:
-                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, self.k, (1, 1),
-                          self.dil, self._flip_pad(), div=self.stride, mask_pass=mask_pass)
+                d = _desc(b, ddst, out, cos, nn, self.k, (1, 1), self.dil, self._flip_pad(), div=self.stride, mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.T, self.T, self.cin * self.T, True, nn, self.cout)
             elif self.k2s2:
-                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, (2, 2), (2, 2),
-                          mask_pass=mask_pass)
+                d = _desc(b, ddst, out, cos, nn, (2, 2), (2, 2), mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.cout * 4, self.cout * 4, 4, False, nn, self.cout)
             else:
-                d = _desc(b, ddst, out, self.cout if self.cout % 4 == 0 else (self.cout + 3) // 4 * 4, nn, self.k, (1, 1),
-                          self.dil, self.pad, mask_pass=mask_pass)
+                d = _desc(b, ddst, out, cos, nn, self.k, (1, 1), self.dil, self.pad, mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.cout * self.T, self.cout * self.T, self.T, False, nn, self.cout)
             _fwd(ddst.buf, pk, None, msk, out.buf, d, epi)
 

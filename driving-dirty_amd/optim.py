@@ -76,6 +76,19 @@ class HipAdam(torch.optim.Optimizer):
                 if p.requires_grad and p.numel() >= big_numel:
                     self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, g=group: self._early_step(q, g)))
 
+    def close(self):
+        """Undo overlap_with_backward: remove the gradient hooks and the backward-phase callback (an optimizer that is dropped
+        while another model is trained in the same process would otherwise stay registered)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._flush_pending in ops.MFMA_PHASE_HOOKS:
+            ops.MFMA_PHASE_HOOKS.remove(self._flush_pending)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._side = None
+        self._sync = None
+
     def _early_step(self, p, group):
         if p.grad is not None:
             self._pending.append((p, group))      # launched when backward reaches its MFMA-bound stretch

@@ -308,6 +308,19 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
                    int64_t sn, int64_t sc, int32_t flip, int32_t n_real, int32_t c_real, int32_t accumulate,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The dilated stride-1 layers of the box heads (ConvTranspose2d k7 d7 / k7 d3 / k8 d8 / k6 d6, spatial_bb/components.py:90-92,
+ * 135-138: forward = flipped-tap gather with pad d(k-1), data gradient = plain gather) on a phase-decomposed, LDS-staged
+ * kernel: rows of equal residue mod d share their input rows, the input patch of an 8-channel chunk sits in LDS, a wave
+ * owns 64 pixels x all Cout.  Same descriptor, weight addressing (w_off, sn, sc, flip) and epilogues (NONE, BIAS, BIAS_RELU,
+ * RELU_MASK) as dd_gconv_*; needs stride 1, div 1, ostride 1, Cin % 8 == 0, Cout <= 96.  dd_dconv_supported() says
+ * whether a descriptor qualifies (callers fall back to dd_gconv_fwd otherwise). */
+int32_t dd_dconv_supported(const dd_gconv_desc* d);
+int64_t dd_dconv_packed_floats(const dd_gconv_desc* d);
+int dd_dconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc,
+                  int32_t flip, int32_t n_real, int32_t c_real, void* stream);
+int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y,
+                 const dd_gconv_desc* d, int32_t epilogue, void* stream);
+
 /* out[c] (+)= sum over the npix pixels of buf[p, coff + c], c < cout <= 128 (bias gradient of a transposed conv whose
  * weight gradient is taken in the role-swapped form, see gconv.py). */
 int64_t dd_channel_sum_workspace_bytes(void);

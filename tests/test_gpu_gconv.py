@@ -55,6 +55,13 @@ CASES = [
     ("dc4_32_3_k1", lambda: nn.ConvTranspose2d(32, 3, 1), (2, 32, 16, 22)),
     ("bm_up1_64_32_k8d8", lambda: nn.ConvTranspose2d(64, 32, 8, dilation=8), (1, 64, 5, 7)),
     ("bm_up3_k6d6_op2", lambda: nn.ConvTranspose2d(16, 8, 6, dilation=6, output_padding=2), (1, 16, 7, 9)),
+    # wide enough for the dilated kernel's 4-row x 128-column tiles, its 8-row x 64-column edge tiles and several row groups
+    ("up1_wide", lambda: nn.ConvTranspose2d(96, 64, 7, dilation=7), (1, 96, 20, 150)),
+    ("up2_wide_2img", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (2, 64, 40, 100)),
+    ("up3_tall", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 70, 30)),
+    ("up4_d3_wide", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (1, 16, 60, 140)),
+    ("bm_up1_wide", lambda: nn.ConvTranspose2d(64, 32, 8, dilation=8), (1, 64, 12, 80)),
+    ("bm_up3_wide_op2", lambda: nn.ConvTranspose2d(16, 8, 6, dilation=6, output_padding=2), (1, 16, 20, 110)),
 ]
 
 
@@ -115,6 +122,39 @@ def test_channel_slices_and_mosaic(dev):
     untouched = big_out.clone()
     untouched[:, 5:11, 30:63, 16:48] = -3.0
     assert float((untouched + 3.0).abs().max()) == 0.0
+
+
+def test_dilated_kernel_slices_mask_pass_and_generic_engine_agree(dev):
+    """The dilated up-conv kernel (csrc/dconv.hip) against the generic gather engine on the same operands, reading a channel
+    slice / writing a channel slice of wider buffers, and the data gradient's ReLU mask with an exempt channel range (the
+    spatial-map slice of the merging heads' concat buffer is an external input, not a ReLU output)."""
+    from driving_dirty_amd import gconv
+    mod = synth.fill_module(nn.ConvTranspose2d(96, 64, 7, dilation=7), seed=31)
+    wd, bd = mod.weight.detach().to(dev), mod.bias.detach().to(dev)
+    layer = gconv.Layer(96, 64, 7, dil=7, transposed=True)
+    b, h, w = 2, 21, 70
+    oh, ow = layer.out_hw(h, w)
+    x = hu((b, h, w, 96), "dcx").to(dev)
+    g = hu((b, oh, ow, 64), "dcg").to(dev)
+    outs = []
+    for on in (True, False):
+        gconv.DCONV = on
+        try:
+            y = torch.full((b, oh, ow, 80), -3.0, device=dev)
+            layer.forward(wd, bd, gconv.View(x), gconv.View(y, 8, 64), gconv.EPI_BIAS_RELU)
+            dx = torch.full((b, h, w, 96), 5.0, device=dev)
+            layer.backward_data(wd, gconv.View(g), gconv.View(dx), relu_src=x, mask_pass=(32, 64))
+            outs.append((y, dx))
+        finally:
+            gconv.DCONV = True
+    (y1, dx1), (y0, dx0) = outs
+    assert float((y1[..., :8] + 3.0).abs().max()) == 0.0 and float((y1[..., 72:] + 3.0).abs().max()) == 0.0
+    assert rel_err(y1[..., 8:72], y0[..., 8:72]) < TOL
+    assert rel_err(dx1, dx0) < TOL
+    # masked where x <= 0 outside the exempt slice, unmasked inside it
+    neg = x <= 0
+    assert float(dx1[..., :32][neg[..., :32]].abs().max()) == 0.0 and float(dx1[..., 64:][neg[..., 64:]].abs().max()) == 0.0
+    assert float(dx1[..., 32:64][neg[..., 32:64]].abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("view,tf", [(3, 0), (4, 1), (1, 2), (5, 3)])

@@ -237,10 +237,10 @@ def test_oracle_spatial_heads(golden, dt, tag, tol):
 
 @pytest.mark.slow
 def test_oracle_full_size_decoder(golden):
-    """oracle.ae_parts.DecoderNet at 256x306 (B = 2, fp64) against full_decoder.npz: the 1,253,376-feature BatchNorm1d."""
+    """oracle.ae_parts.DecoderNet at 256x306 (B = 8, fp64) against full_decoder.npz: the 1,253,376-feature BatchNorm1d."""
     g = golden("full_decoder")
     dec = _drop0(synth.fill_module(ae_parts.DecoderNet(128, 64, 3, 256, 306), seed=8)).double()
-    z = synth.hash_uniform((2, 64), synth.key_salt("full_z"), -1.0, 1.0).double().requires_grad_(True)
+    z = synth.hash_uniform((8, 64), synth.key_salt("full_z"), -1.0, 1.0).double().requires_grad_(True)
     dec.train()
     y = dec(z)
     wy = synth.hash_uniform(tuple(y.shape), synth.key_salt("full_wy")).double()
