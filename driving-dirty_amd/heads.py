@@ -16,6 +16,11 @@ from ._lib import check
 from .gconv import EPI_BIAS, EPI_BIAS_RELU, Layer, View, _p, _stream, add, view_to_nhwc4
 
 
+# Test hook: when set to a dict, the nodes below leave their ReLU outputs (NHWC) in it so that a checker can replay the
+# product's ReLU decisions (oracle.branch); None in production.
+TRACE = None
+
+
 def as_nhwc(t, cstore):
     """NCHW-shaped tensor -> NHWC buffer [B,H,W,cstore]; free when ``t`` already is a channels-last view."""
     b, c, h, w = t.shape
@@ -118,6 +123,8 @@ class SpatialMapFn(torch.autograd.Function):
         oh, ow = cls.OUT.out_hw(3 * th, 2 * tw)
         out = _empty((b, oh, ow, 32), dev)
         cls.OUT.forward(p["out_conv"][0], p["out_conv"][1], View(mosaic), View(out), EPI_BIAS_RELU)
+        if TRACE is not None:
+            TRACE.update(mosaic=mosaic, space_out=out, tile=(th, tw))
         ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
         ctx.tile = (th, tw)
         return out
@@ -196,6 +203,8 @@ class MergeFn(torch.autograd.Function):
         probs = _empty((b, 2 * u.shape[1], 2 * u.shape[2]), dev)
         check(_lib.lib().dd_deconv2x2_c1_fwd(_p(u), _p(p_last[0]), _p(p_last[1]), _p(probs), b, u.shape[1], u.shape[2], 8,
                                              _stream()), "dd_deconv2x2_c1_fwd")
+        if TRACE is not None:
+            TRACE.update(s1=s1, cat=cat, r1=r1, acts=acts)
         ctx.with_rm = with_rm
         ctx.save_for_backward(ssr, s1, rm4 if with_rm else None, r1, probs, p_ssc[0], p_ssd[0],
                               p_rm2[0] if with_rm else None, p_last[0], *[w for w, _ in p_up], *acts)

@@ -405,6 +405,10 @@ MFMA_PHASE_HOOKS = []
 FUSE_C1_WGRAD = os.environ.get("DD_FUSE_C1_WGRAD", "1") != "0"
 
 
+# Test hook: when set to a dict, EncoderConvStack.forward leaves its three ReLU outputs (NHWC) in it, so that a checker can
+# replay the product's ReLU / max-pool decisions (oracle.branch); None in production.
+TRACE = None
+
 _PACK_STREAMS = {}
 
 
@@ -474,6 +478,8 @@ class EncoderConvStack(torch.autograd.Function):
         else:
             a2, s2 = conv_fwd_bits(a1, p2, b2, d2)
         a3 = conv_fwd(a2, p3, b3, d3)
+        if TRACE is not None:
+            TRACE.update(a1=a1, a2=a2, a3=a3)
         ctx.wino = (bool(WINOGRAD), bool(WINOGRAD and WINOGRAD_2D))
         ctx.pool = int(pool)                  # 0: conv feature, 1: pooled vector, 2: both (joint roadmap + box model)
         ctx.rows_per_task = rows_per_task

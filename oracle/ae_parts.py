@@ -21,6 +21,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .branch import PLAIN
+
 POOL = 4          # components.py:23  (max_pool1d kernel over the NCHW-flattened vector)
 CONV_CH = 32      # components.py:19-21
 
@@ -79,21 +81,22 @@ class EncoderNet(nn.Module):
         self.fc_z_out = nn.Linear(hidden_dim, latent_dim)
         self.c3_only = False
 
-    def conv_stack(self, x):
-        x = F.relu(F.conv2d(x, self.c1.weight, self.c1.bias, padding=1))
-        x = F.relu(F.conv2d(x, self.c2.weight, self.c2.bias, padding=1))
-        return F.relu(F.conv2d(x, self.c3.weight, self.c3.bias, stride=2, padding=1))
+    def conv_stack(self, x, branch=PLAIN):
+        x = branch.relu(F.conv2d(x, self.c1.weight, self.c1.bias, padding=1), "relu1")
+        x = branch.relu(F.conv2d(x, self.c2.weight, self.c2.bias, padding=1), "relu2")
+        return branch.relu(F.conv2d(x, self.c3.weight, self.c3.bias, stride=2, padding=1), "relu3")
 
-    def pool(self, feat):
+    def pool(self, feat, branch=PLAIN):
         # windows of 4 run over the C,H,W-flattened vector and may straddle image rows (W_out % 4 != 0)
         flat = feat.reshape(feat.size(0), 1, -1)
-        return F.max_pool1d(flat, POOL).squeeze(1)
+        return branch.max_pool1d(flat, POOL, "pool").squeeze(1)
 
-    def forward(self, x, masks=(None, None)):
-        feat = self.conv_stack(x)
+    def forward(self, x, masks=(None, None), branch=PLAIN):
+        """``branch`` (oracle.branch.Branch) records or replays the ReLU / max-pool decisions; default: plain F.relu."""
+        feat = self.conv_stack(x, branch)
         if self.c3_only:                      # components.py:44-45
             return feat
-        h = self.fc1(self.pool(feat), masks[0])
+        h = self.fc1(self.pool(feat, branch), masks[0])
         h = self.fc2(h, masks[1])
         return self.fc_z_out(h)
 

@@ -12,6 +12,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .branch import PLAIN
+
 
 class SpatialMapNet(nn.Module):
     """Six per-view strip convs laid out as the car sees the road, then a 3x3 conv.
@@ -33,16 +35,18 @@ class SpatialMapNet(nn.Module):
         self.br_conv = nn.Conv2d(3, 32, (1, 50), stride=(3, 2))
         self.out_conv = nn.Conv2d(32, 32, 3)
 
-    def forward(self, x):
+    def forward(self, x, branch=PLAIN):
+        """``branch`` (oracle.branch.Branch) records or replays the ReLU decisions; default: plain F.relu."""
+        R = branch.relu
         v = [x[:, i] for i in range(6)]
-        bl = F.relu(self.bl_conv(v[3]))                                   # :34-35
-        fl = F.relu(self.fl_conv(v[0]))                                   # :37-38
-        b = F.relu(self.b_conv(torch.rot90(v[4], 1, [2, 3])))             # :43-47
-        f = F.relu(self.f_conv(torch.rot90(v[1], 1, [3, 2])))             # :49-52
-        br = F.relu(self.br_conv(torch.flip(v[5], [2, 3])))               # :57-60
-        fr = F.relu(self.fr_conv(torch.flip(v[2], [2, 3])))               # :62-65
+        bl = R(self.bl_conv(v[3]), "bl")                                   # :34-35
+        fl = R(self.fl_conv(v[0]), "fl")                                   # :37-38
+        b = R(self.b_conv(torch.rot90(v[4], 1, [2, 3])), "b")              # :43-47
+        f = R(self.f_conv(torch.rot90(v[1], 1, [3, 2])), "f")              # :49-52
+        br = R(self.br_conv(torch.flip(v[5], [2, 3])), "br")               # :57-60
+        fr = R(self.fr_conv(torch.flip(v[2], [2, 3])), "fr")               # :62-65
         rows = [torch.cat(p, dim=3) for p in ((bl, fl), (b, f), (br, fr))]
-        return F.relu(self.out_conv(torch.cat(rows, dim=2)))              # :70-76
+        return R(self.out_conv(torch.cat(rows, dim=2)), "out")             # :70-76
 
 
 class BoxMergeNet(nn.Module):
@@ -57,11 +61,12 @@ class BoxMergeNet(nn.Module):
         self.up_conv_3 = nn.ConvTranspose2d(16, 8, 6, dilation=6, output_padding=2)
         self.up_conv_4 = nn.ConvTranspose2d(8, 1, 2, stride=2)
 
-    def forward(self, ssr, spatial_map):
-        s = F.relu(self.ss_deconv(F.relu(self.ss_conv(ssr))))
+    def forward(self, ssr, spatial_map, branch=PLAIN):
+        R = branch.relu
+        s = R(self.ss_deconv(R(self.ss_conv(ssr), "ss_conv")), "ss_deconv")
         h = torch.cat([s, spatial_map], dim=1)
-        for layer in (self.up_conv_1, self.up_conv_2, self.up_conv_3):
-            h = F.relu(layer(h))
+        for i, layer in enumerate((self.up_conv_1, self.up_conv_2, self.up_conv_3)):
+            h = R(layer(h), f"up{i + 1}")
         return torch.sigmoid(self.up_conv_4(h))
 
 
@@ -80,10 +85,11 @@ class RoadBoxMergeNet(nn.Module):
         self.up_conv_4 = nn.ConvTranspose2d(16, 8, 7, dilation=3)
         self.up_conv_5 = nn.ConvTranspose2d(8, 1, 2, stride=2)
 
-    def forward(self, ssr, spatial_map, rm):
-        s = F.relu(self.ss_deconv(F.relu(self.ss_conv(ssr))))
-        r = F.relu(self.rm_conv_2(F.relu(self.rm_conv_1(rm))))
+    def forward(self, ssr, spatial_map, rm, branch=PLAIN):
+        R = branch.relu
+        s = R(self.ss_deconv(R(self.ss_conv(ssr), "ss_conv")), "ss_deconv")
+        r = R(self.rm_conv_2(R(self.rm_conv_1(rm), "rm1")), "rm2")
         h = torch.cat([s, spatial_map, r], dim=1)                          # :159, 96 channels
-        for layer in (self.up_conv_1, self.up_conv_2, self.up_conv_3, self.up_conv_4):
-            h = F.relu(layer(h))
+        for i, layer in enumerate((self.up_conv_1, self.up_conv_2, self.up_conv_3, self.up_conv_4)):
+            h = R(layer(h), f"up{i + 1}")
         return torch.sigmoid(self.up_conv_5(h))

@@ -316,3 +316,32 @@ def test_product_state_dict_loads_into_reference_modules():
         assert not res.missing_keys and not res.unexpected_keys
         for k, v in ref.state_dict().items():
             assert torch.equal(v, mine.state_dict()[k]), k
+
+
+def test_branch_record_and_replay():
+    """oracle.branch: replaying a forward's own decisions reproduces it exactly, and an fp64 evaluation on the branch of
+    the fp32 run differentiates the same linear piece (gradients agree to fp32 rounding, with no decision-flip noise)."""
+    from oracle.branch import Branch
+    enc = _drop0(synth.fill_module(ae_parts.EncoderNet(16, 8, 3, 16, 22), seed=1))
+    x = synth.hash_uniform((6, 3, 16, 22), synth.key_salt("br_x"), 0.0, 1.0)
+    enc.train()
+    rec = Branch()
+    z = enc(x, branch=rec)
+    assert sorted(rec.masks) == ["pool", "relu1", "relu2", "relu3"]
+    assert torch.equal(z, enc(x)) and torch.equal(z, enc(x, branch=Branch(rec.masks)))
+    w = synth.hash_uniform(tuple(z.shape), synth.key_salt("br_w"))
+    (z * w).sum().backward()
+    enc64 = _drop0(synth.fill_module(ae_parts.EncoderNet(16, 8, 3, 16, 22), seed=1)).double()
+    enc64.train()
+    (enc64(x.double(), branch=Branch(rec.masks)) * w.double()).sum().backward()
+    for (k, p), (_, q) in zip(enc.named_parameters(), enc64.named_parameters()):
+        if k.endswith(".fc1.bias"):
+            continue                                        # zero by construction in front of a train-mode BatchNorm
+        _close(p.grad, q.grad, 2e-5)
+    sm = synth.fill_module(spatial_parts.RoadBoxMergeNet(), seed=3)
+    ssr, sp = synth.hash_uniform((1, 32, 8, 150), 1, -1.0, 1.0), synth.hash_uniform((1, 32, 16, 38), 2, -1.0, 1.0)
+    rm = (synth.hash_uniform((1, 1, 80, 146), 3, 0.0, 1.0) < 0.3).float()
+    rec = Branch()
+    y = sm(ssr, sp, rm, branch=rec)
+    assert sorted(rec.masks) == ["rm1", "rm2", "ss_conv", "ss_deconv", "up1", "up2", "up3", "up4"]
+    assert torch.equal(y, sm(ssr, sp, rm, branch=Branch(rec.masks)))
