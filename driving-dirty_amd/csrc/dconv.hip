@@ -19,6 +19,11 @@
 // GEMM per (wave, chunk, tap): M = 64 pixels, N = Cout, K = 8 channels; k index pairing of v_mfma_f32_32x32x2_f32:
 // lane (h = l >> 5, n = l & 31) holds channels 4h..4h+3 of pixel n (A) and of output column n (B); MFMA i multiplies
 // channels (i, 4 + i).
+// Cout <= 16 (up_conv_3 forward, up_conv_4 both ways) would leave half or more of a 32-wide column tile empty: those run on
+// v_mfma_f32_16x16x4_f32 (NT = 0 below: same flop rate, N = 16): four 16-pixel m-tiles per wave, lane (g = l >> 4, m = l & 15)
+// holds channels 2g, 2g+1 of pixel m (A, one ds_read_b64) and of column m (B); MFMA j multiplies channels (j, 2+j, 4+j, 6+j).
+#define DD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #include "dd_common.h"
 
 namespace {
@@ -84,6 +89,8 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
                                                                float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
   using G = DcGeom<K, D>;
   constexpr int T = K * K;
+  constexpr bool N16 = NT == 0;                 // 16-wide column tile on the 16x16x4 MFMA
+  constexpr int NTR = N16 ? 1 : NT;             // column tiles held in registers
   __shared__ __attribute__((aligned(16))) float lds[2][G::PX * 8];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,10 +101,12 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
   const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
   const __amdgpu_buffer_rsrc_t ws = dd_rsrc(wp, wp_bytes);
 
-  float bv[NT];
+  float bv[NTR];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && nt * 32 + n < d.cout) ? bias[nt * 32 + n] : 0.f;
+  for (int nt = 0; nt < NTR; ++nt) {
+    const int ch = N16 ? (lane & 15) : nt * 32 + n;
+    bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && ch < d.cout) ? bias[ch] : 0.f;
+  }
 
   // ---- fill state: the 16-byte pieces this thread fetches for a tile (piece p = pixel p >> 1, channel half p & 1)
   int voff[G::NP];
@@ -149,15 +158,19 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
       kx1 = min(K - 1, (d.in_w - 1 - xlo) >= 0 ? (d.in_w - 1 - xlo) / D : -1);
     }
     const int nky = max(ky1 - ky0 + 1, 0), nkx = max(kx1 - kx0 + 1, 0), ntaps = nky * nkx;
-    const int abase = ((row * tw + 64 * xh + n) * 8 + 4 * h) * 4;      // byte offset of this lane's pixel in an LDS buffer
+    // byte offset of this lane's pixel / channel group in an LDS buffer
+    const int abase = N16 ? ((row * tw + 64 * xh + (lane & 15)) * 8 + 2 * (lane >> 4)) * 4 : ((row * tw + 64 * xh + n) * 8 + 4 * h) * 4;
 
-    f32x16 acc[2][NT];
+    f32x16 acc[2][NTR];
+    f32x4 acc16[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NTR; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) acc16[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     DcTile next = tile;
     for (int q = 0; q < NC; ++q) {
@@ -183,31 +196,53 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
       if (ntaps > 0) {
         const char* lbase = (const char*)&lds[par][0] + abase;
         int ky = ky0, kx = kx0;
-        f32x4 A0[2], A1[2], B[2][NT];
+        f32x4 A0[2], A1[2], B[2][NTR];
+        f32x2 P[2][4], Q[2];                  // N16: four 16-pixel A fragments and the weight fragment of a tap
         auto load_tap = [&](int slot, int cky, int ckx) {
           const char* p = lbase + (cky * tw + ckx * D) * 32;
-          A0[slot] = *(const f32x4*)p;
-          A1[slot] = *(const f32x4*)(p + 1024);
-          const int soff = ((q * T + cky * K + ckx) * NT) * 1024;
+          if constexpr (N16) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            B[slot][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff + nt * 1024, 0));
+            for (int t4 = 0; t4 < 4; ++t4) P[slot][t4] = *(const f32x2*)(p + 512 * t4);
+            Q[slot] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ws, lane * 8, (q * T + cky * K + ckx) * 512, 0));
+          } else {
+            A0[slot] = *(const f32x4*)p;
+            A1[slot] = *(const f32x4*)(p + 1024);
+            const int soff = ((q * T + cky * K + ckx) * NTR) * 1024;
+#pragma unroll
+            for (int nt = 0; nt < NTR; ++nt)
+              B[slot][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff + nt * 1024, 0));
+          }
         };
         auto mul_tap = [&](int slot) {
+          if constexpr (N16) {
+            acc16[0] = DD_MFMA16(P[slot][0].x, Q[slot].x, acc16[0]);
+            acc16[1] = DD_MFMA16(P[slot][1].x, Q[slot].x, acc16[1]);
+            if (mt1) {
+              acc16[2] = DD_MFMA16(P[slot][2].x, Q[slot].x, acc16[2]);
+              acc16[3] = DD_MFMA16(P[slot][3].x, Q[slot].x, acc16[3]);
+            }
+            acc16[0] = DD_MFMA16(P[slot][0].y, Q[slot].y, acc16[0]);
+            acc16[1] = DD_MFMA16(P[slot][1].y, Q[slot].y, acc16[1]);
+            if (mt1) {
+              acc16[2] = DD_MFMA16(P[slot][2].y, Q[slot].y, acc16[2]);
+              acc16[3] = DD_MFMA16(P[slot][3].y, Q[slot].y, acc16[3]);
+            }
+          } else {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[0][nt] = DD_MFMA(A0[slot].x, B[slot][nt].x, acc[0][nt]);
-            acc[0][nt] = DD_MFMA(A0[slot].y, B[slot][nt].y, acc[0][nt]);
-            acc[0][nt] = DD_MFMA(A0[slot].z, B[slot][nt].z, acc[0][nt]);
-            acc[0][nt] = DD_MFMA(A0[slot].w, B[slot][nt].w, acc[0][nt]);
-          }
-          if (mt1) {
+            for (int nt = 0; nt < NTR; ++nt) {
+              acc[0][nt] = DD_MFMA(A0[slot].x, B[slot][nt].x, acc[0][nt]);
+              acc[0][nt] = DD_MFMA(A0[slot].y, B[slot][nt].y, acc[0][nt]);
+              acc[0][nt] = DD_MFMA(A0[slot].z, B[slot][nt].z, acc[0][nt]);
+              acc[0][nt] = DD_MFMA(A0[slot].w, B[slot][nt].w, acc[0][nt]);
+            }
+            if (mt1) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[1][nt] = DD_MFMA(A1[slot].x, B[slot][nt].x, acc[1][nt]);
-              acc[1][nt] = DD_MFMA(A1[slot].y, B[slot][nt].y, acc[1][nt]);
-              acc[1][nt] = DD_MFMA(A1[slot].z, B[slot][nt].z, acc[1][nt]);
-              acc[1][nt] = DD_MFMA(A1[slot].w, B[slot][nt].w, acc[1][nt]);
+              for (int nt = 0; nt < NTR; ++nt) {
+                acc[1][nt] = DD_MFMA(A1[slot].x, B[slot][nt].x, acc[1][nt]);
+                acc[1][nt] = DD_MFMA(A1[slot].y, B[slot][nt].y, acc[1][nt]);
+                acc[1][nt] = DD_MFMA(A1[slot].z, B[slot][nt].z, acc[1][nt]);
+                acc[1][nt] = DD_MFMA(A1[slot].w, B[slot][nt].w, acc[1][nt]);
+              }
             }
           }
         };
@@ -237,22 +272,41 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
     if (row_ok) {
       const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)tile.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
       const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)tile.b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+      if constexpr (N16) {
+        const int ch = lane & 15;
+        const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (j == 1 && !mt1) break;
+        for (int t4 = 0; t4 < 4; ++t4) {
+          if (t4 >= 2 && !mt1) break;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int ch = nt * 32 + n;
-          const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int xo = xw + 32 * j + dd_acc_row(r, lane);
+          for (int r = 0; r < 4; ++r) {
+            const int xo = xw + 16 * t4 + 4 * (lane >> 4) + r;      // D row of the 16x16 tile: 4*(lane >> 4) + r
             const bool ok = xo < d.out_w && ch < d.cout;
             const int off = ok ? (((oy + d.ooff_h) * d.omem_w + xo + d.ooff_w) * d.out_cstore + d.out_coff + ch) * 4 : -16;
-            float v = acc[j][nt][r] + bv[nt];
+            float v = acc16[t4][r] + bv[0];
             if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
             if (epi == DD_EPI_RELU_MASK) v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
             dd_bstore1(ys, off, v);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j == 1 && !mt1) break;
+#pragma unroll
+          for (int nt = 0; nt < NTR; ++nt) {
+            const int ch = nt * 32 + n;
+            const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int xo = xw + 32 * j + dd_acc_row(r, lane);
+              const bool ok = xo < d.out_w && ch < d.cout;
+              const int off = ok ? (((oy + d.ooff_h) * d.omem_w + xo + d.ooff_w) * d.out_cstore + d.out_coff + ch) * 4 : -16;
+              float v = acc[j][nt][r] + bv[nt];
+              if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+              if (epi == DD_EPI_RELU_MASK) v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
+              dd_bstore1(ys, off, v);
+            }
           }
         }
       }
@@ -261,10 +315,20 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
   }
 }
 
-// packed[(((q*T + tap)*NT + nt)*64 + lane)*4 + i] = W(n = nt*32 + (lane & 31), c = 8q + 4*(lane >> 5) + i, tap)
+// packed[(((q*T + tap)*NT + nt)*64 + lane)*4 + i] = W(n = nt*32 + (lane & 31), c = 8q + 4*(lane >> 5) + i, tap);
+// Cout <= 16 (nt_count == 0): packed[((q*T + tap)*64 + lane)*2 + j] = W(n = lane & 15, c = 8q + 2*(lane >> 4) + j, tap)
 __global__ void dconv_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int nchunks, int nt_count, int T, long w_off,
                                   long sn, long sc, int flip, int n_real, int c_real) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (nt_count == 0) {
+    if (idx >= (long)nchunks * T * 128) return;
+    const int j = idx & 1, lane = (idx >> 1) & 63;
+    const long g = idx >> 7;
+    const int tap = (int)(g % T), q = (int)(g / T);
+    const int c = 8 * q + 2 * (lane >> 4) + j, n = lane & 15;
+    p[idx] = (n < n_real && c < c_real) ? w[w_off + n * sn + c * sc + (flip ? T - 1 - tap : tap)] : 0.f;
+    return;
+  }
   const long total = (long)nchunks * T * nt_count * 256;
   if (idx >= total) return;
   const int i = idx & 3, lane = (idx >> 2) & 63;
@@ -308,6 +372,7 @@ int64_t dd_dconv_packed_floats(const dd_gconv_desc* d) {
     dd_fail(DD_ERR_UNSUPPORTED, "dconv: not a stride-1 k7d7 / k7d3 / k8d8 / k6d6 layer with Cin %% 8 == 0 and Cout <= 96");
     return -1;
   }
+  if (d->cout <= 16) return (int64_t)(d->cin / 8) * d->kh * d->kw * 128;
   return (int64_t)(d->cin / 8) * d->kh * d->kw * ((d->cout + 31) / 32) * 256;
 }
 
@@ -316,8 +381,8 @@ int dd_dconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t
   DD_REQUIRE(dc_supported(d), DD_ERR_UNSUPPORTED, "dconv_pack: unsupported layer");
   DD_REQUIRE(w && packed, DD_ERR_BAD_ARG, "dconv_pack: NULL pointer");
   DD_REQUIRE(n_real > 0 && n_real <= d->cout && c_real > 0 && c_real <= d->cin, DD_ERR_BAD_ARG, "dconv_pack: n_real/c_real");
-  const int nt = (d->cout + 31) / 32, T = d->kh * d->kw;
-  const long total = (long)(d->cin / 8) * T * nt * 256;
+  const int nt = d->cout <= 16 ? 0 : (d->cout + 31) / 32, T = d->kh * d->kw;
+  const long total = dd_dconv_packed_floats(d);
   hipLaunchKernelGGL(dconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, d->cin / 8, nt,
                      T, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real);
   DD_LAUNCH_CHECK("dconv_pack");
@@ -333,12 +398,12 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
   DD_REQUIRE(epilogue != DD_EPI_RELU_MASK || mask, DD_ERR_BAD_ARG, "dconv_fwd: RELU_MASK needs a mask");
   DD_REQUIRE(!(epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) || bias, DD_ERR_BAD_ARG, "dconv_fwd: bias epilogue needs a bias");
   hipStream_t st = (hipStream_t)stream;
-  const int nt = (d->cout + 31) / 32;
+  const int nt = d->cout <= 16 ? 0 : (d->cout + 31) / 32;
   const int wp_bytes = (int)(dd_dconv_packed_floats(d) * 4);
   const DcPlan plan = dc_plan(*d, d->dil_h);
   const int grid = (int)max(1, min(dd_cu_budget_internal(), plan.total));      // one 8-wave workgroup per CU, all resident
 #define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes)
-#define DD_DC_NT(KK, DD_) do { if (nt == 1) DD_DC(KK, DD_, 1); else if (nt == 2) DD_DC(KK, DD_, 2); else DD_DC(KK, DD_, 3); } while (0)
+#define DD_DC_NT(KK, DD_) do { if (nt == 0) DD_DC(KK, DD_, 0); else if (nt == 1) DD_DC(KK, DD_, 1); else if (nt == 2) DD_DC(KK, DD_, 2); else DD_DC(KK, DD_, 3); } while (0)
   switch (dc_variant(d)) {
     case 0: DD_DC_NT(7, 7); break;
     case 1: DD_DC_NT(7, 3); break;

@@ -166,6 +166,7 @@ def test_hipadam_overlapped_under_data_parallel_matches_single_process(tmp_path)
     dev = torch.device("cuda:0")
     model = _tiny_model(dev)
     opt = HipAdam(model.parameters(), lr=1e-2)
+    opt.SMALL_NUMEL = 999            # the same tensors through the same kernels as on the ranks (>= 1000 elements: one launch each)
     params = dict(model.named_parameters())
     local = [torch.load(f"{out}.local{r}") for r in range(2)]
     for step in range(3):
