@@ -24,6 +24,8 @@
 // holds channels 2g, 2g+1 of pixel m (A, one ds_read_b64) and of column m (B); MFMA j multiplies channels (j, 2+j, 4+j, 6+j).
 #define DD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include <stdlib.h>
+
 #include "dd_common.h"
 
 namespace {
@@ -86,7 +88,7 @@ __device__ __forceinline__ DcTile dc_tile(const DcPlan& p, int D, int t) {
 template <int K, int D, int NT>
 __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, const float* __restrict__ msk,
-                                                               float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
+                                                               float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes, int dbg_repeat) {
   using G = DcGeom<K, D>;
   constexpr int T = K * K;
   constexpr bool N16 = NT == 0;                 // 16-wide column tile on the 16x16x4 MFMA
@@ -246,16 +248,32 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
             }
           }
         };
-        auto advance = [&]() { if (++kx > kx1) { kx = kx0; ++ky; } };
+        // The operand loads of tap i+1 are issued before tap i is multiplied, UNCONDITIONALLY: a load inside an `if` makes the
+        // compiler's s_waitcnt at the join assume it was not issued, i.e. wait for everything (measured in the ISA: vmcnt(0)
+        // in front of the third MFMA of every tap, the prefetch's whole L2 latency exposed).  Past the last tap the iterator
+        // stays on the last tap: one redundant, harmless reload.
+        int left = ntaps - 1;                                      // taps after the one (ky, kx) points at
+        auto advance = [&]() {
+          const bool more = left > 0;
+          left -= more ? 1 : 0;
+          const bool wrap = kx >= kx1;
+          kx = more ? (wrap ? kx0 : kx + 1) : kx;
+          ky = (more && wrap) ? ky + 1 : ky;
+        };
+        for (int rep = 0; rep < dbg_repeat; ++rep) {      // dbg_repeat = 1 (DD_DCONV_REPEAT: timing diagnostic only, results are then wrong)
+        ky = ky0; kx = kx0; left = ntaps - 1;
         load_tap(0, ky, kx);
         advance();
         for (int i = 0; i < ntaps; i += 2) {
-          if (i + 1 < ntaps) { load_tap(1, ky, kx); advance(); }
-          __builtin_amdgcn_sched_barrier(0);          // tap i+1 is requested before tap i is multiplied
+          load_tap(1, ky, kx);
+          advance();
+          __builtin_amdgcn_sched_barrier(0);
           mul_tap(0);
-          if (i + 2 < ntaps) { load_tap(0, ky, kx); advance(); }
+          load_tap(0, ky, kx);
+          advance();
           __builtin_amdgcn_sched_barrier(0);
           if (i + 1 < ntaps) mul_tap(1);
+        }
         }
       }
       // ---- retire the staged pieces into the other buffer (read last one step ago, a barrier since)
@@ -272,22 +290,35 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
     if (row_ok) {
       const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)tile.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
       const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)tile.b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+      // All mask values of a 32x32 (16x16) tile are requested before any of them is used: one conditional load per element
+      // (`epi` is a run-time value) made the compiler wait for each load in turn -- 64..96 serial L2 round trips per tile,
+      // 1.0 .. 1.2 ms of a 5.7 .. 11 ms data-gradient launch (measured by repeating the tap loop, DD_DCONV_REPEAT).
+      const bool masked = epi == DD_EPI_RELU_MASK;
+      const int base = ((oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
       if constexpr (N16) {
         const int ch = lane & 15;
         const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+        int off[16];
+        float mv[16];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          if (t4 >= 2 && !mt1) break;
+        for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int xo = xw + 16 * t4 + 4 * (lane >> 4) + r;      // D row of the 16x16 tile: 4*(lane >> 4) + r
-            const bool ok = xo < d.out_w && ch < d.cout;
-            const int off = ok ? (((oy + d.ooff_h) * d.omem_w + xo + d.ooff_w) * d.out_cstore + d.out_coff + ch) * 4 : -16;
-            float v = acc16[t4][r] + bv[0];
-            if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-            if (epi == DD_EPI_RELU_MASK) v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
-            dd_bstore1(ys, off, v);
+            const bool ok = xo < d.out_w && ch < d.cout && (t4 < 2 || mt1);
+            off[4 * t4 + r] = ok ? (base + xo * d.out_cstore + ch) * 4 : -16;
+            mv[4 * t4 + r] = 1.f;
           }
+        if (masked && !pass) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mv[e] = dd_bload1(ms, off[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc16[e >> 2][e & 3] + bv[0];
+          if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          v = mv[e] > 0.f ? v : 0.f;
+          dd_bstore1(ys, off[e], v);
         }
       } else {
 #pragma unroll
@@ -297,15 +328,29 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
           for (int nt = 0; nt < NTR; ++nt) {
             const int ch = nt * 32 + n;
             const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+            int off[16];
+            float mv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int xo = xw + 32 * j + dd_acc_row(r, lane);
               const bool ok = xo < d.out_w && ch < d.cout;
-              const int off = ok ? (((oy + d.ooff_h) * d.omem_w + xo + d.ooff_w) * d.out_cstore + d.out_coff + ch) * 4 : -16;
+              off[r] = ok ? (base + xo * d.out_cstore + ch) * 4 : -16;
+              mv[r] = 1.f;
+            }
+            if (masked) {      // lanes of an exempt channel ask a zero-size resource (no memory request) and keep 1
+              const __amdgpu_buffer_rsrc_t mr = ms;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float m = dd_bload1(mr, pass ? -16 : off[r]);
+                mv[r] = pass ? 1.f : m;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
               float v = acc[j][nt][r] + bv[nt];
               if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-              if (epi == DD_EPI_RELU_MASK) v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
-              dd_bstore1(ys, off, v);
+              v = mv[r] > 0.f ? v : 0.f;
+              dd_bstore1(ys, off[r], v);
             }
           }
         }
@@ -400,9 +445,10 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
   hipStream_t st = (hipStream_t)stream;
   const int nt = d->cout <= 16 ? 0 : (d->cout + 31) / 32;
   const int wp_bytes = (int)(dd_dconv_packed_floats(d) * 4);
+  static const int dbg_repeat = getenv("DD_DCONV_REPEAT") ? atoi(getenv("DD_DCONV_REPEAT")) : 1;
   const DcPlan plan = dc_plan(*d, d->dil_h);
   const int grid = (int)max(1, min(dd_cu_budget_internal(), plan.total));      // one 8-wave workgroup per CU, all resident
-#define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes)
+#define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes, dbg_repeat)
 #define DD_DC_NT(KK, DD_) do { if (nt == 0) DD_DC(KK, DD_, 0); else if (nt == 1) DD_DC(KK, DD_, 1); else if (nt == 2) DD_DC(KK, DD_, 2); else DD_DC(KK, DD_, 3); } while (0)
   switch (dc_variant(d)) {
     case 0: DD_DC_NT(7, 7); break;
