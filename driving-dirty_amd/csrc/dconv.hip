@@ -463,3 +463,251 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Weight gradient of the same layers (ConvTranspose2d, stride 1, dilation D, no padding):
+//     dW[c][o][ky][kx] = sum over images and input pixels (iy, ix) of  x[iy][ix][c] * g[iy + D*ky][ix + D*kx][o]
+// GEMM per tap: M = Cin, N = Cout, K = pixels (two per v_mfma_f32_32x32x2_f32: lane (h, m) supplies x[pixel h][c = m], lane
+// (h, n) g[pixel h + tap shift][o = n]).  The generic engine (gconv_wgrad_kernel) loads both operands of every MFMA from
+// L1/L2 (0.6 .. 1.3 loads per MFMA).  Here a workgroup owns ONE tap row ky and a range of input rows; per step an XT-pixel
+// piece of an x row and the matching (XT + D(K-1))-pixel piece of the g row iy + D*ky sit in LDS (double buffered,
+// contiguous 16-byte global loads), every tap column kx is an address offset, and the 8 waves split the tap row's
+// (kx, Cin tile, Cout tile) accumulator tiles into NSETS sets and the piece's pixel pairs into 8 / NSETS parts: at most
+// 8 tiles = 128 accumulator registers per wave, two ds_read_b32 per MFMA, no global operand loads in the loop.
+// Partials per workgroup, then a fixed-order fp64 second stage (deterministic).
+
+template <int K, int D, int C, int O, int XT_, int NSETS_>
+struct DwGeom {
+  static constexpr int HALO = D * (K - 1);
+  static constexpr int XT = XT_, NSETS = NSETS_, PARTS = 8 / NSETS_;
+  static constexpr int MT = (C + 31) / 32, NTO = (O + 31) / 32;
+  static constexpr int PER_KY = K * MT * NTO;                       // accumulator tiles per tap row
+  static constexpr int TPW = (PER_KY + NSETS - 1) / NSETS;          // tiles per wave
+  static constexpr int UNITS = XT / 2 / PARTS / 8;                  // 8-pixel-pair units per wave and step
+  static constexpr int XB = XT * C;                                 // floats of the x piece
+  static constexpr int GB = (XT + HALO) * O;                        // floats of the g piece
+  static constexpr int BUF = XB + GB + 64;                          // + slack: lanes past Cout / Cin read (and ignore) the next pixel
+  static constexpr int NPIECE = (BUF / 4 + DC_THREADS - 1) / DC_THREADS;
+  static_assert(XT % (16 * PARTS) == 0 && UNITS >= 1 && TPW <= 8, "piece / tile split");
+};
+
+template <int K, int D, int C, int O, int XT_, int NSETS_>
+__global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 float* __restrict__ part, int wg_per_ky, int B, int H, int W,
+                                                                 int x_cstore, int x_coff, int gh, int gw, int g_cstore, int g_coff) {
+  using G = DwGeom<K, D, C, O, XT_, NSETS_>;
+  __shared__ __attribute__((aligned(16))) float lds[2][G::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, n = lane & 31;
+  const int ky = blockIdx.x / wg_per_ky, wl = blockIdx.x - ky * wg_per_ky;
+  const int set = wave % G::NSETS, prt = wave / G::NSETS;
+  // rows of this workgroup: an even share of the B*H input rows
+  const long rows = (long)B * H;
+  const long r0 = rows * wl / wg_per_ky, r1 = rows * (wl + 1) / wg_per_ky;
+  const int nxt = (W + G::XT - 1) / G::XT;
+  const long nsteps = (r1 - r0) * nxt;
+
+  // LDS byte offsets of this wave's tiles: A = x piece (+ Cin tile), B = g piece (+ tap column, Cout tile)
+  const int px0 = prt * (G::XT / G::PARTS);                          // first pixel of this wave's part of the piece
+  int aoff[G::TPW], boff[G::TPW];
+#pragma unroll
+  for (int i = 0; i < G::TPW; ++i) {
+    const int t = set * G::TPW + i;
+    if (t < G::PER_KY) {
+      const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
+      aoff[i] = ((px0 + h) * C + mt * 32 + n) * 4;
+      boff[i] = (G::XB + (px0 + h + kx * D) * O + nt * 32 + n) * 4;
+    } else {      // no such tile: multiply something harmless (no branch in the loop), the reduce never reads this accumulator
+      aoff[i] = n * 4;
+      boff[i] = n * 4;
+    }
+  }
+  f32x16 acc[G::TPW];
+#pragma unroll
+  for (int i = 0; i < G::TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // fill: piece p (16 bytes) of a step = x piece [0, XB/4), then the g piece.  The per-thread byte offsets inside the two row
+  // pieces never change: they are computed once; a step only rebuilds two wave-uniform descriptors (row piece start, bytes left
+  // in the row: the hardware range check zero-fills what lies past the row end) -- no vector instruction per load.
+  int voff[G::NPIECE];
+#pragma unroll
+  for (int i = 0; i < G::NPIECE; ++i) {
+    const int p = tid + DC_THREADS * i;
+    if (p < G::XB / 4) {
+      const int px = (4 * p) / C, c = 4 * p - px * C;
+      voff[i] = (px * x_cstore + x_coff + c) * 4;
+    } else {
+      const int q = 4 * p - G::XB, pg = q / O, cg = q - pg * O;
+      voff[i] = q < G::GB ? (pg * g_cstore + g_coff + cg) * 4 : -16;
+    }
+  }
+  auto issue = [&](long s, f32x4* st) {
+    const long row = r0 + s / nxt;
+    const int xt = (int)(s % nxt), b = (int)(row / H), iy = (int)(row - (long)b * H);
+    const int x0 = xt * G::XT, gy = iy + D * ky;
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (((long)b * H + iy) * W + x0) * x_cstore, (W - x0) * x_cstore * 4);
+    const __amdgpu_buffer_rsrc_t gs = dd_rsrc(g + (((long)b * gh + gy) * gw + x0) * g_cstore, (gy < gh && x0 < gw) ? (gw - x0) * g_cstore * 4 : 0);
+#pragma unroll
+    for (int i = 0; i < G::NPIECE; ++i) {
+      if (DC_THREADS * (i + 1) <= G::XB / 4) st[i] = dd_bload4(xs, voff[i]);                 // the whole round lies in the x piece
+      else if (DC_THREADS * i >= G::XB / 4) st[i] = dd_bload4(gs, voff[i]);                  // ... in the g piece
+      else {                                                                                 // the round straddles both
+        const bool isx = tid + DC_THREADS * i < G::XB / 4;
+        const f32x4 vx = dd_bload4(xs, isx ? voff[i] : -16), vg = dd_bload4(gs, isx ? -16 : voff[i]);
+        st[i] = isx ? vx : vg;
+      }
+    }
+  };
+  auto retire = [&](int buf, const f32x4* st) {
+#pragma unroll
+    for (int i = 0; i < G::NPIECE; ++i) {
+      const int p = tid + DC_THREADS * i;
+      if (p < G::BUF / 4) *(f32x4*)&lds[buf][4 * p] = st[i];
+    }
+  };
+
+  if (nsteps > 0) {
+    f32x4 st[G::NPIECE];
+    issue(0, st);
+    retire(0, st);
+  }
+  __syncthreads();
+  int par = 0;
+  for (long s = 0; s < nsteps; ++s) {
+    f32x4 st[G::NPIECE];
+    const bool more = s + 1 < nsteps;
+    if (more) issue(s + 1, st);
+    {
+      // operands of pixel pair pp + 1 are read while pair pp is multiplied (left to itself the compiler emits read, read, wait,
+      // MFMA: every MFMA exposed to the LDS latency)
+      const char* lb = (const char*)&lds[par][0];
+      constexpr int NP = G::UNITS * 8;
+      float av[2][G::TPW], bw[2][G::TPW];
+#pragma unroll
+      for (int i = 0; i < G::TPW; ++i) {
+        av[0][i] = *(const float*)(lb + aoff[i]);
+        bw[0][i] = *(const float*)(lb + boff[i]);
+      }
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        if (pp + 1 < NP) {
+#pragma unroll
+          for (int i = 0; i < G::TPW; ++i) {
+            av[(pp + 1) & 1][i] = *(const float*)(lb + aoff[i] + (pp + 1) * 2 * C * 4);
+            bw[(pp + 1) & 1][i] = *(const float*)(lb + boff[i] + (pp + 1) * 2 * O * 4);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G::TPW; ++i) acc[i] = DD_MFMA(av[pp & 1][i], bw[pp & 1][i], acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) retire(par ^ 1, st);
+    __syncthreads();
+    par ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < G::TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[((((long)blockIdx.x * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane] = acc[i][r];
+}
+
+// One block = one accumulator tile of one tap row (1024 threads = 16 registers x 64 lanes): sums the tap row's workgroups and
+// the pixel parts in fp64, in a fixed order, and scatters to the ConvTranspose2d weight layout [Cin][Cout][K][K].
+template <int K, int D, int C, int O, int XT_, int NSETS_>
+__global__ __launch_bounds__(1024) void dconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int wg_per_ky,
+                                                           int accumulate) {
+  using G = DwGeom<K, D, C, O, XT_, NSETS_>;
+  const int ky = blockIdx.x / G::PER_KY, t = blockIdx.x - ky * G::PER_KY;
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int set = t / G::TPW, i = t - set * G::TPW;
+  double s = 0.0;
+  for (int w = 0; w < wg_per_ky; ++w)
+    for (int prt = 0; prt < G::PARTS; ++prt) {
+      const int wave = set + G::NSETS * prt;
+      s += (double)part[((((long)(ky * wg_per_ky + w) * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane];
+    }
+  const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
+  const int c = mt * 32 + dd_acc_row(r, lane), o = nt * 32 + (lane & 31);
+  if (c < C && o < O) {
+    const long wi = (((long)c * O + o) * K + ky) * K + kx;
+    dw[wi] = accumulate ? dw[wi] + (float)s : (float)s;
+  }
+}
+
+struct DwLayer { int k, d, c, o; };
+const DwLayer kDwLayers[] = {{7, 7, 96, 64}, {7, 7, 64, 32}, {7, 7, 32, 16}, {7, 3, 16, 8}, {8, 8, 64, 32}, {8, 8, 32, 16}, {6, 6, 16, 8}};
+
+int dw_variant(int k, int d, int c, int o) {
+  for (int i = 0; i < (int)(sizeof(kDwLayers) / sizeof(kDwLayers[0])); ++i)
+    if (kDwLayers[i].k == k && kDwLayers[i].d == d && kDwLayers[i].c == c && kDwLayers[i].o == o) return i;
+  return -1;
+}
+
+// (K, D, Cin, Cout, piece width, tile sets): 42 / 14 / 7 tiles per tap row -> 8 / 2 / 1 sets of <= 8 tiles
+#define DD_DW_DISPATCH(V, F)                      \
+  switch (V) {                                    \
+    case 0: F(7, 7, 96, 64, 64, 8); break;        \
+    case 1: F(7, 7, 64, 32, 128, 2); break;       \
+    case 2: F(7, 7, 32, 16, 256, 1); break;       \
+    case 3: F(7, 3, 16, 8, 256, 1); break;        \
+    case 4: F(8, 8, 64, 32, 128, 2); break;       \
+    case 5: F(8, 8, 32, 16, 256, 1); break;       \
+    default: F(6, 6, 16, 8, 256, 1); break;       \
+  }
+
+extern "C" {
+
+/* x [B,H,W,x_cstore] (channels [x_coff, +cin)), g = dL/dy [B,gh,gw,g_cstore] (channels [g_coff, +cout)), gh >= H + D(K-1). */
+int32_t dd_dconv_wgrad_supported(int32_t k, int32_t dil, int32_t cin, int32_t cout) {
+  // Measured at bs 32 against the generic weight-gradient kernel: 96->64 11.39 -> 10.36 ms, 64->32 6.25 -> 5.66 ms; the 32->16 and
+  // 16->8 layers fill half / a quarter of the 32-wide MFMA columns here and run faster on the generic kernel (2.73 vs 4.2 ms,
+  // 1.88 vs 4.5 ms): callers are told to keep those there.  DD_DCONV_WGRAD_ALL=1 enables all seven (tests).
+  static const bool all = getenv("DD_DCONV_WGRAD_ALL") != nullptr;
+  const int v = dw_variant(k, dil, cin, cout);
+  return (v == 0 || v == 1 || v == 4 || (all && v >= 0)) ? 1 : 0;
+}
+
+int64_t dd_dconv_wgrad_workspace_bytes(int32_t k, int32_t dil, int32_t cin, int32_t cout) {
+  const int v = dw_variant(k, dil, cin, cout);
+  if (v < 0) return -1;
+  int tpw = 0;
+#define DD_F(KK, DD_, CC, OO, XX, SS) tpw = DwGeom<KK, DD_, CC, OO, XX, SS>::TPW
+  DD_DW_DISPATCH(v, DD_F)
+#undef DD_F
+  return (int64_t)DD_NUM_CU * 8 * tpw * 1024 * 4;
+}
+
+int dd_dconv_wgrad(const float* x, const float* g, float* dw, int32_t batch, int32_t h, int32_t w, int32_t x_cstore, int32_t x_coff,
+                   int32_t cin, int32_t gh, int32_t gw, int32_t g_cstore, int32_t g_coff, int32_t cout, int32_t k, int32_t dil,
+                   int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  const int v = dw_variant(k, dil, cin, cout);
+  DD_REQUIRE(v >= 0, DD_ERR_UNSUPPORTED, "dconv_wgrad: k%d d%d %d->%d is not one of the box heads' up-convs", k, dil, cin, cout);
+  DD_REQUIRE(x && g && dw && workspace, DD_ERR_BAD_ARG, "dconv_wgrad: NULL pointer");
+  DD_REQUIRE(batch > 0 && h > 0 && w > 0 && gh >= h + dil * (k - 1) && gw >= w + dil * (k - 1), DD_ERR_BAD_ARG,
+             "dconv_wgrad: the gradient image %dx%d is smaller than %dx%d + %d", gh, gw, h, w, dil * (k - 1));
+  DD_REQUIRE(x_cstore % 4 == 0 && x_coff % 4 == 0 && x_coff + cin <= x_cstore && g_cstore % 4 == 0 && g_coff % 4 == 0 && g_coff + cout <= g_cstore,
+             DD_ERR_UNSUPPORTED, "dconv_wgrad: channel slices must be 4-aligned");
+  DD_REQUIRE(((uintptr_t)x | (uintptr_t)g) % 16 == 0, DD_ERR_BAD_ARG, "dconv_wgrad: buffers must be 16-byte aligned");
+  DD_REQUIRE((long)h * w * x_cstore * 4 < (1L << 31) && (long)gh * gw * g_cstore * 4 < (1L << 31), DD_ERR_UNSUPPORTED, "dconv_wgrad: one image exceeds 2 GB");
+  DD_REQUIRE(workspace_bytes >= dd_dconv_wgrad_workspace_bytes(k, dil, cin, cout), DD_ERR_WORKSPACE, "dconv_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int wg_per_ky = max(1, dd_cu_budget_internal() / k);          // every tap row gets the same share of the workgroups
+#define DD_F(KK, DD_, CC, OO, XX, SS)                                                                                                        \
+  {                                                                                                                                          \
+    hipLaunchKernelGGL((dconv_wgrad_kernel<KK, DD_, CC, OO, XX, SS>), dim3(wg_per_ky * KK), dim3(DC_THREADS), 0, st, x, g, (float*)workspace, \
+                       wg_per_ky, batch, h, w, x_cstore, x_coff, gh, gw, g_cstore, g_coff);                                                  \
+    hipLaunchKernelGGL((dconv_wgrad_reduce<KK, DD_, CC, OO, XX, SS>), dim3(KK * DwGeom<KK, DD_, CC, OO, XX, SS>::PER_KY), dim3(1024), 0, st, \
+                       (const float*)workspace, dw, wg_per_ky, accumulate);                                                                  \
+  }
+  DD_DW_DISPATCH(v, DD_F)
+#undef DD_F
+  DD_LAUNCH_CHECK("dconv_wgrad");
+  return 0;
+}
+
+}  // extern "C"

@@ -205,6 +205,19 @@ class Layer:
             for ph in range(4):
                 d = _desc(b, src, ddst, cs, self.cout, (1, 1), out_hw=(ih, iw), ostride=(2, 2), ooff=(ph // 2, ph % 2))
                 _wgrad(src.buf, ddst.buf, dw, db, d, ph, 4, self.cout * 4, False, self.cout, self.cin, 2 if ph > 0 else 0)
+        elif (DCONV and self.k[0] == self.k[1] and self.dil[0] == self.dil[1] and self.pad == (0, 0) and src.chans == self.cin
+              and ddst.chans == self.cout and ddst.off_h == 0 and ddst.off_w == 0
+              and _lib.lib().dd_dconv_wgrad_supported(self.k[0], self.dil[0], self.cin, self.cout)):
+            # the box heads' dilated up-convs: LDS-staged weight-gradient kernel (csrc/dconv.hip)
+            lib = _lib.lib()
+            nbytes = lib.dd_dconv_wgrad_workspace_bytes(self.k[0], self.dil[0], self.cin, self.cout)
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            _, ih, iw, ics = src.buf.shape
+            _, gh, gw, gcs = ddst.buf.shape
+            check(lib.dd_dconv_wgrad(_p(src.buf), _p(ddst.buf), _p(dw), b, ih, iw, ics, src.coff, self.cin, gh, gw, gcs, ddst.coff, self.cout,
+                                     self.k[0], self.dil[0], 0, _p(ws), nbytes, _stream()), "dd_dconv_wgrad")
+            if want_bias:
+                channel_sum(ddst, db)
         elif self.cin <= 96 and self.cout % 4 == 0 and ddst.off_h == 0 and ddst.off_w == 0:
             # stride-1 transposed conv, role-swapped: dWt[c][o][t] = sum over INPUT pixels p of x[p][c] * dy[p + t*d - pad][o]
             # is the weight gradient of the plain conv  dx = conv(dy, Wt)  with x in the role of its output gradient.

@@ -321,6 +321,18 @@ int dd_dconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t
 int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y,
                  const dd_gconv_desc* d, int32_t epilogue, void* stream);
 
+/* Weight gradient of the same layers (ConvTranspose2d stride 1, dilation `dil`, kernel k x k, no padding):
+ *   dw[c][o][ky][kx] (IOHW, PyTorch's layout) (+)= sum over images and pixels of x[iy][ix][c] * g[iy + dil*ky][ix + dil*kx][o]
+ * x [batch,h,w,x_cstore] (channels [x_coff,+cin)), g = dL/dy [batch,gh,gw,g_cstore] (channels [g_coff,+cout)) with
+ * gh >= h + dil*(k-1) (output_padding rows are simply never read).  LDS-staged operands, per-workgroup partials in
+ * `workspace`, fp64 fixed-order second stage.  Built for the seven (k, dil, cin, cout) combinations of the box heads:
+ * dd_dconv_wgrad_supported() says which; the bias gradient is dd_channel_sum of g. */
+int32_t dd_dconv_wgrad_supported(int32_t k, int32_t dil, int32_t cin, int32_t cout);
+int64_t dd_dconv_wgrad_workspace_bytes(int32_t k, int32_t dil, int32_t cin, int32_t cout);
+int dd_dconv_wgrad(const float* x, const float* g, float* dw, int32_t batch, int32_t h, int32_t w, int32_t x_cstore, int32_t x_coff,
+                   int32_t cin, int32_t gh, int32_t gw, int32_t g_cstore, int32_t g_coff, int32_t cout, int32_t k, int32_t dil,
+                   int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* out[c] (+)= sum over the npix pixels of buf[p, coff + c], c < cout <= 128 (bias gradient of a transposed conv whose
  * weight gradient is taken in the role-swapped form, see gconv.py). */
 int64_t dd_channel_sum_workspace_bytes(void);
