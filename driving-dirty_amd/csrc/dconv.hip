@@ -394,6 +394,8 @@ int dc_variant(const dd_gconv_desc* d) {      // index of the (K, D) instantiati
   if (k == 7 && dl == 3) return 1;
   if (k == 8 && dl == 8) return 2;
   if (k == 6 && dl == 6) return 3;
+  if (k == 3 && dl == 1) return 4;      // out_conv, the decoder's dc1 / dc2 (one residue class: plain LDS-tiled 3x3)
+  if (k == 3 && dl == 3) return 5;      // rm_conv_2
   return -1;
 }
 
@@ -414,7 +416,7 @@ int32_t dd_dconv_supported(const dd_gconv_desc* d) { return dc_supported(d) ? 1 
 
 int64_t dd_dconv_packed_floats(const dd_gconv_desc* d) {
   if (!dc_supported(d)) {
-    dd_fail(DD_ERR_UNSUPPORTED, "dconv: not a stride-1 k7d7 / k7d3 / k8d8 / k6d6 layer with Cin %% 8 == 0 and Cout <= 96");
+    dd_fail(DD_ERR_UNSUPPORTED, "dconv: not a stride-1 k7d7 / k7d3 / k8d8 / k6d6 / k3d1 / k3d3 layer with Cin %% 8 == 0 and Cout <= 96");
     return -1;
   }
   if (d->cout <= 16) return (int64_t)(d->cin / 8) * d->kh * d->kw * 128;
@@ -454,7 +456,9 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
     case 0: DD_DC_NT(7, 7); break;
     case 1: DD_DC_NT(7, 3); break;
     case 2: DD_DC_NT(8, 8); break;
-    default: DD_DC_NT(6, 6); break;
+    case 3: DD_DC_NT(6, 6); break;
+    case 4: DD_DC_NT(3, 1); break;
+    default: DD_DC_NT(3, 3); break;
   }
 #undef DD_DC_NT
 #undef DD_DC
@@ -639,6 +643,149 @@ __global__ __launch_bounds__(1024) void dconv_wgrad_reduce(const float* __restri
   }
 }
 
+// ---- the 32->16 / 16->8 layers: 16x16 accumulator tiles on v_mfma_f32_16x16x4_f32 (K = 4 pixels per MFMA), ALL tap rows in one
+// workgroup: wave w owns tap row ky = w (waves past K idle) and its K x ceil(Cin/16) x ceil(Cout/16) tiles (4 registers each); per
+// step an XT-pixel piece of one x row and the K matching g pieces sit in LDS, so x and g are read from memory exactly once.
+// Lane (q = l >> 4, m = l & 15) supplies x[pixel q][c = m] and g[pixel q + tap shift][o = m].
+template <int K, int D, int C, int O, int XT_>
+struct Dw16Geom {
+  static constexpr int HALO = D * (K - 1), XT = XT_;
+  static constexpr int MT = (C + 15) / 16, NTO = (O + 15) / 16;
+  static constexpr int TPW = K * MT * NTO;                          // tiles of one tap row = tiles per wave
+  static constexpr int XB = XT * C, GB = (XT + HALO) * O;
+  static constexpr int BUF = XB + K * GB + 64;
+  static constexpr int NPIECE = (BUF / 4 + DC_THREADS - 1) / DC_THREADS;
+  static constexpr int NQ = XT / 4;                                 // pixel quads per step
+  static_assert(XT % 4 == 0 && K <= 8 && C % 4 == 0 && O % 4 == 0, "piece split");
+};
+
+template <int K, int D, int C, int O, int XT_>
+__global__ __launch_bounds__(DC_THREADS) void dconv_wgrad16_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                   float* __restrict__ part, int B, int H, int W, int x_cstore,
+                                                                   int x_coff, int gh, int gw, int g_cstore, int g_coff) {
+  using G = Dw16Geom<K, D, C, O, XT_>;
+  __shared__ __attribute__((aligned(16))) float lds[2][G::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q4 = lane >> 4, m = lane & 15;
+  const bool active = wave < K;
+  const int ky = active ? wave : 0;
+  const long rows = (long)B * H;
+  const long r0 = rows * blockIdx.x / gridDim.x, r1 = rows * (blockIdx.x + 1) / gridDim.x;
+  const int nxt = (W + G::XT - 1) / G::XT;
+  const long nsteps = (r1 - r0) * nxt;
+  const int abase = (q4 * C + m) * 4;                                               // + mt*64 + quad*4*C*4
+  const int bbase = (G::XB + ky * G::GB + q4 * O + m) * 4;                          // + (kx*D*O + nt*16)*4 + quad*4*O*4
+
+  f32x4 acc[G::TPW];
+#pragma unroll
+  for (int i = 0; i < G::TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int voff[G::NPIECE];
+#pragma unroll
+  for (int i = 0; i < G::NPIECE; ++i) {
+    const int p = tid + DC_THREADS * i;
+    if (p < G::XB / 4) {
+      const int px = (4 * p) / C, c = 4 * p - px * C;
+      voff[i] = (px * x_cstore + x_coff + c) * 4;
+    } else {
+      const int e = 4 * p - G::XB, kyi = e / G::GB, r = e - kyi * G::GB, pg = r / O, cg = r - pg * O;
+      voff[i] = kyi < K ? ((kyi * D * gw + pg) * g_cstore + g_coff + cg) * 4 : -16;
+    }
+  }
+  auto issue = [&](long s, f32x4* st) {
+    const long row = r0 + s / nxt;
+    const int xt = (int)(s % nxt), b = (int)(row / H), iy = (int)(row - (long)b * H);
+    const int x0 = xt * G::XT;
+    // x: the rest of this row (pixels past the row end read zeros); g: from (iy, x0) to the end of the image -- tap row kyi is a
+    // row offset inside voff.  g pixels past a row's end belong to the next row: they only ever meet x pixels that are zero.
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (((long)b * H + iy) * W + x0) * x_cstore, (W - x0) * x_cstore * 4);
+    const __amdgpu_buffer_rsrc_t gs = dd_rsrc(g + (((long)b * gh + iy) * gw + x0) * g_cstore, (int)min((long)((gh - iy) * gw - x0) * g_cstore * 4, 0x7fffffffL));
+#pragma unroll
+    for (int i = 0; i < G::NPIECE; ++i) {
+      if (DC_THREADS * (i + 1) <= G::XB / 4) st[i] = dd_bload4(xs, voff[i]);
+      else if (DC_THREADS * i >= G::XB / 4) st[i] = dd_bload4(gs, voff[i]);
+      else {
+        const bool isx = tid + DC_THREADS * i < G::XB / 4;
+        const f32x4 vx = dd_bload4(xs, isx ? voff[i] : -16), vg = dd_bload4(gs, isx ? -16 : voff[i]);
+        st[i] = isx ? vx : vg;
+      }
+    }
+  };
+  auto retire = [&](int buf, const f32x4* st) {
+#pragma unroll
+    for (int i = 0; i < G::NPIECE; ++i) {
+      const int p = tid + DC_THREADS * i;
+      if (p < G::BUF / 4) *(f32x4*)&lds[buf][4 * p] = st[i];
+    }
+  };
+
+  if (nsteps > 0) {
+    f32x4 st[G::NPIECE];
+    issue(0, st);
+    retire(0, st);
+  }
+  __syncthreads();
+  int par = 0;
+  for (long s = 0; s < nsteps; ++s) {
+    f32x4 st[G::NPIECE];
+    const bool more = s + 1 < nsteps;
+    if (more) issue(s + 1, st);
+    if (active) {
+      const char* lb = (const char*)&lds[par][0];
+      float av[2][G::MT], bw[2][K * G::NTO];
+      auto ld = [&](int slot, int quad) {
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt) av[slot][mt] = *(const float*)(lb + abase + (quad * 4 * C + mt * 16) * 4);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+          for (int nt = 0; nt < G::NTO; ++nt)
+            bw[slot][kx * G::NTO + nt] = *(const float*)(lb + bbase + ((quad * 4 + kx * D) * O + nt * 16) * 4);
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int quad = 0; quad < G::NQ; ++quad) {
+        if (quad + 1 < G::NQ) ld((quad + 1) & 1, quad + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+          for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < G::NTO; ++nt)
+              acc[(kx * G::MT + mt) * G::NTO + nt] = DD_MFMA16(av[quad & 1][mt], bw[quad & 1][kx * G::NTO + nt], acc[(kx * G::MT + mt) * G::NTO + nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) retire(par ^ 1, st);
+    __syncthreads();
+    par ^= 1;
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[((((long)blockIdx.x * K + wave) * G::TPW + i) * 4 + r) * 64 + lane] = acc[i][r];
+  }
+}
+
+// One block = one 16x16 tile of one tap row (256 threads = 4 registers x 64 lanes): fp64 sum over the workgroups, fixed order.
+template <int K, int D, int C, int O, int XT_>
+__global__ __launch_bounds__(256) void dconv_wgrad16_reduce(const float* __restrict__ part, float* __restrict__ dw, int nwg, int accumulate) {
+  using G = Dw16Geom<K, D, C, O, XT_>;
+  const int ky = blockIdx.x / G::TPW, t = blockIdx.x - ky * G::TPW;
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int w = 0; w < nwg; ++w) s += (double)part[((((long)w * K + ky) * G::TPW + t) * 4 + r) * 64 + lane];
+  const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
+  const int c = mt * 16 + 4 * (lane >> 4) + r, o = nt * 16 + (lane & 15);      // D[row = 4*(lane >> 4) + r][col = lane & 15]
+  if (c < C && o < O) {
+    const long wi = (((long)c * O + o) * K + ky) * K + kx;
+    dw[wi] = accumulate ? dw[wi] + (float)s : (float)s;
+  }
+}
+
 struct DwLayer { int k, d, c, o; };
 const DwLayer kDwLayers[] = {{7, 7, 96, 64}, {7, 7, 64, 32}, {7, 7, 32, 16}, {7, 3, 16, 8}, {8, 8, 64, 32}, {8, 8, 32, 16}, {6, 6, 16, 8}};
 
@@ -648,38 +795,41 @@ int dw_variant(int k, int d, int c, int o) {
   return -1;
 }
 
-// (K, D, Cin, Cout, piece width, tile sets): 42 / 14 / 7 tiles per tap row -> 8 / 2 / 1 sets of <= 8 tiles
-#define DD_DW_DISPATCH(V, F)                      \
+// (K, D, Cin, Cout, piece width, tile sets): 42 / 14 tiles per tap row -> 8 / 2 sets of <= 8 tiles; the 32->16 / 16->8 layers run
+// on the 16-wide kernel (F16: piece width = a divisor of the layer's input width where there is one)
+#define DD_DW_DISPATCH(V, F, F16)                 \
   switch (V) {                                    \
     case 0: F(7, 7, 96, 64, 64, 8); break;        \
     case 1: F(7, 7, 64, 32, 128, 2); break;       \
-    case 2: F(7, 7, 32, 16, 256, 1); break;       \
-    case 3: F(7, 3, 16, 8, 256, 1); break;        \
+    case 2: F16(7, 7, 32, 16, 68); break;         \
+    case 3: F16(7, 3, 16, 8, 64); break;          \
     case 4: F(8, 8, 64, 32, 128, 2); break;       \
-    case 5: F(8, 8, 32, 16, 256, 1); break;       \
-    default: F(6, 6, 16, 8, 256, 1); break;       \
+    case 5: F16(8, 8, 32, 16, 52); break;         \
+    default: F16(6, 6, 16, 8, 92); break;         \
   }
 
 extern "C" {
 
 /* x [B,H,W,x_cstore] (channels [x_coff, +cin)), g = dL/dy [B,gh,gw,g_cstore] (channels [g_coff, +cout)), gh >= H + D(K-1). */
 int32_t dd_dconv_wgrad_supported(int32_t k, int32_t dil, int32_t cin, int32_t cout) {
-  // Measured at bs 32 against the generic weight-gradient kernel: 96->64 11.39 -> 10.36 ms, 64->32 6.25 -> 5.66 ms; the 32->16 and
-  // 16->8 layers fill half / a quarter of the 32-wide MFMA columns here and run faster on the generic kernel (2.73 vs 4.2 ms,
-  // 1.88 vs 4.5 ms): callers are told to keep those there.  DD_DCONV_WGRAD_ALL=1 enables all seven (tests).
-  static const bool all = getenv("DD_DCONV_WGRAD_ALL") != nullptr;
+  // Measured at bs 32 against the generic weight-gradient kernel: 96->64 11.39 -> 10.36 ms, 64->32 6.25 -> 5.66 ms on the 32-wide
+  // kernel; the 32->16 / 16->8 layers would fill half / a quarter of its MFMA columns (4.2 / 4.5 ms there against 2.73 / 1.88 on
+  // the generic kernel) and run on the 16-wide kernel instead.
   const int v = dw_variant(k, dil, cin, cout);
-  return (v == 0 || v == 1 || v == 4 || (all && v >= 0)) ? 1 : 0;
+  static const bool only32 = getenv("DD_DCONV_WGRAD16_OFF") != nullptr;      // A/B knob: keep the 16-wide layers on the generic kernel
+  return v >= 0 && !(only32 && !(v == 0 || v == 1 || v == 4)) ? 1 : 0;
 }
 
 int64_t dd_dconv_wgrad_workspace_bytes(int32_t k, int32_t dil, int32_t cin, int32_t cout) {
   const int v = dw_variant(k, dil, cin, cout);
   if (v < 0) return -1;
-  int tpw = 0;
-#define DD_F(KK, DD_, CC, OO, XX, SS) tpw = DwGeom<KK, DD_, CC, OO, XX, SS>::TPW
-  DD_DW_DISPATCH(v, DD_F)
+  int64_t per_wg = 0;
+#define DD_F(KK, DD_, CC, OO, XX, SS) per_wg = 8L * DwGeom<KK, DD_, CC, OO, XX, SS>::TPW * 1024 * 4
+#define DD_F16(KK, DD_, CC, OO, XX) per_wg = (int64_t)KK * Dw16Geom<KK, DD_, CC, OO, XX>::TPW * 256 * 4
+  DD_DW_DISPATCH(v, DD_F, DD_F16)
 #undef DD_F
-  return (int64_t)DD_NUM_CU * 8 * tpw * 1024 * 4;
+#undef DD_F16
+  return (int64_t)DD_NUM_CU * per_wg;
 }
 
 int dd_dconv_wgrad(const float* x, const float* g, float* dw, int32_t batch, int32_t h, int32_t w, int32_t x_cstore, int32_t x_coff,
@@ -704,8 +854,17 @@ int dd_dconv_wgrad(const float* x, const float* g, float* dw, int32_t batch, int
     hipLaunchKernelGGL((dconv_wgrad_reduce<KK, DD_, CC, OO, XX, SS>), dim3(KK * DwGeom<KK, DD_, CC, OO, XX, SS>::PER_KY), dim3(1024), 0, st, \
                        (const float*)workspace, dw, wg_per_ky, accumulate);                                                                  \
   }
-  DD_DW_DISPATCH(v, DD_F)
+#define DD_F16(KK, DD_, CC, OO, XX)                                                                                                         \
+  {                                                                                                                                         \
+    const int nwg = dd_cu_budget_internal();                                                                                                \
+    hipLaunchKernelGGL((dconv_wgrad16_kernel<KK, DD_, CC, OO, XX>), dim3(nwg), dim3(DC_THREADS), 0, st, x, g, (float*)workspace, batch, h, w, \
+                       x_cstore, x_coff, gh, gw, g_cstore, g_coff);                                                                         \
+    hipLaunchKernelGGL((dconv_wgrad16_reduce<KK, DD_, CC, OO, XX>), dim3(KK * Dw16Geom<KK, DD_, CC, OO, XX>::TPW), dim3(256), 0, st,         \
+                       (const float*)workspace, dw, nwg, accumulate);                                                                       \
+  }
+  DD_DW_DISPATCH(v, DD_F, DD_F16)
 #undef DD_F
+#undef DD_F16
   DD_LAUNCH_CHECK("dconv_wgrad");
   return 0;
 }

@@ -146,8 +146,7 @@ class Layer:
         _chk(weight, "weight")
         if not self.transposed:
             d = _desc(b, src, dst, cs, self.cout, self.k, self.stride, self.dil, self.pad)
-            pk = _pack(weight, d, 0, self.cin * self.T, self.T, False, self.cout, self.cin)
-            _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
+            _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.cin * self.T, self.T, False, self.cout, self.cin)
         elif self.k2s2:
             ih, iw = src.buf.shape[1:3]
             for ph in range(4):
@@ -178,6 +177,9 @@ class Layer:
             msk = relu_src
             if not self.transposed:
                 d = _desc(b, ddst, out, cos, nn, self.k, (1, 1), self.dil, self._flip_pad(), div=self.stride, mask_pass=mask_pass)
+                if _dconv_ok(d):      # stride-1 3x3 layers (out_conv, rm_conv_2): the LDS-tiled kernel
+                    _conv(ddst.buf, weight, None, msk, out.buf, d, epi, n0 * self.T, self.T, self.cin * self.T, True, nn, self.cout)
+                    continue
                 pk = _pack(weight, d, n0 * self.T, self.T, self.cin * self.T, True, nn, self.cout)
             elif self.k2s2:
                 d = _desc(b, ddst, out, cos, nn, (2, 2), (2, 2), mask_pass=mask_pass)

@@ -62,6 +62,8 @@ CASES = [
     ("up4_d3_wide", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (1, 16, 60, 140)),
     ("bm_up1_wide", lambda: nn.ConvTranspose2d(64, 32, 8, dilation=8), (1, 64, 12, 80)),
     ("bm_up3_wide_op2", lambda: nn.ConvTranspose2d(16, 8, 6, dilation=6, output_padding=2), (1, 16, 20, 110)),
+    ("bm_up2_32_16_k8d8", lambda: nn.ConvTranspose2d(32, 16, 8, dilation=8), (2, 32, 9, 60)),
+    ("up3_two_pieces", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 6, 100)),      # wider than one 68-pixel piece of the 16-wide weight gradient
 ]
 
 
