@@ -281,6 +281,22 @@ def other_configs(dev, steps=5, warmup=2):
     gf = (69.14 + 138.28 + 11.64) * BATCH       # head fwd + head bwd + frozen encoder fwd, GFLOP per step
     finish("config3_bbox_frozen_encoder_bs32", dt, BATCH, {"dtype": "f32", "algorithmic_TFLOPs": round(gf / dt / 1e3, 1),
                                                            "frac_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_F32_MFMA_TF, 3)})
+    del m, ae, opt
+    torch.cuda.empty_cache()
+    # config 4, per GPU: joint roadmap + bounding-box step (one shared encoder pass, both heads, summed losses), bs = 32
+    from driving_dirty_amd.joint import JointRoadMapBBox
+    torch.manual_seed(SEED)
+    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT))
+    m = JointRoadMapBBox(Namespace(pretrained_ae=ae, learning_rate=1e-3, output_img_freq=500)).to(dev)
+    opt = HipAdam(m.parameters(), lr=1e-3)
+    opt.overlap_with_backward()
+
+    def joint_step(i):
+        m.zero_grad(set_to_none=True)
+        m.training_step(batch, i)["loss"].backward()
+        opt.step()
+    finish("config4_joint_roadmap_bbox_bs32_per_gpu", time_steps(joint_step, steps, warmup), BATCH, {"dtype": "f32"})
+    opt.close()
     del m, ae, opt, batch, views, road, tgt
     torch.cuda.empty_cache()
     # config 5, per GPU: bf16 mixed precision at 2x resolution (6x3x512x612), bs = 16, roadmap step fwd+bwd+Adam

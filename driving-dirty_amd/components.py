@@ -129,9 +129,9 @@ class Encoder(nn.Module):
         """x4: [B,H,W,4] NHWC image (channel 3 zero), e.g. straight from ``ops.stitch6`` (fp32) or
         ``ops_bf16.stitch6_bf16`` (bf16: selects the mixed-precision conv stack)."""
         if x4.dtype == torch.bfloat16:
-            if self.c3_only:
-                raise NotImplementedError("the bf16 conv stack feeds the pooled exit only (c3_only is fp32)")
             from . import ops_bf16
+            if self.c3_only:      # the conv feature for the (fp32) box heads: NCHW-shaped view of an fp32 NHWC buffer
+                return ops_bf16.encoder_conv_stack(x4, self.c1, self.c2, self.c3, pool=False).permute(0, 3, 1, 2)
             pooled = ops_bf16.encoder_conv_stack(x4, self.c1, self.c2, self.c3)
             return self._tail(pooled, keeps)
         if self.c3_only:

@@ -119,11 +119,12 @@ class EncoderConvStackBf16(torch.autograd.Function):
 
     Reference arithmetic: Encoder.forward, src/autoencoder/components.py:41-47 (the reference itself is fp32 only; the
     rounding points are those of torch autocast: every conv output is rounded to bf16 once).
-    forward(x4 bf16 [B,H,W,4], w1,b1,w2,b2,w3,b3 fp32) -> pooled fp32 [B, 32*Ho*Wo/4]
+    forward(x4 bf16 [B,H,W,4], w1,b1,w2,b2,w3,b3 fp32, pool) -> pooled fp32 [B, 32*Ho*Wo/4], or (pool = False: the ``c3_only``
+    exit, components.py:44-45) the bf16-rounded c3 feature as an fp32 NHWC tensor [B,Ho,Wo,32] for the fp32 box heads.
     """
 
     @staticmethod
-    def forward(ctx, x4, w1, b1, w2, b2, w3, b3):
+    def forward(ctx, x4, w1, b1, w2, b2, w3, b3, pool=True):
         b, h, w, _ = x4.shape
         d1, d2, d3 = conv_desc(b, h, w, 3, 1), conv_desc(b, h, w, 32, 1), conv_desc(b, h, w, 32, 2)
         a1, s1 = conv_fwd(x4, conv_pack(w1, d1, PACK_FWD), b1, d1)
@@ -137,14 +138,18 @@ class EncoderConvStackBf16(torch.autograd.Function):
         if need[1] or need[2]:
             p2d = conv_pack(w2, d2, PACK_DGRAD_S1)
         ctx.save_for_backward(x4, a1, a2, a3, p2d, p3d, s1, s2)
-        return pool4_fwd(a3)
+        ctx.pool = bool(pool)
+        return pool4_fwd(a3) if pool else to_f32(a3)
 
     @staticmethod
-    def backward(ctx, grad_pooled):
+    def backward(ctx, grad_out):
         x4, a1, a2, a3, p2d, p3d, s1, s2 = ctx.saved_tensors
         b, h, w, _ = x4.shape
         d1, d2, d3 = conv_desc(b, h, w, 3, 1), conv_desc(b, h, w, 32, 1), conv_desc(b, h, w, 32, 2)
-        g3 = pool4_relu_bwd(grad_pooled.contiguous(), a3)
+        if ctx.pool:
+            g3 = pool4_relu_bwd(grad_out.contiguous(), a3)
+        else:      # feature exit: ReLU mask in fp32, then the one rounding to bf16 the contract prescribes for a pre-activation gradient
+            g3 = to_bf16(ops.relu_bwd(grad_out.contiguous(), to_f32(a3)))
         need = ctx.needs_input_grad
         dw3, db3 = conv_wgrad(a2, g3, d3) if (need[5] or need[6]) else (None, None)
         dw2 = db2 = dw1 = db1 = None
@@ -159,8 +164,8 @@ class EncoderConvStackBf16(torch.autograd.Function):
                 g1 = conv_dgrad(g2, p2d, s1, d2)
                 del g2
                 dw1, db1 = conv_wgrad(x4, g1, d1)
-        return None, dw1, db1, dw2, db2, dw3, db3
+        return None, dw1, db1, dw2, db2, dw3, db3, None
 
 
-def encoder_conv_stack(x4, c1, c2, c3):
-    return EncoderConvStackBf16.apply(x4, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias)
+def encoder_conv_stack(x4, c1, c2, c3, pool=True):
+    return EncoderConvStackBf16.apply(x4, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, pool)

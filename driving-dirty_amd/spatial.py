@@ -119,6 +119,11 @@ class BBSpatialRoadMap(LightningModule):
         self.ae.freeze()
         self.ae.encoder.c3_only = True
         self.ae.decoder = None
+        # hparams.precision = "bf16": the (frozen or fine-tuned) encoder conv stack on the bf16 matrix cores, its feature handed to
+        # the fp32 heads (no reference counterpart: oracle/bf16_parts.py states the contract)
+        self.ae.encoder.precision = str(hparam(hparams, "precision", self.ae.encoder.precision))
+        if self.ae.encoder.precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.ae.encoder.precision!r}")
         self.space_map_cnn = SpatialMappingCNN()
         self.box_merge = RoadMapBoxesMergingCNN()
 
@@ -128,7 +133,12 @@ class BBSpatialRoadMap(LightningModule):
     def forward(self, x, rm):
         """x [b,6,3,256,306], rm [b,1,800,800] -> [b,800,800].  spatial_w_rm.py:67-83."""
         space_rep = self.space_map_cnn(x)
-        ssr = self.ae.encoder.forward_nhwc4(ops.stitch6(x.contiguous())[0])
+        if self.ae.encoder.precision == "bf16":
+            from . import ops_bf16
+            wide4 = ops_bf16.stitch6_bf16(x.contiguous())
+        else:
+            wide4 = ops.stitch6(x.contiguous())[0]
+        ssr = self.ae.encoder.forward_nhwc4(wide4)
         yhat = self.box_merge(ssr, space_rep, rm)
         return yhat.squeeze(1)
 

@@ -197,3 +197,31 @@ def test_roadmap_step_in_bf16_against_oracle(dev):
     model.ae.encoder.precision = "fp32"
     l32 = model.training_step((tuple(views.to(dev)), None, tuple(road.to(dev))), 0)["loss"]
     assert abs(float(l32.detach()) - float(out["loss"].detach())) / float(l32.detach()) < 1e-2
+
+
+def test_c3_only_exit_in_bf16_against_oracle(dev):
+    """Encoder(precision='bf16', c3_only=True): the conv feature the box heads consume (components.py:44-45), forward and the
+    conv gradients for an upstream gradient on the feature, vs the mixed-precision oracle."""
+    from driving_dirty_amd.components import Encoder
+    from oracle import ae_parts, bf16_parts
+    enc = synth.fill_module(Encoder(16, 8, 3, 16, 70), seed=37)
+    ref = ae_parts.EncoderNet(16, 8, 3, 16, 70)
+    ref.load_state_dict(enc.state_dict())
+    enc = enc.to(dev)
+    enc.precision = "bf16"
+    enc.c3_only = True
+    x = synth.hash_uniform((3, 3, 16, 70), synth.key_salt("bf_c3x"), 0.0, 1.0)
+    feat = enc(x.to(dev))
+    assert feat.shape == (3, 32, 8, 35) and feat.dtype == torch.float32
+    wf = synth.hash_uniform(tuple(feat.shape), synth.key_salt("bf_c3w"))
+    (feat * wf.to(dev)).sum().backward()
+    _, (a1, a2, a3) = bf16_parts.conv_stack_pooled(bf16r(x), ref.c1, ref.c2, ref.c3)
+    (a3 * wf.double()).sum().backward()
+    # two layers of one-ulp flips upstream perturb a3 slightly beyond one ulp in rare elements (as in test_conv_stack_against_oracle):
+    # the feature is judged against its peak, and almost all of it must be bit-identical
+    d = (feat.detach().cpu().double() - a3.detach()).abs()
+    assert float(d.max() / a3.detach().abs().max()) < 4e-3 and float((d > 0).double().mean()) < 2e-2
+    for k in ("c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias"):
+        r = dict(ref.named_parameters())[k].grad.double()
+        err = float((dict(enc.named_parameters())[k].grad.cpu().double() - r).abs().max() / r.abs().max())
+        assert err < 4e-3, (k, err)
