@@ -58,6 +58,8 @@ class DecoderConvStack(torch.autograd.Function):
         cls.L2.forward(w2, b2, View(a1), View(a2), EPI_BIAS_RELU)
         cls.L3.forward(w3, b3, View(a2), View(a3), EPI_BIAS_RELU)
         cls.L4.forward(w4, b4, View(a3), View(y4, 0, 3), EPI_BIAS)
+        if TRACE is not None:
+            TRACE.update(dc1=a1, dc2=a2, dc3=a3)
         ctx.save_for_backward(x0, a1, a2, a3, w1, w2, w3, w4)
         ctx.dims = (dh, dw)
         return ops.nhwc_to_nchw(y4, 3)

@@ -619,6 +619,8 @@ class BnReluDrop(torch.autograd.Function):
         check(_lib.lib().dd_bn_relu_drop_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(keep),
                                              _p(y), _p(save_mean), _p(save_inv), rows, feat, eps, momentum, scale,
                                              int(training), _p(num_batches_tracked), _stream()), "dd_bn_relu_drop_fwd")
+        if TRACE is not None:
+            TRACE.setdefault("dense", []).append(y)
         ctx.save_for_backward(x, y, gamma, keep, save_mean, save_inv, running_mean, running_var)
         ctx.cfg = (bool(training), eps, scale)
         return y
@@ -676,6 +678,8 @@ class EncoderTail(torch.autograd.Function):
                                          _p(bn2.running_var), _p(nbt(bn2)), _p(keep2), _p(wz), _p(bz), _p(y1), _p(lin2), _p(y2),
                                          _p(z), _p(mean1), _p(inv1), _p(mean2), _p(inv2), m, h1, h2, l, bn1.eps, bn2.eps,
                                          mom(bn1), mom(bn2), scale1, scale2, int(training), _stream()), "dd_mlp_tail_fwd")
+        if TRACE is not None:
+            TRACE.setdefault("dense", []).extend([y1, y2])
         ctx.save_for_backward(lin1, y1, lin2, y2, gamma1, gamma2, keep1, keep2, w2, wz, mean1, inv1, mean2, inv2,
                               bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var)
         ctx.cfg = (training, bn1.eps, bn2.eps, scale1, scale2)

@@ -55,8 +55,8 @@ class FcBlock(nn.Module):
         self.fc1 = nn.Linear(in_dim, out_dim)
         self.fc_bn = nn.BatchNorm1d(out_dim)
 
-    def forward(self, x, mask=None):
-        h = F.relu(self.fc_bn(self.fc1(x)))
+    def forward(self, x, mask=None, branch=PLAIN, name="dense"):
+        h = branch.relu(self.fc_bn(self.fc1(x)), name)
         if mask is not None:
             return h * mask / (1.0 - self.drop_p)
         return F.dropout(h, self.drop_p)
@@ -96,8 +96,8 @@ class EncoderNet(nn.Module):
         feat = self.conv_stack(x, branch)
         if self.c3_only:                      # components.py:44-45
             return feat
-        h = self.fc1(self.pool(feat, branch), masks[0])
-        h = self.fc2(h, masks[1])
+        h = self.fc1(self.pool(feat, branch), masks[0], branch, "fc1")
+        h = self.fc2(h, masks[1], branch, "fc2")
         return self.fc_z_out(h)
 
 
@@ -123,12 +123,13 @@ class DecoderNet(nn.Module):
         self.dc3 = nn.ConvTranspose2d(32, 32, 2, stride=2)
         self.dc4 = nn.ConvTranspose2d(32, in_channels, 1)
 
-    def forward(self, z, masks=(None, None)):
-        h = self.fc2(self.fc1(z, masks[0]), masks[1])
+    def forward(self, z, masks=(None, None), branch=PLAIN):
+        """``branch`` (oracle.branch.Branch) records or replays the five ReLU decisions; default: plain F.relu."""
+        h = self.fc2(self.fc1(z, masks[0], branch, "d_fc1"), masks[1], branch, "d_fc2")
         h = h.reshape(h.size(0), 64, self.deconv_dim_h, self.deconv_dim_w)
-        h = F.relu(F.conv_transpose2d(h, self.dc1.weight, self.dc1.bias, padding=1))
-        h = F.relu(F.conv_transpose2d(h, self.dc2.weight, self.dc2.bias, padding=1))
-        h = F.relu(F.conv_transpose2d(h, self.dc3.weight, self.dc3.bias, stride=2))
+        h = branch.relu(F.conv_transpose2d(h, self.dc1.weight, self.dc1.bias, padding=1), "dc1")
+        h = branch.relu(F.conv_transpose2d(h, self.dc2.weight, self.dc2.bias, padding=1), "dc2")
+        h = branch.relu(F.conv_transpose2d(h, self.dc3.weight, self.dc3.bias, stride=2), "dc3")
         return F.conv_transpose2d(h, self.dc4.weight, self.dc4.bias)      # no activation (components.py:92)
 
 

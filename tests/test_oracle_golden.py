@@ -327,7 +327,7 @@ def test_branch_record_and_replay():
     enc.train()
     rec = Branch()
     z = enc(x, branch=rec)
-    assert sorted(rec.masks) == ["pool", "relu1", "relu2", "relu3"]
+    assert sorted(rec.masks) == ["fc1", "fc2", "pool", "relu1", "relu2", "relu3"]
     assert torch.equal(z, enc(x)) and torch.equal(z, enc(x, branch=Branch(rec.masks)))
     w = synth.hash_uniform(tuple(z.shape), synth.key_salt("br_w"))
     (z * w).sum().backward()
