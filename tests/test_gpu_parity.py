@@ -450,9 +450,12 @@ def _grad_floor(g, key):
 
 
 def _budget(g, key):
-    """Tolerance for one fixture tensor: 1e-3 of its peak (north_star), or twice the deviation the REFERENCE's
-    own fp32 run shows from its fp64 run, whichever is larger.  At B = 2 the train-mode BatchNorm1d makes the
-    full-size gradients ill-conditioned: the reference's fp32 gradients differ from fp64 by up to 1e-2."""
+    """Tolerance for one tensor of the B = 2 EDGE-CASE fixture: 1e-3 of its peak (north_star), or twice the deviation the
+    REFERENCE's own fp32 run shows from its fp64 run, whichever is larger.  Through a train-mode BatchNorm1d over TWO rows the
+    normalised values are +-1 whatever the inputs: the gradient that reaches everything upstream of it is an eps = 1e-5 effect,
+    a difference of nearly equal numbers (the reference's fp32 gradients are up to 2e-2 of peak off their fp64 values there).
+    The well-conditioned checks of this path are at the headline batch: tests/test_gpu_round2.py (B = 32 fixture; the fp64
+    oracle on the product's own ReLU / max-pool branch within 2e-4, no budget)."""
     a, b = g[key + "_f64"], g[key + "_f32"]
     ref_dev = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-30))
     return max(CHAIN_TOL, 2.0 * ref_dev) if ref_dev < 1.0 else CHAIN_TOL
@@ -498,7 +501,8 @@ def _samp(t, idx):
 
 
 def test_full_size_roadmap_against_reference_golden(dev, golden):
-    """Config-2 shapes (6x3x256x306 -> 800x800) at B = 2: loss, z, logits and every gradient vs the fixture."""
+    """Config-2 shapes (6x3x256x306 -> 800x800) at B = 2, the ill-conditioned edge case (see _budget): loss, z, logits and
+    every gradient vs the fixture.  The headline batch is checked in tests/test_gpu_round2.py."""
     from driving_dirty_amd.autoencoder import BasicAE
     from driving_dirty_amd.roadmap import RoadMapBCE
     g = golden("full_roadmap")
