@@ -338,7 +338,11 @@ def run_rank(a):
     backend = os.environ.get("DD_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1:
+    rehearse = world == 1 and os.environ.get("DD_REHEARSE_RCCL") == "1"      # the N > 1 call pattern on a 1-rank RCCL communicator
+    if rehearse:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("DD_RESERVED_CUS", "16"))
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -353,7 +357,7 @@ def run_rank(a):
     # RCCL's all-reduce workgroups run for milliseconds beside the conv backward and need LDS the conv workgroups do not
     # leave free: GradSync gives them their own compute units (and RCCL is capped at as many channels) from the first big
     # gradient to the end of the step, so the conv grids stay one resident round.  DD_RESERVED_CUS overrides.
-    reserve = int(os.environ.get("DD_RESERVED_CUS", "16")) if world > 1 else 0
+    reserve = int(os.environ.get("DD_RESERVED_CUS", "16")) if (world > 1 or rehearse) else 0
     if a.cu_budget:
         _lib.check(_lib.lib().dd_set_cu_budget(a.cu_budget), "dd_set_cu_budget")
 
@@ -367,9 +371,9 @@ def run_rank(a):
     model.training_step(synthetic_batch(dev, 2, rank), 0)["loss"].backward()   # unfreezes the AE (epoch 0 >= 0)
     model.zero_grad(set_to_none=True)
     opt = HipAdam(model.parameters(), lr=1e-3)
-    sync = GradSync(model, reserve_cus=reserve)          # broadcasts rank 0's parameters and buffers
+    sync = GradSync(model, reserve_cus=reserve, force_collectives=rehearse)          # broadcasts rank 0's parameters and buffers
     if not a.no_adam_overlap:
-        opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if world > 1 else None)
+        opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if (world > 1 or rehearse) else None)
     batch = synthetic_batch(dev, BATCH, rank)
     timer = KernelTimer()
     timer.install()
@@ -385,7 +389,7 @@ def run_rank(a):
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
@@ -393,13 +397,13 @@ def run_rank(a):
     for i in range(a.steps):
         loss = step(a.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
     n_ranks_seen = 1
-    if world > 1:
+    if world > 1 or rehearse:
         cdev = dev if backend == "nccl" else "cpu"
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -445,6 +449,7 @@ def run_rank(a):
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "n_ranks_seen": n_ranks_seen,
+            **({"rehearsal": "N > 1 call pattern on a 1-rank RCCL communicator (DD_REHEARSE_RCCL=1)"} if rehearse else {}),
             "config": {"workload": "BASELINE configs[1]: roadmap segmentation 6x3x256x306 -> 800x800 mask, "
                                    "bs=32 per GPU, fp32, hidden %d / latent %d, encoder unfrozen, fwd+bwd+Adam" % (HIDDEN, LATENT),
                        "global_batch": world * BATCH, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
@@ -467,7 +472,7 @@ def run_rank(a):
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

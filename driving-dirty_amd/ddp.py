@@ -29,18 +29,22 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25, reserve_cus=0):
+    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25, reserve_cus=0, force_collectives=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collectives: issue every collective even in a 1-rank group -- a rehearsal of the N > 1 call pattern (async
+        # all-reduce of gradient pieces from autograd hooks, the optimizer's per-piece waits, the CU hand-over) on the real
+        # backend when only one GPU is at hand; results are unchanged (a 1-rank all-reduce is the identity)
+        self.active = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         self.big_numel = big_numel
         self.chunk_numel = max(4, chunk_numel - chunk_numel % 4)      # pieces start on 16-byte boundaries
         # RCCL's workgroups need compute units the resident conv grids do not leave: while collectives are in flight (from
         # the first big gradient to finish()) the conv kernels are launched on 256 - reserve_cus units; the forward, which
         # runs beside no collective, keeps the whole GPU.
-        self.reserve_cus = int(reserve_cus) if self.world > 1 else 0
+        self.reserve_cus = int(reserve_cus) if self.active else 0
         self._reserved = False
         self.params = [p for p in module.parameters()]
-        if self.world > 1:      # every replica starts from rank 0's weights and BatchNorm statistics (DDP's contract)
+        if self.active:      # every replica starts from rank 0's weights and BatchNorm statistics (DDP's contract)
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=self.group)
@@ -48,7 +52,7 @@ class GradSync:
         self._by_param = {}
         self._small = []
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -89,7 +93,7 @@ class GradSync:
 
     def finish(self):
         """Reduce the small gradients in one message and wait for everything in flight."""
-        if self.world > 1 and self._small:
+        if self.active and self._small:
             flat = torch.cat([p.grad.reshape(-1) for p in self._small])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             off = 0

@@ -192,3 +192,24 @@ def test_hipadam_overlapped_under_data_parallel_matches_single_process(tmp_path)
     # in the last bit is the kernels' own run-to-run summation order inside one backward)
     bad = {k: d for k, d in diffs.items() if d > 1e-6}
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_bench_step_over_a_one_rank_rccl_communicator():
+    """The N > 1 call pattern of the bench step -- RCCL initialised on the device, rank 0's weights broadcast, each gradient
+    piece all-reduced asynchronously from its autograd hook, HipAdam waiting piece by piece on its side stream, compute units
+    handed to RCCL for the backward, the barrier and the MAX-over-ranks timing -- on the real backend with the one GPU of
+    this box (a 1-rank all-reduce is the identity, so the step must also still produce a finite loss)."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DD_REHEARSE_RCCL="1", MASTER_PORT=str(35500 + os.getpid() % 2000))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-others", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_ranks_seen"] == 1 and "rehearsal" in line and line["value"] > 0
+    loss = line["config"]["final_loss"]
+    assert loss == loss and abs(loss) < 1e3                                  # finite
