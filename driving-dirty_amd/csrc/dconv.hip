@@ -448,6 +448,11 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
   const int nt = d->cout <= 16 ? 0 : (d->cout + 31) / 32;
   const int wp_bytes = (int)(dd_dconv_packed_floats(d) * 4);
   static const int dbg_repeat = getenv("DD_DCONV_REPEAT") ? atoi(getenv("DD_DCONV_REPEAT")) : 1;
+  // the full transposed forward of the wide layers: input-aligned tiles, no border zero multiplied (dconv_t.hip)
+  if (dd_dconv_tfwd_launch(x, packed, bias, y, d, epilogue, wp_bytes, st)) {
+    DD_LAUNCH_CHECK("dconv_tfwd");
+    return 0;
+  }
   const DcPlan plan = dc_plan(*d, d->dil_h);
   const int grid = (int)max(1, min(dd_cu_budget_internal(), plan.total));      // one 8-wave workgroup per CU, all resident
 #define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes, dbg_repeat)
