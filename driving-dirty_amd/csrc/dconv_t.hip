@@ -1,55 +1,81 @@
-// Forward of the dilated stride-1 ConvTranspose2d layers (spatial_bb/components.py:135-136), "input-aligned" form.
+// Forward of the dilated stride-1 ConvTranspose2d layers (spatial_bb/components.py:135-137), "input-aligned" form.
 //
 // The flipped-tap gather of dconv.hip makes every OUTPUT pixel visit all k x k taps; with out = in + d(k-1) a quarter of
 // those (pixel, tap) pairs read the zero border (298^2 x 49 visits for 256^2 x 49 products: x1.36; tap skipping per
 // 64-pixel wave tile and 4-row group recovers little because EVERY tile of a 43-wide residue class is near a border).
-// Here the m-tiles are aligned to the INPUT row instead: for tap column kx the 32 input pixels [32t, 32t + 32) feed the 32
-// output pixels [32t + s(kx), ...), s(kx) = pad_w - d*kx -- one ACCUMULATOR TILE PER (m-tile, tap column), and no border
-// zero is ever multiplied:
+// Here the m-tiles are aligned to the INPUT row instead: for tap column kx the input pixels [Wt, Wt + W) feed the output
+// pixels [Wt + s(kx), ...), s(kx) = pad_w - d*kx -- one ACCUMULATOR TILE PER (m-tile, tap column), and no border zero is
+// ever multiplied:
 //
-//   * a workgroup (8 waves) owns one output row oy of one image x one 32-channel column tile: the k_valid <= k input rows
-//     oy - pad + d*ky of an 8-channel chunk sit in LDS (double buffered: row ky of chunk q + 1 is fetched while tap row ky of
-//     chunk q is multiplied); tap rows outside the image are skipped for the whole workgroup -- exact in y as well;
-//   * the row's (m-tile, kx) accumulator tiles are dealt evenly to the 8 waves (up_conv_1: 8 m-tiles x 7 = 7 per wave, one
-//     m-tile each; up_conv_2: 10 x 7 = 70 -> 9 per wave); per (chunk, tap row, tile) one ds_read_b128 and one lane-linear
-//     16-byte weight load at a scalar offset (the image dd_dconv_pack writes) feed 4 MFMAs; both are requested one whole tap
-//     row ahead, into the registers the tile's MFMAs have just read;
+//   * a workgroup (8 waves) owns one output row oy of one image x one column tile of output channels: the k_valid <= k
+//     input rows oy - pad + d*ky of an 8-channel chunk sit in LDS (double buffered: row ky of chunk q + 1 -- after the last
+//     chunk, of the workgroup's NEXT row -- is fetched while tap row ky of chunk q is multiplied); tap rows outside the image
+//     are skipped for the whole workgroup: exact in y as well;
+//   * the row's (m-tile, kx) accumulator tiles are dealt evenly to the 8 waves; per (chunk, tap row, tile) one LDS read and
+//     one lane-linear weight load at a scalar offset (the images dd_dconv_pack writes) feed the tile's MFMAs; the weight
+//     fragment is requested one whole tap row ahead, into the registers the tile's MFMAs have just read;
 //   * epilogue: the k partial rows are added into one LDS row image at their shifts (k barrier-separated passes: a fixed
 //     order, deterministic), then bias / ReLU and 16-byte stores.
+//
+// Three forms (MODE):
+//   0  Cout > 16, at most 8 m-tiles of 32 pixels (up_conv_1, 256 wide): wave w owns m-tile w and its k tap columns --
+//      one A fragment per (chunk, tap row) feeds 4k v_mfma_f32_32x32x2_f32;
+//   1  Cout > 16, wider rows (up_conv_2, 298 wide -> 10 m-tiles x 7 = 70 tiles, 9 per wave);
+//   2  Cout <= 16 (up_conv_3, 340 wide): tiles of 16 pixels x 16 channels on v_mfma_f32_16x16x4_f32 (154 tiles, 20 per wave).
 //
 // Tasks are dealt to the XCDs in (image, residue class, phase row, column tile) order, so the workgroups resident on one XCD
 // walk neighbouring rows of ONE class and share their input rows (k users each) in that XCD's L2.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "dd_common.h"
 
 namespace {
 
 constexpr int TF_THREADS = 512;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define DD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int K, int IWP>
+template <int K, int D, int MODE, int IWP>
 struct TfGeom {
+  static constexpr bool N16 = MODE == 2;
+  static constexpr int TW = N16 ? 16 : 32;                // pixels of an m-tile
+  static constexpr int NE = N16 ? 4 : 16;                 // accumulator registers of a tile
   static constexpr int ROWF = IWP * 8;                    // floats of a patch row (IWP pixels x 8 channels)
   static constexpr int BUFF = K * ROWF;                   // floats of one buffer
   static constexpr int NPR = (IWP * 2 + TF_THREADS - 1) / TF_THREADS;      // 16-byte pieces per thread and patch row
-  static constexpr int OPITCH = 40;                       // floats per pixel of the output row image (32 channels + 8: lanes 32..63
-                                                          // of an accumulator tile sit 4 pixels further = 160 floats = 32 banks on)
-  static constexpr int OWMAX = BUFF / OPITCH;             // widest output row (+ 1 spare pixel) the image (one buffer) holds
+  // floats per pixel of the output row image.  32-wide tiles: lanes 32..63 sit 4 pixels = 160 floats = 32 banks further;
+  // 16-wide tiles: the four lane groups sit 4 pixels = 80 floats = 16 banks apart.
+  static constexpr int P = N16 ? 20 : 40;
+  static constexpr int HALO = D * (K - 1);
 };
 
-// NSLOT accumulator tiles per wave; ONE_MT: the tiles of a wave are (m-tile = wave, kx = slot) (needs n_mt <= 8, NSLOT == K)
-template <int K, int D, int NSLOT, bool ONE_MT, int IWP>
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding vector-memory operation
+// (vmcnt(0)): here that would drain the weight fragments requested a tap row ahead at every chunk boundary -- a full L2
+// round trip with all 8 waves of the workgroup idle (measured: ~3k cycles per chunk, 12 % of up_conv_1's forward).  Nothing this
+// kernel reads from global memory is written by it, so only the LDS patch / row image need the ordering.
+__device__ __forceinline__ void tf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct TfTask {
+  int b, nt, oy, ry, ky0, ky1;
+};
+
+template <int K, int D, int NSLOT, int MODE, int IWP>
 __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
-                                                                const dd_gconv_desc d, int epi, int wp_bytes) {
-  using G = TfGeom<K, IWP>;
+                                                                const dd_gconv_desc d, int epi, int wp_bytes, int dbg_repeat, int dbg_flags) {
+  using G = TfGeom<K, D, MODE, IWP>;
+  constexpr bool N16 = G::N16, ONE_MT = MODE == 0;
+  constexpr int TW = G::TW, NE = G::NE, P = G::P;
+  using frag = typename std::conditional<N16, f32x2, f32x4>::type;
+  using acc_t = typename std::conditional<N16, f32x4, f32x16>::type;
   __shared__ __attribute__((aligned(16))) float lds[2][G::BUFF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, n = lane & 31;
-  const int NC = d.cin >> 3, NTC = (d.cout + 31) >> 5;
+  const int NC = d.cin >> 3, NTC = N16 ? 1 : (d.cout + 31) >> 5;
   const int rows_max = (d.out_h + D - 1) / D;
-  const int n_mt = (d.in_w + 31) >> 5;
+  const int n_mt = (d.in_w + TW - 1) / TW;
   const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
   const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
   const __amdgpu_buffer_rsrc_t ws = dd_rsrc(wp, wp_bytes);
@@ -64,7 +90,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
     poff[i] = (p >> 1) < d.in_w ? ((p >> 1) * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : (int)0xC0000000;
   }
   // this wave's tiles: linear index L = m-tile * K + kx
-  int s_mt[NSLOT], s_kx[NSLOT];
+  int s_kx[NSLOT];
   bool s_ok[NSLOT];
   int aoff[NSLOT];                                       // byte offset of this lane's A fragment of the slot in a patch row
   int ioff[NSLOT];                                       // float index of accumulator element 0 of the slot in the output row image
@@ -72,156 +98,233 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
   for (int i = 0; i < NSLOT; ++i) {
     const int L = ONE_MT ? wave * K + i : wave * NSLOT + i;
     s_ok[i] = L < n_mt * K;
-    s_mt[i] = s_ok[i] ? L / K : 0;
-    s_kx[i] = s_ok[i] ? L - s_mt[i] * K : 0;
-    aoff[i] = ((s_mt[i] * 32 + n) * 8 + 4 * h) * 4;
-    ioff[i] = (s_mt[i] * 32 + 4 * h) * G::OPITCH + n;
+    const int mt = s_ok[i] ? L / K : 0;
+    s_kx[i] = s_ok[i] ? L - mt * K : 0;
+    if constexpr (N16) {
+      aoff[i] = ((mt * 16 + (lane & 15)) * 8 + 2 * (lane >> 4)) * 4;
+      ioff[i] = (mt * 16 + 4 * (lane >> 4)) * P + (lane & 15);
+    } else {
+      aoff[i] = ((mt * 32 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
+      ioff[i] = (mt * 32 + 4 * (lane >> 5)) * P + (lane & 31);
+    }
   }
 
   // ---- tasks of this workgroup: XCD = blockIdx % 8 owns the x-th eighth of the (image, residue, phase row, column tile) list
   const int per_x = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
   const int per_img = D * rows_max * NTC;
   const long len = (long)d.batch * per_img;
-  const long seg0 = len * xcd / 8, seg1 = len * (xcd + 1) / 8;
-
-  for (long t = seg0 + slot; t < seg1; t += per_x) {
-    const int b = (int)(t / per_img);
-    int rem = (int)(t - (long)b * per_img);
-    const int nt = rem % NTC;
+  const long seg1 = len * (xcd + 1) / 8;
+  auto decode = [&](long t, TfTask& k) -> bool {      // false: a phase row past the last output row of its residue class
+    k.b = (int)(t / per_img);
+    int rem = (int)(t - (long)k.b * per_img);
+    k.nt = rem % NTC;
     rem /= NTC;
     const int r = rem / rows_max, jy = rem - r * rows_max;
-    const int oy = r + D * jy;
-    if (oy >= d.out_h) continue;
-    const int ry = oy - d.pad_h;
-    const int ky0 = ry >= 0 ? 0 : (-ry + D - 1) / D;
-    const int ky1 = min(K - 1, (d.in_h - 1 - ry) >= 0 ? (d.in_h - 1 - ry) / D : -1);
-    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)b * d.in_h * d.in_w * d.in_cstore, in_bytes);
-    const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+    k.oy = r + D * jy;
+    k.ry = k.oy - d.pad_h;
+    k.ky0 = k.ry >= 0 ? 0 : (-k.ry + D - 1) / D;
+    k.ky1 = min(K - 1, (d.in_h - 1 - k.ry) >= 0 ? (d.in_h - 1 - k.ry) / D : -1);
+    return k.oy < d.out_h;
+  };
+  auto next_task = [&](long t, TfTask& k) -> long {   // first valid task at or after t in this workgroup's sequence; seg1 if none
+    while (t < seg1 && !decode(t, k)) t += per_x;
+    return t < seg1 ? t : seg1;
+  };
 
-    f32x16 acc[NSLOT];
+  frag Bf[NSLOT];
+  auto bload = [&](int i, int q, int ky, int nt) {
+    if constexpr (N16) {
+      Bf[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ws, lane * 8, ((q * K + ky) * K + s_kx[i]) * 512, 0));
+    } else {
+      const int soff = (((q * K + ky) * K + s_kx[i]) * NTC + nt) * 1024;
+      Bf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff, 0));
+    }
+  };
+
+  TfTask cur, nxt;
+  long t = next_task(len * xcd / 8 + (blockIdx.x >> 3), cur);
+  bool prefetched = false;                             // chunk 0 of `cur` (and its first weight fragments) already requested
+  int par = 0;
+  while (t < seg1) {
+    const long tn = next_task(t + per_x, nxt);
+    const bool have_next = tn < seg1;
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)cur.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    const __amdgpu_buffer_rsrc_t xn = dd_rsrc(x + (long)nxt.b * d.in_h * d.in_w * d.in_cstore, have_next ? in_bytes : 0);
+    const int ky0 = cur.ky0, ky1 = cur.ky1, ry = cur.ry;
+
+    acc_t acc[NSLOT];
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      for (int e = 0; e < NE; ++e) acc[i][e] = 0.f;
 
+    bool fetched_next = false;
     if (ky1 >= ky0) {
-      // ---- chunk 0 of this task (not overlapped: once per ~300k cycles of multiplying)
-      for (int ky = ky0; ky <= ky1; ++ky) {
-        const int rowoff = (ry + D * ky) * d.in_w * d.in_cstore * 4;
+      if (!prefetched) {
+        // ---- chunk 0 of this task, all rows requested before the first is stored (first task of the workgroup only)
+        f32x4 v[K][G::NPR];
 #pragma unroll
-        for (int i = 0; i < G::NPR; ++i) {
-          const int p = tid + TF_THREADS * i;
-          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, poff[i] + rowoff, 0, 0));
-          if (p < IWP * 2) *(f32x4*)&lds[0][ky * G::ROWF + p * 4] = v;
+        for (int ky = 0; ky < K; ++ky) {
+          const int rowoff = (ky >= ky0 && ky <= ky1) ? (ry + D * ky) * d.in_w * d.in_cstore * 4 : (int)0xC0000000;
+#pragma unroll
+          for (int i = 0; i < G::NPR; ++i) v[ky][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, (int)((unsigned)poff[i] + (unsigned)rowoff), 0, 0));
         }
-      }
-      // weight fragments of the first tap row (the ring then runs one tap row ahead, across chunk boundaries)
-      constexpr int AR = 3;                      // general form: A fragments are requested AR tiles ahead
-      static_assert(ONE_MT || NSLOT % AR == 0, "A ring");
-      f32x4 Bf[NSLOT], Af[ONE_MT ? 1 : AR];
-      auto bload = [&](int i, int q, int ky) {
-        const int soff = (((q * K + ky) * K + s_kx[i]) * NTC + nt) * 1024;
-        Bf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff, 0));
-      };
 #pragma unroll
-      for (int i = 0; i < NSLOT; ++i) bload(i, 0, ky0);
-      __syncthreads();
-      int par = 0;
-      for (int q = 0; q < NC; ++q) {
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+          for (int i = 0; i < G::NPR; ++i) {
+            const int p = tid + TF_THREADS * i;
+            if (p < IWP * 2) *(f32x4*)&lds[par][ky * G::ROWF + p * 4] = v[ky][i];
+          }
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) bload(i, 0, ky0, cur.nt);
+      }
+      tf_barrier();
+      constexpr int AR = ONE_MT ? 1 : (N16 ? 4 : 3);        // A fragments are requested AR tiles ahead
+      static_assert(ONE_MT || NSLOT % AR == 0, "A ring");
+      frag Af[AR];
+      for (int q = 0; q < ((dbg_flags & 8) ? 0 : NC); ++q) {
         const bool more = q + 1 < NC;
         const char* lbase = (const char*)&lds[par][0];
         float* nbuf = &lds[par ^ 1][0];
-        // A fragments of the chunk's first tap row
-        if constexpr (ONE_MT) {
-          Af[0] = *(const f32x4*)(lbase + aoff[0] + ky0 * (G::ROWF * 4));
-        } else {
 #pragma unroll
-          for (int i = 0; i < AR; ++i) Af[i] = *(const f32x4*)(lbase + aoff[i] + ky0 * (G::ROWF * 4));
-        }
+        for (int i = 0; i < AR; ++i) Af[i] = *(const frag*)(lbase + aoff[i] + ky0 * (G::ROWF * 4));
         for (int ky = ky0; ky <= ky1; ++ky) {
           const bool lastk = ky == ky1;
-          // the tap row whose weights are requested now: the next one of this chunk, the first one of the next chunk, or (at
-          // the very end) this one again -- a harmless reload, so that the loads stay unconditional
-          const int qn = lastk ? (more ? q + 1 : q) : q;
-          const int kyn = lastk ? (more ? ky0 : ky) : ky + 1;
+          // the tap row whose weights are requested now: the next one of this chunk, the first one of the next chunk, the
+          // first one of the next task, or (at the very end) this one again -- a harmless reload: the loads stay unconditional
+          const bool to_next = lastk && !more && have_next && nxt.ky1 >= nxt.ky0;
+          const int qn = lastk ? (more ? q + 1 : (to_next ? 0 : q)) : q;
+          const int kyn = lastk ? (more ? ky0 : (to_next ? nxt.ky0 : ky)) : ky + 1;
+          const int ntn = to_next ? nxt.nt : cur.nt;
           const int kya = lastk ? ky : ky + 1;               // A comes from THIS buffer: past the last tap row, re-read it
+          // the patch row fetched during this tap row: row ky of the next chunk, or (last chunk) a row of the next task's chunk 0
+          const int nky = nxt.ky0 + (ky - ky0);
+          const bool st_next = !more && have_next && nky <= nxt.ky1;
+          const bool st = more || st_next;
+          const int srow = more ? ky : nky;
           f32x4 stage[G::NPR];
-          if (more) {
-            const int rowoff = (ry + D * ky) * d.in_w * d.in_cstore * 4;
+          if (st) {
+            const int rowoff = ((more ? ry : nxt.ry) + D * srow) * d.in_w * d.in_cstore * 4;
+            const __amdgpu_buffer_rsrc_t rs = more ? xs : xn;
 #pragma unroll
             for (int i = 0; i < G::NPR; ++i)
-              stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, poff[i] + rowoff, 32 * (q + 1), 0));
+              stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[i] + rowoff, more ? 32 * (q + 1) : 0, 0));
+          }
+          for (int rep = 1; rep < dbg_repeat; ++rep) {      // DD_DCONV_REPEAT: timing diagnostic only (results are then wrong)
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+              if constexpr (N16) {
+                acc[i] = DD_MFMA16(Af[i % AR].x, Bf[i].x, acc[i]);
+                acc[i] = DD_MFMA16(Af[i % AR].y, Bf[i].y, acc[i]);
+              } else {
+                acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
+                acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
+                acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
+                acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
           if constexpr (ONE_MT) {
-            const f32x4 An = *(const f32x4*)(lbase + aoff[0] + kya * (G::ROWF * 4));
+            const frag An = *(const frag*)(lbase + aoff[0] + kya * (G::ROWF * 4));
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) {
               acc[i] = DD_MFMA(Af[0].x, Bf[i].x, acc[i]);
               acc[i] = DD_MFMA(Af[0].y, Bf[i].y, acc[i]);
               acc[i] = DD_MFMA(Af[0].z, Bf[i].z, acc[i]);
               acc[i] = DD_MFMA(Af[0].w, Bf[i].w, acc[i]);
-              bload(i, qn, kyn);                           // in flight for the NSLOT - 1 tiles until this slot comes round again
+              bload(i, qn, kyn, ntn);                      // in flight for the NSLOT - 1 tiles until this slot comes round again
               __builtin_amdgcn_sched_barrier(0);
             }
             Af[0] = An;
           } else {
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) {
-              acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
-              acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
-              acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
-              acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
-              bload(i, qn, kyn);
-              Af[i % AR] = *(const f32x4*)(lbase + aoff[(i + AR) % NSLOT] + (i + AR < NSLOT ? ky : kya) * (G::ROWF * 4));
+              if constexpr (N16) {
+                acc[i] = DD_MFMA16(Af[i % AR].x, Bf[i].x, acc[i]);
+                acc[i] = DD_MFMA16(Af[i % AR].y, Bf[i].y, acc[i]);
+              } else {
+                acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
+                acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
+                acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
+                acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
+              }
+              bload(i, qn, kyn, ntn);
+              Af[i % AR] = *(const frag*)(lbase + aoff[(i + AR) % NSLOT] + (i + AR < NSLOT ? ky : kya) * (G::ROWF * 4));
               __builtin_amdgcn_sched_barrier(0);
             }
           }
-          if (more) {
+          if (st) {
 #pragma unroll
             for (int i = 0; i < G::NPR; ++i) {
               const int p = tid + TF_THREADS * i;
-              if (p < IWP * 2) *(f32x4*)&nbuf[ky * G::ROWF + p * 4] = stage[i];
+              if (p < IWP * 2) *(f32x4*)&nbuf[srow * G::ROWF + p * 4] = stage[i];
             }
           }
         }
-        __syncthreads();
+        tf_barrier();
         par ^= 1;
+      }
+      // lds[par] now holds what was fetched during the last chunk: the first rows of the next task's chunk 0.  Rows it has
+      // beyond this task's count (a border row followed by a fuller one) are fetched here, not overlapped.
+      fetched_next = have_next && nxt.ky1 >= nxt.ky0;
+      if (fetched_next) {
+        for (int nky = nxt.ky0 + (ky1 - ky0 + 1); nky <= nxt.ky1; ++nky) {
+          const int rowoff = (nxt.ry + D * nky) * d.in_w * d.in_cstore * 4;
+#pragma unroll
+          for (int i = 0; i < G::NPR; ++i) {
+            const int p = tid + TF_THREADS * i;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xn, poff[i] + rowoff, 0, 0));
+            if (p < IWP * 2) *(f32x4*)&lds[par][nky * G::ROWF + p * 4] = v;
+          }
+        }
       }
     }
 
-    // ---- epilogue: the K partial rows are added into one output row image at their shifts, pass kx = tap column kx
-    float* img = &lds[0][0];
-    for (int i = tid; i < (n_mt * 32 + D * (K - 1)) * (G::OPITCH / 4); i += TF_THREADS) *(f32x4*)&img[i * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    // ---- epilogue in the buffer the next task does not start from: the K partial rows are added into one output row image
+    // at their shifts, pass kx = tap column kx
+    float* img = &lds[par ^ 1][0];
+    if (!(dbg_flags & 4))
+    for (int i = tid; i < (n_mt * TW + G::HALO) * (P / 4); i += TF_THREADS) *(f32x4*)&img[i * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    tf_barrier();
+    if (!(dbg_flags & 1))
 #pragma unroll
     for (int pass = 0; pass < K; ++pass) {
-      const int shift = D * (K - 1 - pass);                // = pad_w - D*pass (the launcher checked pad_w)
+      const int shift = D * (K - 1 - pass);                  // = pad_w - D*pass (the launcher checked pad_w)
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
         if (ONE_MT ? (i == pass && s_ok[i]) : (s_ok[i] && s_kx[i] == pass)) {
           float* p0 = img + ioff[i];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) p0[((e & 3) + 8 * (e >> 2) + shift) * G::OPITCH] += acc[i][e];
+          for (int e = 0; e < NE; ++e) p0[((N16 ? e : (e & 3) + 8 * (e >> 2)) + shift) * P] += acc[i][e];
         }
       }
-      __syncthreads();
+      tf_barrier();
     }
-    // write-out: 8 lanes per pixel, 16 bytes each
-    const int base = ((oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
-    for (int i = tid; i < d.out_w * 8; i += TF_THREADS) {
-      const int px = i >> 3, c = 32 * nt + 4 * (i & 7);
-      if (c < d.cout) {
-        f32x4 v = *(const f32x4*)&img[px * G::OPITCH + 4 * (i & 7)];
-        if (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) v += *(const f32x4*)&bias[c];
-        if (epi == DD_EPI_BIAS_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    // write-out: 16 bytes per lane
+    if (!(dbg_flags & 2)) {
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
+      constexpr int LPP = N16 ? 4 : 8;                       // lanes per pixel
+      for (int i = tid; i < d.out_w * LPP; i += TF_THREADS) {
+        const int px = i / LPP, c4 = 4 * (i % LPP), c = 32 * cur.nt + c4;
+        if (c < d.cout) {
+          f32x4 v = *(const f32x4*)&img[px * P + c4];
+          if (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) v += *(const f32x4*)&bias[c];
+          if (epi == DD_EPI_BIAS_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ys,
+                                                 (base + px * d.out_cstore + c) * 4, 0, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ys,
-                                               (base + px * d.out_cstore + c) * 4, 0, 0);
       }
     }
-    __syncthreads();
+    tf_barrier();
+    prefetched = fetched_next;
+    cur = nxt;
+    t = tn;
   }
 }
 
@@ -237,21 +340,27 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   const int k = d->kh, dl = d->dil_h;
   if (d->pad_h != dl * (k - 1) || d->pad_w != dl * (k - 1)) return false;                    // the full transposed form only
   if (d->out_h < d->in_h + dl * (k - 1) || d->out_w < d->in_w + dl * (k - 1)) return false;  // every partial lands inside the row
-  if (d->cin % 8 || d->cout < 32 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
+  if (d->cin % 8 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
   if (((uintptr_t)bias & 15) != 0) return false;
+  if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;      // rejected offsets must stay rejected with a row offset added
   const int grid = dd_cu_budget_internal() & ~7;
   if (grid < 8) return false;
-  const int n_mt = (d->in_w + 31) / 32;
-#define DD_TF(KK, DD_, NS, ONE, IWP_)                                                                                          \
+  static const int dbg_repeat = getenv("DD_DCONV_REPEAT") ? atoi(getenv("DD_DCONV_REPEAT")) : 1;
+  static const int dbg_flags = getenv("DD_DCONV_TFWD_DBG") ? atoi(getenv("DD_DCONV_TFWD_DBG")) : 0;      // timing diagnostics (wrong results)
+#define DD_TF(KK, DD_, NS, MODE_, IWP_)                                                                                        \
   do {                                                                                                                         \
-    using G = TfGeom<KK, IWP_>;                                                                                                \
-    if (d->in_w > IWP_ || n_mt * 32 + DD_ * (KK - 1) > G::OWMAX || d->out_w > G::OWMAX || n_mt * KK > 8 * NS || (ONE && n_mt > 8)) return false;                    \
-    hipLaunchKernelGGL((dconv_tfwd_kernel<KK, DD_, NS, ONE, IWP_>), dim3(grid), dim3(TF_THREADS), 0, st, x, packed, bias, y,  \
-                       *d, epilogue, wp_bytes);                                                                                \
+    using G = TfGeom<KK, DD_, MODE_, IWP_>;                                                                                    \
+    const int n_mt = (d->in_w + G::TW - 1) / G::TW;                                                                            \
+    if (d->in_w > IWP_ || (n_mt * G::TW + G::HALO) * G::P > G::BUFF || d->out_w * G::P > G::BUFF || n_mt * KK > 8 * NS ||      \
+        (MODE_ == 0 && n_mt > 8))                                                                                              \
+      return false;                                                                                                            \
+    hipLaunchKernelGGL((dconv_tfwd_kernel<KK, DD_, NS, MODE_, IWP_>), dim3(grid), dim3(TF_THREADS), 0, st, x, packed, bias, y, \
+                       *d, epilogue, wp_bytes, dbg_repeat, dbg_flags);                                                                   \
     return true;                                                                                                               \
   } while (0)
-  if (k == 7 && dl == 7 && d->in_w <= 256) DD_TF(7, 7, 7, true, 256);
-  if (k == 7 && dl == 7 && d->in_w <= 320) DD_TF(7, 7, 9, false, 320);
+  if (k == 7 && dl == 7 && d->cout > 16 && d->in_w <= 256) DD_TF(7, 7, 7, 0, 256);
+  if (k == 7 && dl == 7 && d->cout > 16 && d->in_w <= 320) DD_TF(7, 7, 9, 1, 320);
+  if (k == 7 && dl == 7 && d->cout <= 16 && d->in_w <= 352) DD_TF(7, 7, 20, 2, 352);
 #undef DD_TF
   return false;
 }
