@@ -93,21 +93,18 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
   int s_kx[NSLOT];
   bool s_ok[NSLOT];
   int aoff[NSLOT];                                       // byte offset of this lane's A fragment of the slot in a patch row
-  int ioff[NSLOT];                                       // float index of accumulator element 0 of the slot in the output row image
+  int s_mt[NSLOT];                                       // (wave-uniform: scalar registers)
 #pragma unroll
   for (int i = 0; i < NSLOT; ++i) {
     const int L = ONE_MT ? wave * K + i : wave * NSLOT + i;
     s_ok[i] = L < n_mt * K;
     const int mt = s_ok[i] ? L / K : 0;
     s_kx[i] = s_ok[i] ? L - mt * K : 0;
-    if constexpr (N16) {
-      aoff[i] = ((mt * 16 + (lane & 15)) * 8 + 2 * (lane >> 4)) * 4;
-      ioff[i] = (mt * 16 + 4 * (lane >> 4)) * P + (lane & 15);
-    } else {
-      aoff[i] = ((mt * 32 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
-      ioff[i] = (mt * 32 + 4 * (lane >> 5)) * P + (lane & 31);
-    }
+    s_mt[i] = mt;
+    aoff[i] = N16 ? ((mt * 16 + (lane & 15)) * 8 + 2 * (lane >> 4)) * 4 : ((mt * 32 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
   }
+  // float index of this lane's accumulator element 0 of m-tile 0 in the output row image
+  const int ioff_lane = N16 ? 4 * (lane >> 4) * P + (lane & 15) : 4 * (lane >> 5) * P + (lane & 31);
 
   // ---- tasks of this workgroup: XCD = blockIdx % 8 owns the x-th eighth of the (image, residue, phase row, column tile) list
   const int per_x = gridDim.x >> 3;
@@ -284,41 +281,52 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
     }
 
     // ---- epilogue in the buffer the next task does not start from: the K partial rows are added into one output row image
-    // at their shifts, pass kx = tap column kx
+    // at their shifts.  Tap column K-1 (shift 0) goes first and is STORED (its tiles cover pixels [0, n_mt*TW); the HALO pixels
+    // beyond are zeroed in the same phase), the others are added in K-1 barrier-separated passes.
     float* img = &lds[par ^ 1][0];
-    if (!(dbg_flags & 4))
-    for (int i = tid; i < (n_mt * TW + G::HALO) * (P / 4); i += TF_THREADS) *(f32x4*)&img[i * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
-    tf_barrier();
-    if (!(dbg_flags & 1))
+    constexpr int LPP = N16 ? 4 : 8;                         // lanes per pixel of the write-out (16 bytes each)
+    constexpr int WIT = ((IWP + G::HALO) * LPP + TF_THREADS - 1) / TF_THREADS;      // out_w <= n_mt*TW + HALO <= IWP + HALO
+    const int c4 = 4 * (tid % LPP), cch = 32 * cur.nt + c4;  // 512 % LPP == 0: a thread always writes the same channel group
+    f32x4 bvec = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && cch < d.cout) bvec = *(const f32x4*)&bias[cch];
+    if (!(dbg_flags & 1)) {
+      if (tid < G::HALO * (P / 4)) *(f32x4*)&img[n_mt * TW * P + tid * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      static_assert(G::HALO * (P / 4) <= TF_THREADS, "one zeroing store per thread");
 #pragma unroll
-    for (int pass = 0; pass < K; ++pass) {
-      const int shift = D * (K - 1 - pass);                  // = pad_w - D*pass (the launcher checked pad_w)
+      for (int pass = K - 1; pass >= 0; --pass) {
+        const int shift = D * (K - 1 - pass);                // = pad_w - D*pass (the launcher checked pad_w)
 #pragma unroll
-      for (int i = 0; i < NSLOT; ++i) {
-        if (ONE_MT ? (i == pass && s_ok[i]) : (s_ok[i] && s_kx[i] == pass)) {
-          float* p0 = img + ioff[i];
+        for (int i = 0; i < NSLOT; ++i) {
+          if (ONE_MT ? (i == pass && s_ok[i]) : (s_ok[i] && s_kx[i] == pass)) {
+            float* p0 = img + ioff_lane + s_mt[i] * (TW * P);
 #pragma unroll
-          for (int e = 0; e < NE; ++e) p0[((N16 ? e : (e & 3) + 8 * (e >> 2)) + shift) * P] += acc[i][e];
+            for (int e = 0; e < NE; ++e) {
+              float* pe = p0 + ((N16 ? e : (e & 3) + 8 * (e >> 2)) + shift) * P;
+              if (pass == K - 1) *pe = acc[i][e]; else *pe += acc[i][e];
+            }
+          }
         }
+        tf_barrier();
       }
-      tf_barrier();
     }
-    // write-out: 16 bytes per lane
     if (!(dbg_flags & 2)) {
       const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
-      const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
-      constexpr int LPP = N16 ? 4 : 8;                       // lanes per pixel
-      for (int i = tid; i < d.out_w * LPP; i += TF_THREADS) {
-        const int px = i / LPP, c4 = 4 * (i % LPP), c = 32 * cur.nt + c4;
-        if (c < d.cout) {
-          f32x4 v = *(const f32x4*)&img[px * P + c4];
-          if (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) v += *(const f32x4*)&bias[c];
-          if (epi == DD_EPI_BIAS_RELU) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ys,
-                                                 (base + px * d.out_cstore + c) * 4, 0, 0);
+      const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff + cch;
+      f32x4 v[WIT];
+#pragma unroll
+      for (int j = 0; j < WIT; ++j) {
+        const int px = (tid + TF_THREADS * j) / LPP;
+        v[j] = px < d.out_w ? *(const f32x4*)&img[px * P + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < WIT; ++j) {
+        const int px = (tid + TF_THREADS * j) / LPP;
+        f32x4 o = v[j] + bvec;
+        if (epi == DD_EPI_BIAS_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
+        const int off = (px < d.out_w && cch < d.cout) ? (base + px * d.out_cstore) * 4 : -16;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), ys, off, 0, 0);
       }
     }
     tf_barrier();
@@ -351,7 +359,7 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   do {                                                                                                                         \
     using G = TfGeom<KK, DD_, MODE_, IWP_>;                                                                                    \
     const int n_mt = (d->in_w + G::TW - 1) / G::TW;                                                                            \
-    if (d->in_w > IWP_ || (n_mt * G::TW + G::HALO) * G::P > G::BUFF || d->out_w * G::P > G::BUFF || n_mt * KK > 8 * NS ||      \
+    if (d->in_w > IWP_ || (n_mt * G::TW + G::HALO) * G::P > G::BUFF || d->out_w > n_mt * G::TW + G::HALO || n_mt * KK > 8 * NS ||      \
         (MODE_ == 0 && n_mt > 8))                                                                                              \
       return false;                                                                                                            \
     hipLaunchKernelGGL((dconv_tfwd_kernel<KK, DD_, NS, MODE_, IWP_>), dim3(grid), dim3(TF_THREADS), 0, st, x, packed, bias, y, \
