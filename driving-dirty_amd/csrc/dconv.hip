@@ -485,13 +485,20 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
 // 8 tiles = 128 accumulator registers per wave, two ds_read_b32 per MFMA, no global operand loads in the loop.
 // Partials per workgroup, then a fixed-order fp64 second stage (deterministic).
 
+// NSETS_ = 0, "balanced": a tile count that 8 does not divide (96->64: 42) -- every wave owns OWN = PER_KY / 8 tiles over all
+// pixel pairs of the piece, the NSH = PER_KY % 8 tiles left over are SHARED: each wave multiplies them for its eighth of the
+// pixel pairs (its own partial sums, added by the second stage like those of the pixel parts).  42 tiles = 8 x 5.25: with sets
+// of 6 one wave in eight multiplied nothing useful.
 template <int K, int D, int C, int O, int XT_, int NSETS_>
 struct DwGeom {
   static constexpr int HALO = D * (K - 1);
-  static constexpr int XT = XT_, NSETS = NSETS_, PARTS = 8 / NSETS_;
+  static constexpr bool BAL = NSETS_ == 0;
+  static constexpr int XT = XT_, NSETS = BAL ? 8 : NSETS_, PARTS = 8 / NSETS;
   static constexpr int MT = (C + 31) / 32, NTO = (O + 31) / 32;
   static constexpr int PER_KY = K * MT * NTO;                       // accumulator tiles per tap row
-  static constexpr int TPW = (PER_KY + NSETS - 1) / NSETS;          // tiles per wave
+  static constexpr int OWN = BAL ? PER_KY / 8 : (PER_KY + NSETS - 1) / NSETS;      // tiles a wave owns
+  static constexpr int NSH = BAL ? PER_KY % 8 : 0;                  // shared tiles
+  static constexpr int TPW = OWN + NSH;                             // accumulator tiles per wave
   static constexpr int UNITS = XT / 2 / PARTS / 8;                  // 8-pixel-pair units per wave and step
   static constexpr int XB = XT * C;                                 // floats of the x piece
   static constexpr int GB = (XT + HALO) * O;                        // floats of the g piece
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __
   int aoff[G::TPW], boff[G::TPW];
 #pragma unroll
   for (int i = 0; i < G::TPW; ++i) {
-    const int t = set * G::TPW + i;
+    const int t = i < G::OWN ? set * G::OWN + i : 8 * G::OWN + (i - G::OWN);      // (balanced: set = wave)
     if (t < G::PER_KY) {
       const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
       aoff[i] = ((px0 + h) * C + mt * 32 + n) * 4;
@@ -594,9 +601,24 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __
       // MFMA: every MFMA exposed to the LDS latency)
       const char* lb = (const char*)&lds[par][0];
       constexpr int NP = G::UNITS * 8;
-      float av[2][G::TPW], bw[2][G::TPW];
+      float av[2][G::OWN], bw[2][G::OWN];
+      // shared tiles: this wave's eighth of the pixel pairs, all operands requested up front
+      constexpr int NSP = G::BAL ? NP / 8 : 0;
+      static_assert(!G::BAL || NP % 8 == 0, "pixel pairs of a piece split over the 8 waves");
+      float sa[NSP > 0 ? NSP : 1][G::NSH > 0 ? G::NSH : 1], sb[NSP > 0 ? NSP : 1][G::NSH > 0 ? G::NSH : 1];
+      if constexpr (G::BAL) {
+        const char* la = lb + wave * (NSP * 2 * C * 4);
+        const char* lg = lb + wave * (NSP * 2 * O * 4);
 #pragma unroll
-      for (int i = 0; i < G::TPW; ++i) {
+        for (int j = 0; j < NSP; ++j)
+#pragma unroll
+          for (int k = 0; k < G::NSH; ++k) {
+            sa[j][k] = *(const float*)(la + aoff[G::OWN + k] + j * 2 * C * 4);
+            sb[j][k] = *(const float*)(lg + boff[G::OWN + k] + j * 2 * O * 4);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < G::OWN; ++i) {
         av[0][i] = *(const float*)(lb + aoff[i]);
         bw[0][i] = *(const float*)(lb + boff[i]);
       }
@@ -604,14 +626,20 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __
       for (int pp = 0; pp < NP; ++pp) {
         if (pp + 1 < NP) {
 #pragma unroll
-          for (int i = 0; i < G::TPW; ++i) {
+          for (int i = 0; i < G::OWN; ++i) {
             av[(pp + 1) & 1][i] = *(const float*)(lb + aoff[i] + (pp + 1) * 2 * C * 4);
             bw[(pp + 1) & 1][i] = *(const float*)(lb + boff[i] + (pp + 1) * 2 * O * 4);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < G::TPW; ++i) acc[i] = DD_MFMA(av[pp & 1][i], bw[pp & 1][i], acc[i]);
+        for (int i = 0; i < G::OWN; ++i) acc[i] = DD_MFMA(av[pp & 1][i], bw[pp & 1][i], acc[i]);
+        if constexpr (G::BAL) {
+          if (pp < NSP) {      // the shared tiles' MFMAs ride along with the first pairs (their operands landed long ago)
+#pragma unroll
+            for (int k = 0; k < G::NSH; ++k) acc[G::OWN + k] = DD_MFMA(sa[pp < NSP ? pp : 0][k], sb[pp < NSP ? pp : 0][k], acc[G::OWN + k]);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -633,13 +661,20 @@ __global__ __launch_bounds__(1024) void dconv_wgrad_reduce(const float* __restri
   using G = DwGeom<K, D, C, O, XT_, NSETS_>;
   const int ky = blockIdx.x / G::PER_KY, t = blockIdx.x - ky * G::PER_KY;
   const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int set = t / G::TPW, i = t - set * G::TPW;
   double s = 0.0;
-  for (int w = 0; w < wg_per_ky; ++w)
-    for (int prt = 0; prt < G::PARTS; ++prt) {
-      const int wave = set + G::NSETS * prt;
-      s += (double)part[((((long)(ky * wg_per_ky + w) * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane];
-    }
+  if (G::BAL && t >= 8 * G::OWN) {      // a shared tile: every wave of every workgroup holds a partial sum
+    const int i = G::OWN + (t - 8 * G::OWN);
+    for (int w = 0; w < wg_per_ky; ++w)
+      for (int wave = 0; wave < 8; ++wave)
+        s += (double)part[((((long)(ky * wg_per_ky + w) * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane];
+  } else {
+    const int set = t / G::OWN, i = t - set * G::OWN;
+    for (int w = 0; w < wg_per_ky; ++w)
+      for (int prt = 0; prt < G::PARTS; ++prt) {
+        const int wave = set + G::NSETS * prt;
+        s += (double)part[((((long)(ky * wg_per_ky + w) * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane];
+      }
+  }
   const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
   const int c = mt * 32 + dd_acc_row(r, lane), o = nt * 32 + (lane & 31);
   if (c < C && o < O) {
@@ -800,11 +835,11 @@ int dw_variant(int k, int d, int c, int o) {
   return -1;
 }
 
-// (K, D, Cin, Cout, piece width, tile sets): 42 / 14 tiles per tap row -> 8 / 2 sets of <= 8 tiles; the 32->16 / 16->8 layers run
+// (K, D, Cin, Cout, piece width, tile sets): 42 tiles per tap row -> balanced (0: 5 own + 2 shared per wave), 14 -> 2 sets of 7; the 32->16 / 16->8 layers run
 // on the 16-wide kernel (F16: piece width = a divisor of the layer's input width where there is one)
 #define DD_DW_DISPATCH(V, F, F16)                 \
   switch (V) {                                    \
-    case 0: F(7, 7, 96, 64, 64, 8); break;        \
+    case 0: F(7, 7, 96, 64, 64, 0); break;        \
     case 1: F(7, 7, 64, 32, 128, 2); break;       \
     case 2: F16(7, 7, 32, 16, 68); break;         \
     case 3: F16(7, 3, 16, 8, 64); break;          \
