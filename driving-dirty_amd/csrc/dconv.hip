@@ -840,7 +840,7 @@ int dw_variant(int k, int d, int c, int o) {
 #define DD_DW_DISPATCH(V, F, F16)                 \
   switch (V) {                                    \
     case 0: F(7, 7, 96, 64, 64, 0); break;        \
-    case 1: F(7, 7, 64, 32, 128, 2); break;       \
+    case 1: F(7, 7, 64, 32, 64, 2); break;        \
     case 2: F16(7, 7, 32, 16, 68); break;         \
     case 3: F16(7, 3, 16, 8, 64); break;          \
     case 4: F(8, 8, 64, 32, 128, 2); break;       \
