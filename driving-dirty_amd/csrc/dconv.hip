@@ -453,6 +453,11 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
     DD_LAUNCH_CHECK("dconv_tfwd");
     return 0;
   }
+  // the data gradient of the 96->64 / 64->32 layers: one output row per workgroup, unrolled tap columns (dconv_t.hip)
+  if (dd_dconv_gfwd_launch(x, packed, bias, mask, y, d, epilogue, wp_bytes, st)) {
+    DD_LAUNCH_CHECK("dconv_gfwd");
+    return 0;
+  }
   const DcPlan plan = dc_plan(*d, d->dil_h);
   const int grid = (int)max(1, min(dd_cu_budget_internal(), plan.total));      // one 8-wave workgroup per CU, all resident
 #define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes, dbg_repeat)

@@ -336,6 +336,197 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
   }
 }
 
+
+// =====================================================================================================================
+// The DATA GRADIENT of the same layers (a plain dilated convolution: pad 0, out = in - d(k-1), every tap valid), one output
+// row per workgroup like the forward above: no row-group quantisation, and a tap loop without iterators -- tap columns
+// unrolled, one ds_read_b128 and NTC weight loads per 4*NTC MFMAs, each requested a whole tap row ahead into the registers
+// the tap's MFMAs have just read (the tap loop of dconv_fwd_kernel spends 17 % of its issue slots on its (ky, kx) iterator,
+// operand addresses and waits: T(r) = r*9.8 + 0.45 ms against 8.4 ms of MFMAs for up_conv_1).
+//   wave w owns m-tile w (32 output pixels) x all NTC column tiles: rows of at most 8 m-tiles (up_conv_1: 256).  Wider rows
+//   (up_conv_2: 298 -> 10 m-tiles) stay on dconv_fwd_kernel: dealing the two extra m-tiles to the 8 waves as tap-split shared
+//   tiles was tried and measured slower (5.19 against 5.02 ms: registers spilled inside the tap loop).
+template <int K, int D, int NTC, int IWP>
+__global__ __launch_bounds__(TF_THREADS) void dconv_gfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, const float* __restrict__ msk,
+                                                                float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
+  using G = TfGeom<K, D, 1, IWP>;
+  constexpr int T = K * K;
+  __shared__ __attribute__((aligned(16))) float lds[2][G::BUFF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, n = lane & 31;
+  const int NC = d.cin >> 3;
+  const int rows_max = (d.out_h + D - 1) / D;
+  const int n_mt = (d.out_w + 31) >> 5;
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+  const __amdgpu_buffer_rsrc_t ws = dd_rsrc(wp, wp_bytes);
+
+  int poff[G::NPR];
+#pragma unroll
+  for (int i = 0; i < G::NPR; ++i) {
+    const int p = tid + TF_THREADS * i;
+    poff[i] = (p >> 1) < d.in_w ? ((p >> 1) * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : (int)0xC0000000;
+  }
+  const int aoff_own = ((wave * 32 + n) * 8 + 4 * h) * 4;
+
+  float bv[NTC];
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) {
+    const int ch = nt * 32 + n;
+    bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && ch < d.cout) ? bias[ch] : 0.f;
+  }
+
+  const int per_x = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int per_img = D * rows_max;
+  const long len = (long)d.batch * per_img;
+  const long seg1 = len * (xcd + 1) / 8;
+  auto decode = [&](long t, int& b, int& oy) -> bool {
+    b = (int)(t / per_img);
+    const int rem = (int)(t - (long)b * per_img);
+    const int r = rem / rows_max, jy = rem - r * rows_max;
+    oy = r + D * jy;
+    return oy < d.out_h;
+  };
+  auto next_task = [&](long t, int& b, int& oy) -> long {
+    while (t < seg1 && !decode(t, b, oy)) t += per_x;
+    return t < seg1 ? t : seg1;
+  };
+
+  f32x4 Bf[K][NTC], Aown[K];
+  auto bload = [&](int kx, int q, int ky) {
+    const int soff = ((q * T + ky * K + kx) * NTC) * 1024;
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+      Bf[kx][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff + nt * 1024, 0));
+  };
+
+  int cb, coy, nb, noy;
+  long t = next_task(len * xcd / 8 + (blockIdx.x >> 3), cb, coy);
+  bool prefetched = false;
+  int par = 0;
+  while (t < seg1) {
+    const long tn = next_task(t + per_x, nb, noy);
+    const bool have_next = tn < seg1;
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)cb * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    const __amdgpu_buffer_rsrc_t xn = dd_rsrc(x + (long)nb * d.in_h * d.in_w * d.in_cstore, have_next ? in_bytes : 0);
+
+    f32x16 acc[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    if (!prefetched) {
+      f32x4 v[K][G::NPR];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int rowoff = (coy + D * ky) * d.in_w * d.in_cstore * 4;
+#pragma unroll
+        for (int i = 0; i < G::NPR; ++i) v[ky][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, poff[i] + rowoff, 0, 0));
+      }
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int i = 0; i < G::NPR; ++i) {
+          const int p = tid + TF_THREADS * i;
+          if (p < IWP * 2) *(f32x4*)&lds[par][ky * G::ROWF + p * 4] = v[ky][i];
+        }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) bload(kx, 0, 0);
+    }
+    tf_barrier();
+    for (int q = 0; q < NC; ++q) {
+      const bool more = q + 1 < NC;
+      const char* lbase = (const char*)&lds[par][0];
+      float* nbuf = &lds[par ^ 1][0];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) Aown[kx] = *(const f32x4*)(lbase + aoff_own + kx * D * 32);
+      for (int ky = 0; ky < K; ++ky) {
+        const bool lastk = ky == K - 1;
+        const bool to_next = lastk && !more && have_next;
+        const int qn = lastk ? (more ? q + 1 : (to_next ? 0 : q)) : q;
+        const int kyn = lastk ? ((more || to_next) ? 0 : ky) : ky + 1;
+        const int kya = lastk ? ky : ky + 1;
+        const bool st = more || have_next;
+        f32x4 stage[G::NPR];
+        if (st) {
+          const int rowoff = ((more ? coy : noy) + D * ky) * d.in_w * d.in_cstore * 4;
+          const __amdgpu_buffer_rsrc_t rs = more ? xs : xn;
+#pragma unroll
+          for (int i = 0; i < G::NPR; ++i)
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[i] + rowoff, more ? 32 * (q + 1) : 0, 0));
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int nt = 0; nt < NTC; ++nt) {
+            acc[nt] = DD_MFMA(Aown[kx].x, Bf[kx][nt].x, acc[nt]);
+            acc[nt] = DD_MFMA(Aown[kx].y, Bf[kx][nt].y, acc[nt]);
+            acc[nt] = DD_MFMA(Aown[kx].z, Bf[kx][nt].z, acc[nt]);
+            acc[nt] = DD_MFMA(Aown[kx].w, Bf[kx][nt].w, acc[nt]);
+          }
+          bload(kx, qn, kyn);
+          Aown[kx] = *(const f32x4*)(lbase + aoff_own + kya * (G::ROWF * 4) + kx * D * 32);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st) {
+#pragma unroll
+          for (int i = 0; i < G::NPR; ++i) {
+            const int p = tid + TF_THREADS * i;
+            if (p < IWP * 2) *(f32x4*)&nbuf[ky * G::ROWF + p * 4] = stage[i];
+          }
+        }
+      }
+      tf_barrier();
+      par ^= 1;
+    }
+
+    // ---- write-out (as in dconv_fwd_kernel: all mask values of a tile requested before the first is used)
+    {
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cb * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)cb * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+      const bool masked = epi == DD_EPI_RELU_MASK;
+      const int base = ((coy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
+      auto put = [&](const f32x16& a, int mt, int nt, float bvn, bool on) {
+        const int ch = nt * 32 + n;
+        const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+        int off[16];
+        float mv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int xo = mt * 32 + dd_acc_row(r, lane);
+          const bool ok = on && xo < d.out_w && ch < d.cout;
+          off[r] = ok ? (base + xo * d.out_cstore + ch) * 4 : -16;
+          mv[r] = 1.f;
+        }
+        if (masked) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float m = dd_bload1(ms, pass ? -16 : off[r]);
+            mv[r] = pass ? 1.f : m;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = a[r] + bvn;
+          if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          v = mv[r] > 0.f ? v : 0.f;
+          dd_bstore1(ys, off[r], v);
+        }
+      };
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) put(acc[nt], wave, nt, bv[nt], wave < n_mt);
+    }
+    tf_barrier();
+    prefetched = have_next;
+    cb = nb; coy = noy;
+    t = tn;
+  }
+}
+
 }  // namespace
 
 // Launches the input-aligned forward if the layer is one it is built for; returns false (nothing launched) otherwise.
@@ -370,5 +561,28 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   if (k == 7 && dl == 7 && d->cout > 16 && d->in_w <= 320) DD_TF(7, 7, 9, 1, 320);
   if (k == 7 && dl == 7 && d->cout <= 16 && d->in_w <= 352) DD_TF(7, 7, 20, 2, 352);
 #undef DD_TF
+  return false;
+}
+
+// The same for the data gradient (gather form, pad 0): false = not one of its layers, nothing launched.
+bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                          int epilogue, int wp_bytes, hipStream_t st) {
+  static const bool off = getenv("DD_DCONV_GFWD_OFF") && atoi(getenv("DD_DCONV_GFWD_OFF")) != 0;
+  if (off) return false;
+  if (d->kh != d->kw || d->dil_h != d->dil_w || d->pad_h != 0 || d->pad_w != 0) return false;
+  const int k = d->kh, dl = d->dil_h, halo = dl * (k - 1);
+  if (d->out_h > d->in_h - halo || d->out_w > d->in_w - halo || d->cin % 8) return false;
+  if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;
+  const int grid = dd_cu_budget_internal() & ~7;
+  if (grid < 8) return false;
+  const int n_mt = (d->out_w + 31) / 32, ntc = (d->cout + 31) / 32;
+#define DD_GF(KK, DD_, NTC_, IWP_)                                                                                             \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL((dconv_gfwd_kernel<KK, DD_, NTC_, IWP_>), dim3(grid), dim3(TF_THREADS), 0, st, x, packed, bias,        \
+                       mask, y, *d, epilogue, wp_bytes);                                                                       \
+    return true;                                                                                                               \
+  } while (0)
+  if (k == 7 && dl == 7 && ntc == 3 && n_mt <= 8 && d->in_w <= 320) DD_GF(7, 7, 3, 320);
+#undef DD_GF
   return false;
 }

@@ -61,3 +61,5 @@ __device__ __forceinline__ void dd_range(long total, int i, int n, long& idx, lo
 // dconv_t.hip: the input-aligned forward of the dilated transposed layers; false = not one of its layers, nothing launched.
 bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias, float* y, const dd_gconv_desc* d, int epilogue,
                           int wp_bytes, hipStream_t st);
+bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                          int epilogue, int wp_bytes, hipStream_t st);
