@@ -163,6 +163,31 @@ def test_dilated_kernel_slices_mask_pass_and_generic_engine_agree(dev):
     assert float(dx1[..., 32:64][neg[..., 32:64]].abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("cin,cout,w", [(96, 64, 256), (64, 32, 298), (32, 16, 340)])
+def test_row_kernels_are_deterministic(dev, cin, cout, w):
+    """The input-aligned forward adds its k partial rows in barrier-separated passes, the balanced weight gradient sums its
+    shared-tile partials in a fixed-order second stage, the row-per-workgroup data gradient has no cross-wave sums at all:
+    two launches on the same operands must agree bit for bit."""
+    from driving_dirty_amd import gconv
+    mod = synth.fill_module(nn.ConvTranspose2d(cin, cout, 7, dilation=7), seed=5)
+    wd, bd = mod.weight.detach().to(dev), mod.bias.detach().to(dev)
+    layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+    b, h = 2, 16
+    oh, ow = layer.out_hw(h, w)
+    x = hu((b, h, w, cin), "detx").to(dev)
+    g = hu((b, oh, ow, cout), "detg").to(dev)
+    outs = []
+    for _ in range(2):
+        y = torch.empty(b, oh, ow, cout, device=dev)
+        layer.forward(wd, bd, gconv.View(x), gconv.View(y), gconv.EPI_BIAS_RELU)
+        dx = torch.empty(b, h, w, cin, device=dev)
+        layer.backward_data(wd, gconv.View(g), gconv.View(dx), relu_src=x)
+        dw, db = layer.backward_weight(gconv.View(x), gconv.View(g))
+        outs.append((y, dx, dw.clone(), db.clone()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("view,tf", [(3, 0), (4, 1), (1, 2), (5, 3)])
 def test_view_transform(dev, view, tf):
     from driving_dirty_amd import gconv
