@@ -696,7 +696,11 @@ template <int K, int D, int C, int O, int XT_>
 struct Dw16Geom {
   static constexpr int HALO = D * (K - 1), XT = XT_;
   static constexpr int MT = (C + 15) / 16, NTO = (O + 15) / 16;
-  static constexpr int TPW = K * MT * NTO;                          // tiles of one tap row = tiles per wave
+  // Cout <= 8 would leave half of every 16-wide column tile empty: two tap columns share a tile -- column n < 8 is
+  // (kx = 2p, o = n), column n >= 8 is (kx = 2p + 1, o = n - 8); the B operand is a per-lane LDS address either way
+  static constexpr bool PAIR = O <= 8;
+  static constexpr int KXT = PAIR ? (K + 1) / 2 : K;               // column-tile groups along kx
+  static constexpr int TPW = KXT * MT * NTO;                        // tiles of one tap row = tiles per wave
   static constexpr int XB = XT * C, GB = (XT + HALO) * O;
   static constexpr int BUF = XB + K * GB + 64;
   static constexpr int NPIECE = (BUF / 4 + DC_THREADS - 1) / DC_THREADS;
@@ -720,7 +724,8 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad16_kernel(const float* 
   const int nxt = (W + G::XT - 1) / G::XT;
   const long nsteps = (r1 - r0) * nxt;
   const int abase = (q4 * C + m) * 4;                                               // + mt*64 + quad*4*C*4
-  const int bbase = (G::XB + ky * G::GB + q4 * O + m) * 4;                          // + (kx*D*O + nt*16)*4 + quad*4*O*4
+  const int bbase = G::PAIR ? (G::XB + ky * G::GB + (q4 + (m >> 3) * D) * O + (m & 7)) * 4      // + (2p*D*O)*4 + quad*4*O*4
+                            : (G::XB + ky * G::GB + q4 * O + m) * 4;                          // + (kx*D*O + nt*16)*4 + quad*4*O*4
 
   f32x4 acc[G::TPW];
 #pragma unroll
@@ -778,15 +783,15 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad16_kernel(const float* 
     if (more) issue(s + 1, st);
     if (active) {
       const char* lb = (const char*)&lds[par][0];
-      float av[2][G::MT], bw[2][K * G::NTO];
+      float av[2][G::MT], bw[2][G::KXT * G::NTO];
       auto ld = [&](int slot, int quad) {
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt) av[slot][mt] = *(const float*)(lb + abase + (quad * 4 * C + mt * 16) * 4);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx)
+        for (int kx = 0; kx < G::KXT; ++kx)
 #pragma unroll
           for (int nt = 0; nt < G::NTO; ++nt)
-            bw[slot][kx * G::NTO + nt] = *(const float*)(lb + bbase + ((quad * 4 + kx * D) * O + nt * 16) * 4);
+            bw[slot][kx * G::NTO + nt] = *(const float*)(lb + bbase + ((quad * 4 + (G::PAIR ? 2 * kx : kx) * D) * O + nt * 16) * 4);
       };
       ld(0, 0);
 #pragma unroll
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad16_kernel(const float* 
         if (quad + 1 < G::NQ) ld((quad + 1) & 1, quad + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx)
+        for (int kx = 0; kx < G::KXT; ++kx)
 #pragma unroll
           for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
@@ -823,9 +828,11 @@ __global__ __launch_bounds__(256) void dconv_wgrad16_reduce(const float* __restr
   const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0.0;
   for (int w = 0; w < nwg; ++w) s += (double)part[((((long)w * K + ky) * G::TPW + t) * 4 + r) * 64 + lane];
-  const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
-  const int c = mt * 16 + 4 * (lane >> 4) + r, o = nt * 16 + (lane & 15);      // D[row = 4*(lane >> 4) + r][col = lane & 15]
-  if (c < C && o < O) {
+  const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT;
+  const int kx = G::PAIR ? 2 * (t / (G::NTO * G::MT)) + ((lane & 15) >> 3) : t / (G::NTO * G::MT);
+  const int c = mt * 16 + 4 * (lane >> 4) + r;                                  // D[row = 4*(lane >> 4) + r][col = lane & 15]
+  const int o = G::PAIR ? (lane & 7) : nt * 16 + (lane & 15);
+  if (c < C && o < O && kx < K) {
     const long wi = (((long)c * O + o) * K + ky) * K + kx;
     dw[wi] = accumulate ? dw[wi] + (float)s : (float)s;
   }
