@@ -22,4 +22,4 @@ python3 tools/pmc_sq.py gpurun_out/${R}_upconv_sq_counters.json $O/up_sq > $O/up
 python3 tools/pmc_traffic.py $O/fetch $O/write gpurun_out/${R}_c2_fwd_traffic.json > $O/traffic_fwd.log 2>&1
 python3 tools/pmc_traffic.py $O/fetch $O/write gpurun_out/${R}_c2_dgrad_w1_traffic.json dgrad_w1 > $O/traffic_dg.log 2>&1
 cp profiles/${R}_bench_kernel_stats.csv profiles/${R}_bbox_bs32_kernel_stats.csv gpurun_out/ 2>/dev/null
-tail -2 $O/*_sum.log $O/traffic_*.log
+for f in $O/*_sum.log $O/traffic_*.log; do tail -n 2 $f; done
