@@ -60,6 +60,10 @@ CASES = [
     ("up1_full_width", lambda: nn.ConvTranspose2d(96, 64, 7, dilation=7), (2, 96, 9, 256)),      # the input-aligned forward, 8 m-tiles
     ("up1_ragged_250", lambda: nn.ConvTranspose2d(96, 64, 7, dilation=7), (1, 96, 5, 250)),      # ... last m-tile 26 pixels
     ("up2_full_width", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (2, 64, 9, 298)),      # ... 70 tiles over 8 waves
+    ("up2_257_nine_tiles", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (1, 64, 3, 257)),  # ... 63 tiles, one pixel in the last m-tile
+    ("up2_320_ten_full", lambda: nn.ConvTranspose2d(64, 64, 7, dilation=7), (1, 64, 2, 320)),     # ... widest row, two column tiles
+    ("up3_352_widest", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 2, 352)),
+    ("up3_17_two_tiles", lambda: nn.ConvTranspose2d(32, 8, 7, dilation=7), (1, 32, 8, 17)),       # Cout 8 on the 16-wide form
     ("up3_full_width", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 9, 340)),      # ... 16-wide tiles, 154 over 8 waves
     ("up2_wide_2img", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (2, 64, 40, 100)),
     ("up3_tall", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 70, 30)),
