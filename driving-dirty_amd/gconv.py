@@ -88,6 +88,9 @@ def _fwd(x, packed, bias, mask, y, d, epi):
 # The dilated stride-1 layers (the box heads' up-convs) have their own phase-decomposed, LDS-staged kernel (csrc/dconv.hip);
 # DD_DCONV=0 routes them through the generic gather engine again (A/B knob, same results up to summation order).
 DCONV = os.environ.get("DD_DCONV", "1") != "0"
+# Data gradient of strided Conv2d layers by input phase (Layer._backward_data_phased); DD_PHASED_DGRAD=0: the gather with a
+# divisibility test per tap again (A/B knob).
+PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
 
 
 def _dconv_ok(d):
@@ -171,6 +174,9 @@ class Layer:
             if _dconv_ok(d):
                 _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout)
                 return
+        if (not self.transposed and self.stride != (1, 1) and self.dil == (1, 1) and self.pad == (0, 0) and cin_out <= 64
+                and PHASED_DGRAD):
+            return self._backward_data_phased(weight, ddst, dsrc, relu_src, mask_pass, epi, cos)
         for n0 in range(0, cin_out, 64):                    # the generic kernel writes at most 64 channels per launch
             nn = min(64, cin_out - n0)
             out = View(dsrc.buf, dsrc.coff + n0, nn, dsrc.off_h, dsrc.off_w, dsrc.h, dsrc.w)
@@ -188,6 +194,32 @@ class Layer:
                 d = _desc(b, ddst, out, cos, nn, self.k, (1, 1), self.dil, self.pad, mask_pass=mask_pass)
                 pk = _pack(weight, d, n0 * self.cout * self.T, self.cout * self.T, self.T, False, nn, self.cout)
             _fwd(ddst.buf, pk, None, msk, out.buf, d, epi)
+
+    def _backward_data_phased(self, weight, ddst, dsrc, relu_src, mask_pass, epi, cos):
+        """Data gradient of a strided Conv2d (no padding, no dilation) by input phase: input pixels of equal residue
+        (iy mod sh, ix mod sw) = (ry, rx) only ever meet the taps ky = ry + sh*jy, kx = rx + sw*jx, so
+            dx[sh*my + ry, sw*mx + rx] = sum_j g[my - jy, mx - jx] * w[ry + sh*jy, rx + sw*jx]
+        is a stride-1 transposed convolution of g with the (ry, rx) sub-kernel, written at output stride (sh, sw), offset
+        (ry, rx).  The gather with a divisibility test visits all kh*kw taps for every pixel (ss_conv, k 1x24 stride 7: 24 taps
+        for the 3.4 that contribute -- 3.6 ms at bs 32); the sh*sw phase launches do exactly the useful work (0.5 ms)."""
+        b = ddst.buf.shape[0]
+        sh, sw = self.stride
+        for ry in range(min(sh, self.k[0])):
+            for rx in range(min(sw, self.k[1])):
+                sub = weight[:, :, ry::sh, rx::sw].contiguous()                  # [cout, cin, njy, njx]
+                njy, njx = sub.shape[2:]
+                t = njy * njx
+                mh, mw = (dsrc.h - ry + sh - 1) // sh, (dsrc.w - rx + sw - 1) // sw      # pixels of this phase
+                out = View(dsrc.buf, dsrc.coff, self.cin, dsrc.off_h, dsrc.off_w, dsrc.h, dsrc.w)
+                d = _desc(b, ddst, out, cos, self.cin, (njy, njx), (1, 1), (1, 1), (njy - 1, njx - 1), out_hw=(mh, mw),
+                          ostride=(sh, sw), ooff=(ry, rx), mask_pass=mask_pass)
+                pk = _pack(sub, d, 0, t, self.cin * t, True, self.cin, self.cout)
+                _fwd(ddst.buf, pk, None, relu_src, out.buf, d, epi)
+        # phases past the kernel extent (stride > kernel) receive no gradient
+        for ry in range(sh):
+            for rx in range(sw):
+                if ry >= self.k[0] or rx >= self.k[1]:
+                    dsrc.buf[:, dsrc.off_h + ry:dsrc.off_h + dsrc.h:sh, dsrc.off_w + rx:dsrc.off_w + dsrc.w:sw, dsrc.coff:dsrc.coff + self.cin] = 0
 
     # ---- weight (+bias) gradient
     def backward_weight(self, src, ddst, want_bias=True):
