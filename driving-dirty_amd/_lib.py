@@ -46,6 +46,7 @@ SIGNATURES = {
     "dd_boxes_to_binary_map": (_i32, [_p, _i32, _p, _p, _i32, _p]),
     "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_subsample_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_nhwc_to_nchw": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_conv_packed_floats": (_i64, [_DP, _i32]),
     "dd_conv_pack": (_i32, [_p, _p, _DP, _i32, _p]),

@@ -283,6 +283,22 @@ __global__ __launch_bounds__(256) void pool4_bwd_any(const float* __restrict__ d
 
 int grid_for(long n) { return (int)min((n + 255) / 256, (long)DD_NUM_CU * 8); }
 
+// dst[b][u][v] = (src[b][stride*u + offset][stride*v + offset], 0, 0, 0), zero outside the image: the pixels a strided, equally
+// dilated, single-channel convolution ever reads (rm_conv_1: k7 stride 3 dilation 3 pad 1 touches only rows / columns
+// 3u - 1), as an NHWC4 image on which that convolution is dense
+__global__ __launch_bounds__(256) void subsample_nhwc4_kernel(const float* __restrict__ src, f32x4* __restrict__ dst, int h, int w,
+                                                              int oh, int ow, int stride, int offset, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int v = (int)(i % ow);
+  const long r = i / ow;
+  const int u = (int)(r % oh), b = (int)(r / oh);
+  const int y = stride * u + offset, x = stride * v + offset;
+  float val = 0.f;
+  if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) val = src[((long)b * h + y) * w + x];
+  dst[i] = f32x4{val, 0.f, 0.f, 0.f};
+}
+
 }  // namespace
 
 extern "C" {
@@ -321,6 +337,16 @@ int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch,
   hipLaunchKernelGGL(stitch6_u8_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, frames, (f32x4*)wide_nhwc4,
                      batch, height, width);
   DD_LAUNCH_CHECK("stitch6_u8");
+  return 0;
+}
+
+int dd_subsample_nhwc4(const float* src, float* dst, int32_t batch, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t stride,
+                       int32_t offset, void* stream) {
+  DD_REQUIRE(src && dst && batch > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && stride > 0, DD_ERR_BAD_ARG, "subsample_nhwc4: bad argument");
+  const long total = (long)batch * oh * ow;
+  hipLaunchKernelGGL(subsample_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (f32x4*)dst, h, w,
+                     oh, ow, stride, offset, total);
+  DD_LAUNCH_CHECK("subsample_nhwc4");
   return 0;
 }
 

@@ -150,10 +150,19 @@ class SpatialMapFn(torch.autograd.Function):
         return (None, *flat)
 
 
+def road_map_taps(rm):
+    """rm [B,1,H,W] -> the NHWC4 image of the pixels rm_conv_1 (k7, stride 3, dilation 3, padding 1: components.py:80) reads,
+    (3u - 1, 3v - 1) for u, v in [0, out + 6): on it the layer is a dense 7x7 convolution with the same products in the same
+    order, and neither the forward nor the weight gradient gathers from a 16-byte-per-pixel copy of the full mask."""
+    oh, ow = MergeFn.RM1.out_hw(rm.shape[-2], rm.shape[-1])
+    return ops.subsample_nhwc4(rm, 3, -1, oh + 6, ow + 6)
+
+
 # ------------------------------------------------------------------------------------------------ merging heads
 class MergeFn(torch.autograd.Function):
-    """ssr [B,128,918,32], spatial map [B,256,256,32] (both NHWC) and, for the road-map variant, rm [B,800,800,4]
-    (NHWC4 of the 1-channel mask) -> box-mask probabilities [B,800,800].
+    """ssr [B,128,918,32], spatial map [B,256,256,32] (both NHWC) and, for the road-map variant, rm4 [B,268,268,4]
+    (``road_map_taps``: the pixels (3u - 1, 3v - 1) of the 1-channel mask that rm_conv_1 reads, NHWC4) -> box-mask
+    probabilities [B,800,800].
 
     The channel concat (components.py:109,159) is a 64- or 96-channel NHWC buffer that ss_deconv and rm_conv_2
     write by channel slice; up_conv_N run as flipped-tap dilated gathers; the last ConvTranspose2d(8->1,k2,s2)+sigmoid
@@ -161,7 +170,8 @@ class MergeFn(torch.autograd.Function):
 
     SS_CONV = Layer(32, 32, (1, 24), stride=(1, 7))
     SS_DECONV = Layer(32, 32, 2, stride=2, transposed=True)
-    RM1 = Layer(1, 32, 7, stride=3, dil=3, pad=1)
+    RM1 = Layer(1, 32, 7, stride=3, dil=3, pad=1)       # rm_conv_1 as the reference states it (shapes) ...
+    RM1S = Layer(1, 32, 7)                              # ... and as it runs: dense, on the road map's pixels (3u - 1, 3v - 1)
     RM2 = Layer(32, 32, 3, dil=3)
     UPS_RM = (Layer(96, 64, 7, dil=7, transposed=True), Layer(64, 32, 7, dil=7, transposed=True),
               Layer(32, 16, 7, dil=7, transposed=True), Layer(16, 8, 7, dil=3, transposed=True))
@@ -189,9 +199,9 @@ class MergeFn(torch.autograd.Function):
         cat[..., 32:64].copy_(space)
         r1 = None
         if with_rm:
-            rh, rw = cls.RM1.out_hw(rm4.shape[1], rm4.shape[2])
+            rh, rw = cls.RM1S.out_hw(rm4.shape[1], rm4.shape[2])
             r1 = _empty((b, rh, rw, 32), dev)
-            cls.RM1.forward(p_rm1[0], p_rm1[1], View(rm4), View(r1), EPI_BIAS_RELU)
+            cls.RM1S.forward(p_rm1[0], p_rm1[1], View(rm4), View(r1), EPI_BIAS_RELU)
             assert cls.RM2.out_hw(rh, rw) == (ch, cw)
             cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
         acts = [cat]
@@ -247,7 +257,7 @@ class MergeFn(torch.autograd.Function):
             g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))
             gr1 = _empty(r1.shape, dev)
             cls.RM2.backward_data(w_rm2, View(gcat, 64, 32), View(gr1), relu_src=r1)
-            g_rm1 = cls.RM1.backward_weight(View(rm4), View(gr1))
+            g_rm1 = cls.RM1S.backward_weight(View(rm4), View(gr1))
         g_ssd = cls.SS_DECONV.backward_weight(View(s1), View(gcat, 0, 32))
         gs1 = _empty(s1.shape, dev)
         cls.SS_DECONV.backward_data(w_ssd, View(gcat, 0, 32), View(gs1), relu_src=s1)

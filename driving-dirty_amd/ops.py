@@ -127,6 +127,16 @@ def nchw_to_nhwc(x, c_store):
     return out
 
 
+def subsample_nhwc4(x, stride, offset, oh, ow):
+    """x [B,1,H,W] or [B,H,W] -> [B,oh,ow,4] with channel 0 = x[stride*u + offset, stride*v + offset] (zero outside)."""
+    _dev(x, "x")
+    b, h, w = x.shape[0], x.shape[-2], x.shape[-1]
+    assert x.numel() == b * h * w, "subsample_nhwc4: one channel"
+    out = torch.empty((b, oh, ow, 4), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_subsample_nhwc4(_p(x.contiguous()), _p(out), b, h, w, oh, ow, stride, offset, _stream()), "dd_subsample_nhwc4")
+    return out
+
+
 def nhwc_to_nchw(x, c):
     b, h, w, cs = x.shape
     _dev(x, "x")

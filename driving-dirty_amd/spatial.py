@@ -11,7 +11,7 @@ from torch import nn
 
 from . import ops
 from .autoencoder import BasicAE
-from .heads import MergeFn, SpatialMapFn, _ORDER, as_nhwc
+from .heads import MergeFn, SpatialMapFn, _ORDER, as_nhwc, road_map_taps
 from .lightning import LightningModule, hparam, pretrained_ae
 
 
@@ -54,7 +54,7 @@ class _Merging(nn.Module):
     def _run(self, ssr, spatial_map, rm):
         _gpu(ssr, type(self).__name__)
         names = ["ss_conv", "ss_deconv"] + (["rm_conv_1", "rm_conv_2"] if self.with_rm else []) + self.up_names
-        rm4 = ops.nchw_to_nhwc(rm.contiguous(), 4) if self.with_rm else None
+        rm4 = road_map_taps(rm) if self.with_rm else None
         probs = MergeFn.apply(as_nhwc(ssr, 32), as_nhwc(spatial_map, 32), rm4, self.with_rm, *self._params(names))
         return probs.unsqueeze(1)                        # [B,1,800,800] like the reference
 

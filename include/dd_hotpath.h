@@ -353,6 +353,12 @@ int dd_deconv2x2_c1_bwd(const float* x, const float* wt, const float* probs, con
  * 2 = rot90(k=1, dims [3,2]) (view 1, "f"), 3 = flip([2,3]) (views 5 and 2).  Rotations swap H and W. */
 int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t height, int32_t width, int32_t view,
                      int32_t transform, void* stream);
+/* rm_conv_1 (spatial_bb/components.py:80, Conv2d(1, 32, 7, stride=3, dilation=3, padding=1)) reads only the road-map pixels
+ * (3u - 1, 3v - 1): dst[b][u][v] = (src[b][stride*u + offset][stride*v + offset], 0, 0, 0) (zero outside the image) is the
+ * NHWC4 image on which the same taps form a DENSE k x k convolution -- same products, same order, 1/9 of the bytes.
+ * src [batch,h,w] (one channel), dst [batch,oh,ow,4]. */
+int dd_subsample_nhwc4(const float* src, float* dst, int32_t batch, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                       int32_t stride, int32_t offset, void* stream);
 /* out[i] = a[i] + b[i] (gradient fan-in of the shared views / feature), n % 4 == 0. */
 int dd_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* Mean binary cross-entropy on PROBABILITIES (spatial_w_rm.py:131 F.binary_cross_entropy; log clamped at -100 like

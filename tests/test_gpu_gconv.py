@@ -227,3 +227,28 @@ def test_channel_sum(dev, shape, coff, chans):
     twice = torch.empty_like(out)
     gconv.channel_sum(gconv.View(buf, coff, chans), twice)
     assert torch.equal(again, twice)            # fixed summation order
+
+
+def test_road_map_taps_make_rm_conv_1_dense(dev):
+    """dd_subsample_nhwc4 + a dense 7x7 convolution = Conv2d(1, 32, 7, stride=3, dilation=3, padding=1) (components.py:80): the
+    subsampled image holds exactly the pixels (3u - 1, 3v - 1); forward and weight gradient against fp64 torch on the
+    original layer."""
+    from driving_dirty_amd import gconv, ops
+    from driving_dirty_amd.heads import MergeFn, road_map_taps
+    mod = synth.fill_module(nn.Conv2d(1, 32, 7, stride=3, dilation=3, padding=1), seed=9).double()
+    rm = (hu((2, 1, 101, 95), "rmt", 0.0, 1.0) < 0.4).float()
+    x = rm.double()
+    y_ref = F.relu(mod(x))
+    gy = hu(tuple(y_ref.shape), "rmg").double() * (y_ref > 0)
+    (y_ref * gy).sum().backward()
+    taps = road_map_taps(rm.to(dev))
+    oh, ow = MergeFn.RM1.out_hw(101, 95)
+    assert tuple(taps.shape) == (2, oh + 6, ow + 6, 4)
+    ref = F.pad(rm, (1, 3 * (ow + 5) - 95, 1, 3 * (oh + 5) - 101))[:, 0, ::3, ::3][:, :oh + 6, :ow + 6]
+    assert torch.equal(taps[..., 0].cpu(), ref) and float(taps[..., 1:].abs().max()) == 0.0
+    wd, bd = mod.weight.detach().float().to(dev), mod.bias.detach().float().to(dev)
+    yb = torch.zeros(2, oh, ow, 32, device=dev)
+    MergeFn.RM1S.forward(wd, bd, gconv.View(taps), gconv.View(yb), gconv.EPI_BIAS_RELU)
+    assert rel_err(yb.permute(0, 3, 1, 2), y_ref) < TOL
+    dw, db = MergeFn.RM1S.backward_weight(gconv.View(taps), gconv.View(to_nhwc(gy.float(), 32).to(dev)))
+    assert rel_err(dw, mod.weight.grad) < TOL and rel_err(db, mod.bias.grad) < TOL
