@@ -1,0 +1,164 @@
+// rm_conv_1 of RoadMapBoxesMergingCNN (spatial_bb/components.py:80,148): relu(Conv2d(1 -> 32, k7, stride 3, dilation 3, padding 1))
+// on the road map, as a DENSE 7x7 convolution on the pixels it reads (dd_subsample_nhwc4: s[u][v] = rm[3u - 1][3v - 1]).
+//
+// One input channel: the K dimension of the GEMM is the TAPS.  The generic engine pads the channel to 4 and issues 98
+// v_mfma_f32_32x32x2_f32 per 32-pixel x 32-channel tile, three quarters of them on zeros; here a tap row is 4 column pairs
+// (kx = 2j + h, the 8th column has zero weights), 28 MFMAs per tile, the weights live in 28 registers and the A operand is
+// one ds_read_b32 per MFMA out of a 7-row LDS patch of the image.
+//
+// Weight gradient: dW[co][ky][kx] = sum over pixels of g[px][co] * s[px + (ky, kx)], M = 32 output channels, N = taps (two
+// column tiles: taps 0..31, then 32..48 + a column of ones that yields the bias gradient), K = pixels: per pixel pair one
+// 256-byte row of g from memory, two ds_read_b32 and two MFMAs.  Per-wave partial sums, fp64 fixed-order second stage.
+#include "dd_common.h"
+
+namespace {
+
+constexpr int C1_K = 7, C1_T = 49, C1_CO = 32;
+constexpr int C1_PITCH = 352;      // floats of a patch row: image width (<= 320) + a 32-pixel tile's overhang
+constexpr int C1_MAXW = 320;
+
+// ---- forward: one workgroup (4 waves) per output row
+__global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float* __restrict__ s4, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int sh, int sw, int relu) {
+  __shared__ float patch[C1_K][C1_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, n = lane & 31;
+  const int oh = sh - (C1_K - 1), ow = sw - (C1_K - 1);
+  const int b = blockIdx.x / oh, oy = blockIdx.x - b * oh;
+  // weights of this lane: column pair j of tap row ky -> w[co = n][ky][2j + h] (zero for the 8th column)
+  float bw[C1_K][4];
+#pragma unroll
+  for (int ky = 0; ky < C1_K; ++ky)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[ky][j] = (2 * j + h < C1_K) ? w[n * C1_T + ky * C1_K + 2 * j + h] : 0.f;
+  const float bv = bias ? bias[n] : 0.f;
+  for (int i = tid; i < C1_K * C1_PITCH; i += 256) {
+    const int r = i / C1_PITCH, c = i - r * C1_PITCH;
+    patch[r][c] = c < sw ? s4[(((long)b * sh + oy + r) * sw + c) * 4] : 0.f;
+  }
+  __syncthreads();
+  const int ntile = (ow + 31) >> 5;
+  for (int t = wave; t < ntile; t += 4) {
+    const int ox0 = t * 32;
+    float a[C1_K][4];
+#pragma unroll
+    for (int ky = 0; ky < C1_K; ++ky)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[ky][j] = patch[ky][ox0 + n + 2 * j + h];
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < C1_K; ++ky)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = DD_MFMA(a[ky][j], bw[ky][j], acc);
+    float* yr = y + (((long)b * oh + oy) * ow) * C1_CO;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ox = ox0 + dd_acc_row(e, lane);
+      float v = acc[e] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      if (ox < ow) yr[ox * C1_CO + n] = v;
+    }
+  }
+}
+
+// ---- weight gradient: persistent workgroups walk output rows; the 4 waves split a row's pixel pairs
+__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restrict__ s4, const float* __restrict__ g,
+                                                            float* __restrict__ part, int batch, int sh, int sw) {
+  __shared__ float patch[C1_K + 1][C1_PITCH];      // row 7: ones (the bias column, and what the padding columns read)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, n = lane & 31;
+  const int oh = sh - (C1_K - 1), ow = sw - (C1_K - 1);
+  // B operand of this lane: column tile 0 = tap n, column tile 1 = tap 32 + n (< 49), else the ones row
+  int boff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int t = 32 * nt + n;
+    boff[nt] = t < C1_T ? ((t / C1_K) * C1_PITCH + t % C1_K + h) * 4 : (C1_K * C1_PITCH + h) * 4;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+  for (int i = tid; i < C1_PITCH; i += 256) patch[C1_K][i] = 1.f;
+  const int npair = (ow + 1) >> 1;
+  for (long row = blockIdx.x; row < (long)batch * oh; row += gridDim.x) {
+    const int b = (int)(row / oh), oy = (int)(row - (long)b * oh);
+    __syncthreads();
+    for (int i = tid; i < C1_K * C1_PITCH; i += 256) {
+      const int r = i / C1_PITCH, c = i - r * C1_PITCH;
+      patch[r][c] = c < sw ? s4[(((long)b * sh + oy + r) * sw + c) * 4] : 0.f;
+    }
+    __syncthreads();
+    const float* gr = g + ((long)b * oh + oy) * ow * C1_CO;
+    const char* pb = (const char*)&patch[0][0];
+    // pairs wave, wave + 4, ...: four at a time, loads first
+    for (int p0 = wave; p0 < npair; p0 += 16) {
+      float av[4], b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + 4 * u, px = 2 * p + h;
+        av[u] = (p < npair && px < ow) ? gr[px * C1_CO + n] : 0.f;      // a pixel past the row end contributes nothing
+        const int po = min(p, npair - 1) * 8;
+        b0[u] = *(const float*)(pb + boff[0] + po);
+        b1[u] = *(const float*)(pb + boff[1] + po);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[0] = DD_MFMA(av[u], b0[u], acc[0]);
+        acc[1] = DD_MFMA(av[u], b1[u], acc[1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[((((long)blockIdx.x * 4 + wave) * 2 + nt) * 16 + e) * 64 + lane] = acc[nt][e];
+}
+
+// one thread per (tap or bias column, output channel): fp64 sum over workgroups and waves in a fixed order
+__global__ __launch_bounds__(64) void conv1ch_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nwg) {
+  const int col = blockIdx.x;               // 0..48 taps, 49 bias
+  const int co = threadIdx.x;               // D row
+  if (co >= C1_CO) return;
+  // D[row = co][col]: register e, lane l with dd_acc_row(e, l) == co and (l & 31) == col & 31
+  const int nt = col >> 5, n = col & 31;
+  const int hh = (co >> 2) & 1, e = (co & 3) + 4 * (co >> 3);
+  const int lane = 32 * hh + n;
+  double s = 0.0;
+  for (int w = 0; w < nwg * 4; ++w) s += (double)part[(((long)w * 2 + nt) * 16 + e) * 64 + lane];
+  if (col < C1_T) dw[co * C1_T + col] = (float)s;
+  else if (db) db[co] = (float)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dd_conv1ch_fwd(const float* taps4, const float* w, const float* bias, float* y, int32_t batch, int32_t sh, int32_t sw, int32_t relu,
+                   void* stream) {
+  DD_REQUIRE(taps4 && w && y && batch > 0, DD_ERR_BAD_ARG, "conv1ch_fwd: bad argument");
+  DD_REQUIRE(sh >= C1_K && sw >= C1_K && sw <= C1_MAXW, DD_ERR_UNSUPPORTED, "conv1ch_fwd: image %dx%d (width at most %d)", sh, sw, C1_MAXW);
+  const int oh = sh - (C1_K - 1);
+  hipLaunchKernelGGL(conv1ch_fwd_kernel, dim3((unsigned)(batch * oh)), dim3(256), 0, (hipStream_t)stream, taps4, w, bias, y, sh, sw, relu);
+  DD_LAUNCH_CHECK("conv1ch_fwd");
+  return 0;
+}
+
+int64_t dd_conv1ch_wgrad_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 2 * 4 * 2 * 16 * 64 * 4; }
+
+int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias, int32_t batch, int32_t sh, int32_t sw, void* workspace,
+                     void* stream) {
+  DD_REQUIRE(taps4 && g && dw && workspace && batch > 0, DD_ERR_BAD_ARG, "conv1ch_wgrad: bad argument");
+  DD_REQUIRE(sh >= C1_K && sw >= C1_K && sw <= C1_MAXW, DD_ERR_UNSUPPORTED, "conv1ch_wgrad: image %dx%d (width at most %d)", sh, sw, C1_MAXW);
+  const long rows = (long)batch * (sh - (C1_K - 1));
+  const int nwg = (int)max(1L, min((long)dd_cu_budget_internal() * 2, rows));
+  hipLaunchKernelGGL(conv1ch_wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, taps4, g, (float*)workspace, batch, sh, sw);
+  hipLaunchKernelGGL(conv1ch_wgrad_reduce, dim3(C1_T + 1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, dw, dbias, nwg);
+  DD_LAUNCH_CHECK("conv1ch_wgrad");
+  return 0;
+}
+
+}  // extern "C"

@@ -171,7 +171,8 @@ class MergeFn(torch.autograd.Function):
     SS_CONV = Layer(32, 32, (1, 24), stride=(1, 7))
     SS_DECONV = Layer(32, 32, 2, stride=2, transposed=True)
     RM1 = Layer(1, 32, 7, stride=3, dil=3, pad=1)       # rm_conv_1 as the reference states it (shapes) ...
-    RM1S = Layer(1, 32, 7)                              # ... and as it runs: dense, on the road map's pixels (3u - 1, 3v - 1)
+    RM1S = Layer(1, 32, 7)                              # ... and as a dense layer on the road map's pixels (3u - 1, 3v - 1): the generic-engine
+                                                        # form of what ops.conv1ch_* run (kept as the cross-check of tests/test_gpu_gconv.py)
     RM2 = Layer(32, 32, 3, dil=3)
     UPS_RM = (Layer(96, 64, 7, dil=7, transposed=True), Layer(64, 32, 7, dil=7, transposed=True),
               Layer(32, 16, 7, dil=7, transposed=True), Layer(16, 8, 7, dil=3, transposed=True))
@@ -199,9 +200,8 @@ class MergeFn(torch.autograd.Function):
         cat[..., 32:64].copy_(space)
         r1 = None
         if with_rm:
-            rh, rw = cls.RM1S.out_hw(rm4.shape[1], rm4.shape[2])
-            r1 = _empty((b, rh, rw, 32), dev)
-            cls.RM1S.forward(p_rm1[0], p_rm1[1], View(rm4), View(r1), EPI_BIAS_RELU)
+            r1 = ops.conv1ch_fwd(rm4, p_rm1[0], p_rm1[1], relu=True)      # rm_conv_1: taps as the K dimension (csrc/conv1ch.hip)
+            rh, rw = r1.shape[1:3]
             assert cls.RM2.out_hw(rh, rw) == (ch, cw)
             cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
         acts = [cat]
@@ -257,7 +257,7 @@ class MergeFn(torch.autograd.Function):
             g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))
             gr1 = _empty(r1.shape, dev)
             cls.RM2.backward_data(w_rm2, View(gcat, 64, 32), View(gr1), relu_src=r1)
-            g_rm1 = cls.RM1S.backward_weight(View(rm4), View(gr1))
+            g_rm1 = ops.conv1ch_wgrad(rm4, gr1)
         g_ssd = cls.SS_DECONV.backward_weight(View(s1), View(gcat, 0, 32))
         gs1 = _empty(s1.shape, dev)
         cls.SS_DECONV.backward_data(w_ssd, View(gcat, 0, 32), View(gs1), relu_src=s1)

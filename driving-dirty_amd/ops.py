@@ -137,6 +137,26 @@ def subsample_nhwc4(x, stride, offset, oh, ow):
     return out
 
 
+def conv1ch_fwd(taps4, w, bias, relu=True):
+    """taps4 [B,sh,sw,4] (channel 0), w [32,1,7,7] -> relu(conv + bias) [B,sh-6,sw-6,32] (NHWC)."""
+    b, sh, sw, _ = taps4.shape
+    assert tuple(w.shape) == (32, 1, 7, 7) and w.is_contiguous()
+    y = torch.empty((b, sh - 6, sw - 6, 32), device=taps4.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv1ch_fwd(_p(taps4), _p(w), _p(bias), _p(y), b, sh, sw, int(relu), _stream()), "dd_conv1ch_fwd")
+    return y
+
+
+def conv1ch_wgrad(taps4, g):
+    """-> (dw [32,1,7,7], db [32]) of conv1ch_fwd from g = dL/dy [B,sh-6,sw-6,32] (ReLU mask already applied)."""
+    b, sh, sw, _ = taps4.shape
+    assert tuple(g.shape) == (b, sh - 6, sw - 6, 32) and g.is_contiguous()
+    dw = torch.empty((32, 1, 7, 7), device=g.device, dtype=torch.float32)
+    db = torch.empty(32, device=g.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().dd_conv1ch_wgrad_workspace_bytes(), device=g.device, dtype=torch.uint8)
+    check(_lib.lib().dd_conv1ch_wgrad(_p(taps4), _p(g), _p(dw), _p(db), b, sh, sw, _p(ws), _stream()), "dd_conv1ch_wgrad")
+    return dw, db
+
+
 def nhwc_to_nchw(x, c):
     b, h, w, cs = x.shape
     _dev(x, "x")

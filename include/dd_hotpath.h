@@ -359,6 +359,15 @@ int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t heig
  * src [batch,h,w] (one channel), dst [batch,oh,ow,4]. */
 int dd_subsample_nhwc4(const float* src, float* dst, int32_t batch, int32_t h, int32_t w, int32_t oh, int32_t ow,
                        int32_t stride, int32_t offset, void* stream);
+/* ... and that dense convolution itself, 1 -> 32 channels, 7x7: y [batch,sh-6,sw-6,32] = (relu)(conv(taps4 channel 0) + bias),
+ * w [32,1,7,7] (the parameter as it is), sw <= 320.  The taps are the K dimension of the GEMM (28 MFMAs per 32 x 32 tile
+ * instead of the 98 of a channel padded to 4).  dd_conv1ch_wgrad: dw [32,1,7,7] and dbias [32] (may be NULL) from
+ * g = dL/dy [batch,sh-6,sw-6,32] (already masked by the ReLU); deterministic (fp64 fixed-order second stage). */
+int dd_conv1ch_fwd(const float* taps4, const float* w, const float* bias, float* y, int32_t batch, int32_t sh, int32_t sw,
+                   int32_t relu, void* stream);
+int64_t dd_conv1ch_wgrad_workspace_bytes(void);
+int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias, int32_t batch, int32_t sh, int32_t sw,
+                     void* workspace, void* stream);
 /* out[i] = a[i] + b[i] (gradient fan-in of the shared views / feature), n % 4 == 0. */
 int dd_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* Mean binary cross-entropy on PROBABILITIES (spatial_w_rm.py:131 F.binary_cross_entropy; log clamped at -100 like

@@ -250,5 +250,13 @@ def test_road_map_taps_make_rm_conv_1_dense(dev):
     yb = torch.zeros(2, oh, ow, 32, device=dev)
     MergeFn.RM1S.forward(wd, bd, gconv.View(taps), gconv.View(yb), gconv.EPI_BIAS_RELU)
     assert rel_err(yb.permute(0, 3, 1, 2), y_ref) < TOL
-    dw, db = MergeFn.RM1S.backward_weight(gconv.View(taps), gconv.View(to_nhwc(gy.float(), 32).to(dev)))
+    gb = to_nhwc(gy.float(), 32).to(dev)
+    dw, db = MergeFn.RM1S.backward_weight(gconv.View(taps), gconv.View(gb))
     assert rel_err(dw, mod.weight.grad) < TOL and rel_err(db, mod.bias.grad) < TOL
+    # the product's kernels for this layer (taps as the K dimension of the GEMM, csrc/conv1ch.hip)
+    y1 = ops.conv1ch_fwd(taps, wd, bd, relu=True)
+    assert rel_err(y1.permute(0, 3, 1, 2), y_ref) < TOL
+    dw1, db1 = ops.conv1ch_wgrad(taps, gb)
+    assert rel_err(dw1, mod.weight.grad) < TOL and rel_err(db1, mod.bias.grad) < TOL
+    dw2, db2 = ops.conv1ch_wgrad(taps, gb)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)          # fixed summation order
