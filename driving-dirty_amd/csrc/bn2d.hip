@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float* __restr
 // the grid zeroed.  Row layout: [2c] = sum, [2c+1] = sum of squares of channel c; the entries of lanes 32..63 stay zero.
 __global__ __launch_bounds__(256) void bn2d_stats_kernel(const f32x4* __restrict__ u, float* __restrict__ stats, long n4) {
   __shared__ float red[4][8][8];
-  const int cg = threadIdx.x & 7;
   f32x4 ss = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {   // stride % 8 == 0
     const f32x4 v = u[i];
