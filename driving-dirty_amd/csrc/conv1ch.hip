@@ -8,7 +8,7 @@
 //
 // Weight gradient: dW[co][ky][kx] = sum over pixels of g[px][co] * s[px + (ky, kx)], M = 32 output channels, N = taps (two
 // column tiles: taps 0..31, then 32..48 + a column of ones that yields the bias gradient), K = pixels: per pixel pair one
-// 256-byte row of g from memory, two ds_read_b32 and two MFMAs.  Per-wave partial sums, fp64 fixed-order second stage.
+// 256-byte row of g from memory, two ds_read_b32 and two MFMAs.  Per-workgroup partial sums, fp64 fixed-order second stage.
 #include "dd_common.h"
 
 namespace {
@@ -112,25 +112,37 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restr
       }
     }
   }
+  // the four waves' sums meet in LDS (wave order), one partial image per workgroup goes to the second stage
+  __shared__ float wsum[4][2 * 16 * 64];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) part[((((long)blockIdx.x * 4 + wave) * 2 + nt) * 16 + e) * 64 + lane] = acc[nt][e];
+    for (int e = 0; e < 16; ++e) wsum[wave][(nt * 16 + e) * 64 + lane] = acc[nt][e];
+  __syncthreads();
+  for (int i = tid; i < 2 * 16 * 64; i += 256) part[(long)blockIdx.x * (2 * 16 * 64) + i] = ((wsum[0][i] + wsum[1][i]) + wsum[2][i]) + wsum[3][i];
 }
 
-// one thread per (tap or bias column, output channel): fp64 sum over workgroups and waves in a fixed order
-__global__ __launch_bounds__(64) void conv1ch_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nwg) {
+// one block per tap (or bias) column: 32 output channels x 16 slices of the workgroups' partials; a slice is summed in
+// fp64 in index order, the 16 slice sums in slice order -- a fixed order whatever the grid
+__global__ __launch_bounds__(512) void conv1ch_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nwg) {
+  __shared__ double red[16][C1_CO];
   const int col = blockIdx.x;               // 0..48 taps, 49 bias
-  const int co = threadIdx.x;               // D row
-  if (co >= C1_CO) return;
+  const int co = threadIdx.x & 31, slice = threadIdx.x >> 5;
   // D[row = co][col]: register e, lane l with dd_acc_row(e, l) == co and (l & 31) == col & 31
   const int nt = col >> 5, n = col & 31;
   const int hh = (co >> 2) & 1, e = (co & 3) + 4 * (co >> 3);
   const int lane = 32 * hh + n;
   double s = 0.0;
-  for (int w = 0; w < nwg * 4; ++w) s += (double)part[(((long)w * 2 + nt) * 16 + e) * 64 + lane];
-  if (col < C1_T) dw[co * C1_T + col] = (float)s;
-  else if (db) db[co] = (float)s;
+  for (int w = slice; w < nwg; w += 16) s += (double)part[(((long)w * 2 + nt) * 16 + e) * 64 + lane];
+  red[slice][co] = s;
+  __syncthreads();
+  if (slice == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][co];
+    if (col < C1_T) dw[co * C1_T + col] = (float)t;
+    else if (db) db[co] = (float)t;
+  }
 }
 
 }  // namespace
@@ -147,7 +159,7 @@ int dd_conv1ch_fwd(const float* taps4, const float* w, const float* bias, float*
   return 0;
 }
 
-int64_t dd_conv1ch_wgrad_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 2 * 4 * 2 * 16 * 64 * 4; }
+int64_t dd_conv1ch_wgrad_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 2 * 2 * 16 * 64 * 4; }
 
 int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias, int32_t batch, int32_t sh, int32_t sw, void* workspace,
                      void* stream) {
@@ -156,7 +168,7 @@ int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias
   const long rows = (long)batch * (sh - (C1_K - 1));
   const int nwg = (int)max(1L, min((long)dd_cu_budget_internal() * 2, rows));
   hipLaunchKernelGGL(conv1ch_wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, taps4, g, (float*)workspace, batch, sh, sw);
-  hipLaunchKernelGGL(conv1ch_wgrad_reduce, dim3(C1_T + 1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, dw, dbias, nwg);
+  hipLaunchKernelGGL(conv1ch_wgrad_reduce, dim3(C1_T + 1), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, dw, dbias, nwg);
   DD_LAUNCH_CHECK("conv1ch_wgrad");
   return 0;
 }
