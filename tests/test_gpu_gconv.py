@@ -260,3 +260,31 @@ def test_road_map_taps_make_rm_conv_1_dense(dev):
     assert rel_err(dw1, mod.weight.grad) < TOL and rel_err(db1, mod.bias.grad) < TOL
     dw2, db2 = ops.conv1ch_wgrad(taps, gb)
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)          # fixed summation order
+
+
+@pytest.mark.parametrize("budget", [240, 12])
+def test_row_kernels_under_a_reduced_cu_budget(dev, budget):
+    """Data-parallel runs hand compute units to RCCL (dd_set_cu_budget): the persistent grids of the row kernels shrink
+    (240 -> 30 workgroups per XCD; 12 -> one per XCD, 8 used) and must still cover every row exactly once."""
+    from driving_dirty_amd import _lib, gconv
+    mod = synth.fill_module(nn.ConvTranspose2d(96, 64, 7, dilation=7), seed=3).double()
+    x = hu((1, 96, 11, 256), "cbx", 0.0, 1.0).double().requires_grad_(True)
+    y_ref = F.relu(mod(x))
+    gy = hu(tuple(y_ref.shape), "cbg").double() * (y_ref > 0)
+    y_ref.backward(gy)
+    layer = gconv.Layer(96, 64, 7, dil=7, transposed=True)
+    oh, ow = layer.out_hw(11, 256)
+    xb, gb = to_nhwc(x.detach().float(), 96).to(dev), to_nhwc(gy.float(), 64).to(dev)
+    wd, bd = mod.weight.detach().float().to(dev), mod.bias.detach().float().to(dev)
+    _lib.check(_lib.lib().dd_set_cu_budget(budget), "dd_set_cu_budget")
+    try:
+        yb = torch.zeros(1, oh, ow, 64, device=dev)
+        layer.forward(wd, bd, gconv.View(xb), gconv.View(yb), gconv.EPI_BIAS_RELU)
+        dxb = torch.zeros(1, 11, 256, 96, device=dev)
+        layer.backward_data(wd, gconv.View(gb), gconv.View(dxb))
+        dw, db = layer.backward_weight(gconv.View(xb), gconv.View(gb))
+    finally:
+        _lib.check(_lib.lib().dd_set_cu_budget(256), "dd_set_cu_budget")
+    assert rel_err(yb.permute(0, 3, 1, 2), y_ref) < TOL
+    assert rel_err(dxb.permute(0, 3, 1, 2), x.grad) < TOL
+    assert rel_err(dw, mod.weight.grad) < TOL and rel_err(db, mod.bias.grad) < TOL
