@@ -421,6 +421,93 @@ __global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, c
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
 
+// ---- ConvTranspose2d(32 -> 32, k2 s2) + bias + ReLU in ONE launch (the decoder's dc3, components.py:72,91; ss_deconv of the
+// box heads): the four output phases are four column tiles of one GEMM -- M = 32 input pixels, N = 4 x 32, K = 32 -- so
+// the input is read once (four generic 1x1 launches read it four times, 0.19 ms each at bs 32 for 80 MB in / 80 MB out).
+// Lane (m, h) holds channels 16h..16h+15 of pixel m (64 contiguous bytes); MFMA s pairs channels (s, 16 + s); the 64
+// weight values a lane needs stay in registers.  Output pixel (2y + a, 2x + b) of phase p = 2a + b: one 128-byte line.
+__global__ __launch_bounds__(256) void deconv2x2_c32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                long npix, int w, int relu) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, n = lane & 31;
+  float bw[4][16];                                       // wt[ci][co][a][b] (IOHW): phase p, k-step s -> ci = s + 16h, co = n
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bw[p][s] = wt[((s + 16 * h) * 32 + n) * 4 + p];
+  const float bv = bias ? bias[n] : 0.f;
+  const long ntile = (npix + 31) >> 5;
+  const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x, (int)min(npix * 128, 0x7fffffffL));
+  for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
+    const long px = t * 32 + n;
+    f32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = dd_bload4(xs, px < npix ? (int)(px * 128 + h * 64 + j * 16) : -16);
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = DD_MFMA(a[j][i], bw[p][4 * j + i], acc[p]);
+    // rows of the accumulator: pixels t*32 + 4h + (e&3) + 8(e>>2); (global row R = image*h + y, column) of the first, then at
+    // most one wrap into the next row (w >= 32)
+    const long p0 = t * 32 + 4 * h;
+    const long r0 = p0 / w;
+    const int c0 = (int)(p0 - r0 * w);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int off = (e & 3) + 8 * (e >> 2);
+      int c = c0 + off;
+      long r = r0;
+      if (c >= w) { c -= w; r += 1; }
+      if (p0 + off < npix) {
+        float* o = out + ((2 * r) * (2L * w) + 2 * c) * 32 + n;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float v = acc[p][e] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          o[((p >> 1) * (2L * w) + (p & 1)) * 32] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- ConvTranspose2d(32 -> 3, k1) + bias, written as NCHW (the decoder's dc4, components.py:73,92, and its output layout):
+// three dot products per pixel -- a VALU kernel, one 128-byte line read per pixel, coalesced plane writes.
+__global__ __launch_bounds__(256) void conv1x1_c32_c3_nchw_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                  const float* __restrict__ bias, float* __restrict__ out, long plane, long npix) {
+  __shared__ float wl[32 * 3 + 3];
+  if (threadIdx.x < 96) wl[threadIdx.x] = wt[threadIdx.x];                      // wt[ci][k] (IOHW, k1)
+  if (threadIdx.x < 3) wl[96 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    float z0 = wl[96], z1 = wl[97], z2 = wl[98];
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      const f32x4 v = *(const f32x4*)(x + p * 32 + c4 * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = c4 * 4 + i;
+        z0 += v[i] * wl[ci * 3];
+        z1 += v[i] * wl[ci * 3 + 1];
+        z2 += v[i] * wl[ci * 3 + 2];
+      }
+    }
+    const long b = p / plane, q = p - b * plane;
+    float* o = out + b * 3 * plane + q;
+    o[0] = z0;
+    o[plane] = z1;
+    o[2 * plane] = z2;
+  }
+}
+
 // ---- last layer of the box heads: ConvTranspose2d(C -> 1, k2 s2) + sigmoid (spatial_bb/components.py:93,139,117,168).
 // One output channel cannot feed a 32-wide MFMA column; it is 4*C MACs per input pixel: a VALU kernel, HBM-bound.
 template <int C>
@@ -800,6 +887,27 @@ int dd_channel_sum(const float* buf, float* out, int64_t npix, int32_t cstore, i
   hipLaunchKernelGGL(channel_sum_final, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, out, grid, cout,
                      accumulate);
   DD_LAUNCH_CHECK("channel_sum final");
+  return 0;
+}
+
+int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
+                         void* stream) {
+  DD_REQUIRE(x && wt && out && batch > 0 && h > 0 && w >= 32, DD_ERR_BAD_ARG, "deconv2x2_c32_fwd: bad argument (width at least 32)");
+  const long npix = (long)batch * h * w;
+  DD_REQUIRE(npix * 128 < (1L << 31), DD_ERR_UNSUPPORTED, "deconv2x2_c32_fwd: input exceeds 2 GB");
+  const long ntile = (npix + 31) / 32;
+  hipLaunchKernelGGL(deconv2x2_c32_fwd_kernel, dim3((unsigned)min((ntile + 3) / 4, (long)DD_NUM_CU * 8)), dim3(256), 0, (hipStream_t)stream, x, wt,
+                     bias, out, npix, w, relu);
+  DD_LAUNCH_CHECK("deconv2x2_c32_fwd");
+  return 0;
+}
+
+int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, void* stream) {
+  DD_REQUIRE(x && wt && out && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "conv1x1_c32_c3_nchw: bad argument");
+  const long plane = (long)h * w, npix = plane * batch;
+  hipLaunchKernelGGL(conv1x1_c32_c3_nchw_kernel, dim3((unsigned)min((npix + 255) / 256, (long)DD_NUM_CU * 16)), dim3(256), 0, (hipStream_t)stream,
+                     x, wt, bias, out, plane, npix);
+  DD_LAUNCH_CHECK("conv1x1_c32_c3_nchw");
   return 0;
 }
 

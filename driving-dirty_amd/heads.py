@@ -53,16 +53,21 @@ class DecoderConvStack(torch.autograd.Function):
         b, dev = h.shape[0], h.device
         x0 = ops.nchw_to_nhwc(h.contiguous().view(b, 64, dh, dw), 64)
         a1, a2 = _empty((b, dh, dw, 32), dev), _empty((b, dh, dw, 32), dev)
-        a3, y4 = _empty((b, 2 * dh, 2 * dw, 32), dev), _zeros((b, 2 * dh, 2 * dw, 4), dev)
         cls.L1.forward(w1, b1, View(x0), View(a1), EPI_BIAS_RELU)
         cls.L2.forward(w2, b2, View(a1), View(a2), EPI_BIAS_RELU)
-        cls.L3.forward(w3, b3, View(a2), View(a3), EPI_BIAS_RELU)
-        cls.L4.forward(w4, b4, View(a3), View(y4, 0, 3), EPI_BIAS)
+        if dw >= 32:      # dc3 in one launch (four phases = four column tiles), dc4 straight to the NCHW output
+            a3 = ops.deconv2x2_c32_fwd(a2, w3.contiguous(), b3, relu=True)
+            y = ops.conv1x1_c32_c3_nchw(a3, w4.contiguous(), b4)
+        else:
+            a3, y4 = _empty((b, 2 * dh, 2 * dw, 32), dev), _zeros((b, 2 * dh, 2 * dw, 4), dev)
+            cls.L3.forward(w3, b3, View(a2), View(a3), EPI_BIAS_RELU)
+            cls.L4.forward(w4, b4, View(a3), View(y4, 0, 3), EPI_BIAS)
+            y = ops.nhwc_to_nchw(y4, 3)
         if TRACE is not None:
             TRACE.update(dc1=a1, dc2=a2, dc3=a3)
         ctx.save_for_backward(x0, a1, a2, a3, w1, w2, w3, w4)
         ctx.dims = (dh, dw)
-        return ops.nhwc_to_nchw(y4, 3)
+        return y
 
     @staticmethod
     def backward(ctx, gy):

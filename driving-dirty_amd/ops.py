@@ -137,6 +137,24 @@ def subsample_nhwc4(x, stride, offset, oh, ow):
     return out
 
 
+def deconv2x2_c32_fwd(x, wt, bias, relu=True):
+    """x [B,h,w,32] NHWC, wt [32,32,2,2] -> (relu)(ConvTranspose2d k2 s2) [B,2h,2w,32] NHWC, one launch."""
+    b, h, w, c = x.shape
+    assert c == 32 and tuple(wt.shape) == (32, 32, 2, 2) and x.is_contiguous() and wt.is_contiguous()
+    out = torch.empty((b, 2 * h, 2 * w, 32), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_deconv2x2_c32_fwd(_p(x), _p(wt), _p(bias), _p(out), b, h, w, int(relu), _stream()), "dd_deconv2x2_c32_fwd")
+    return out
+
+
+def conv1x1_c32_c3_nchw(x, wt, bias):
+    """x [B,h,w,32] NHWC, wt [32,3,1,1] -> ConvTranspose2d k1 [B,3,h,w] NCHW."""
+    b, h, w, c = x.shape
+    assert c == 32 and tuple(wt.shape) == (32, 3, 1, 1) and x.is_contiguous() and wt.is_contiguous()
+    out = torch.empty((b, 3, h, w), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dd_conv1x1_c32_c3_nchw(_p(x), _p(wt), _p(bias), _p(out), b, h, w, _stream()), "dd_conv1x1_c32_c3_nchw")
+    return out
+
+
 def conv1ch_fwd(taps4, w, bias, relu=True):
     """taps4 [B,sh,sw,4] (channel 0), w [32,1,7,7] -> relu(conv + bias) [B,sh-6,sw-6,32] (NHWC)."""
     b, sh, sw, _ = taps4.shape

@@ -348,6 +348,15 @@ int dd_deconv2x2_c1_fwd(const float* x, const float* wt, const float* bias, floa
 int dd_deconv2x2_c1_bwd(const float* x, const float* wt, const float* probs, const float* dprobs, float* dx, float* dwt,
                         float* dbias, int32_t batch, int32_t h, int32_t w, int32_t c, void* workspace, void* stream);
 
+/* The decoder's tail (components.py:72-73,91-92): dc3 = relu(ConvTranspose2d(32 -> 32, k2 s2)) in ONE launch -- the four output
+ * phases are four column tiles of one GEMM, the input is read once -- x [batch,h,w,32] NHWC, wt [32,32,2,2] (IOHW, the parameter),
+ * out [batch,2h,2w,32] NHWC, w >= 32; and dc4 = ConvTranspose2d(32 -> 3, k1) written as the NCHW image the decoder returns:
+ * x [batch,h,w,32] NHWC, wt [32,3,1,1], out [batch,3,h,w]. */
+int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
+                         int32_t relu, void* stream);
+int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
+                           void* stream);
+
 /* One camera view of views[B,6,3,H,W] -> NHWC4 [B,H',W',4] with the geometric transform SpatialMappingCNN applies
  * before its strip convs (spatial_bb/components.py:43-65): 0 = none, 1 = rot90(k=1, dims [2,3]) (view 4, "b"),
  * 2 = rot90(k=1, dims [3,2]) (view 1, "f"), 3 = flip([2,3]) (views 5 and 2).  Rotations swap H and W. */

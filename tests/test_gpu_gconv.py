@@ -288,3 +288,22 @@ def test_row_kernels_under_a_reduced_cu_budget(dev, budget):
     assert rel_err(yb.permute(0, 3, 1, 2), y_ref) < TOL
     assert rel_err(dxb.permute(0, 3, 1, 2), x.grad) < TOL
     assert rel_err(dw, mod.weight.grad) < TOL and rel_err(db, mod.bias.grad) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 5, 37), (1, 32, 9, 32), (3, 32, 7, 153)])
+def test_decoder_tail_kernels(dev, shape):
+    """dc3 = relu(ConvTranspose2d(32, 32, 2, stride=2)) in one launch and dc4 = ConvTranspose2d(32, 3, 1) written as NCHW
+    (components.py:72-73,91-92) against fp64 torch; m-tiles that straddle rows and images (w = 37)."""
+    from driving_dirty_amd import ops
+    dc3 = synth.fill_module(nn.ConvTranspose2d(32, 32, 2, stride=2), seed=4).double()
+    dc4 = synth.fill_module(nn.ConvTranspose2d(32, 3, 1), seed=5).double()
+    x = hu(shape, "dtx").double()
+    a3_ref = F.relu(dc3(x))
+    y_ref = dc4(a3_ref)
+    xb = to_nhwc(x.float(), 32).to(dev)
+    a3 = ops.deconv2x2_c32_fwd(xb, dc3.weight.detach().float().to(dev), dc3.bias.detach().float().to(dev), relu=True)
+    assert rel_err(a3.permute(0, 3, 1, 2), a3_ref) < TOL
+    y = ops.conv1x1_c32_c3_nchw(a3, dc4.weight.detach().float().to(dev), dc4.bias.detach().float().to(dev))
+    assert tuple(y.shape) == tuple(y_ref.shape) and rel_err(y, y_ref) < TOL
+    lin = ops.deconv2x2_c32_fwd(xb, dc3.weight.detach().float().to(dev), None, relu=False)      # no bias, no ReLU
+    assert rel_err(lin.permute(0, 3, 1, 2), F.conv_transpose2d(x, dc3.weight, None, stride=2)) < TOL
