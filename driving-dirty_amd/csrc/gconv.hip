@@ -421,6 +421,18 @@ __global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, c
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
 
+// ---- a channel slice of one NHWC buffer into a channel slice of another (torch.cat / tensor slicing of the merging heads'
+// concat buffer, components.py:109,159): 16 bytes per lane, both sides in whole lines when the slices are 32 channels wide
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, long npix, int c4,
+                                                            int src_cstore, int src_coff, int dst_cstore, int dst_coff) {
+  const long total = npix * c4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / c4;
+    const int c = (int)(i - p * c4) * 4;
+    *(f32x4*)(dst + p * dst_cstore + dst_coff + c) = *(const f32x4*)(src + p * src_cstore + src_coff + c);
+  }
+}
+
 // ---- ConvTranspose2d(32 -> 32, k2 s2) + bias + ReLU in ONE launch (the decoder's dc3, components.py:72,91; ss_deconv of the
 // box heads): the four output phases are four column tiles of one GEMM -- M = 32 input pixels, N = 4 x 32, K = 32 -- so
 // the input is read once (four generic 1x1 launches read it four times, 0.19 ms each at bs 32 for 80 MB in / 80 MB out).
@@ -948,6 +960,19 @@ int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t heig
   hipLaunchKernelGGL(view_to_nhwc4_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
                      (hipStream_t)stream, views, (f32x4*)out, batch, height, width, view, transform);
   DD_LAUNCH_CHECK("view_to_nhwc4");
+  return 0;
+}
+
+int dd_copy_channels(const float* src, float* dst, int64_t npix, int32_t channels, int32_t src_cstore, int32_t src_coff, int32_t dst_cstore,
+                     int32_t dst_coff, void* stream) {
+  DD_REQUIRE(src && dst && npix > 0 && channels > 0, DD_ERR_BAD_ARG, "copy_channels: bad argument");
+  DD_REQUIRE(channels % 4 == 0 && src_cstore % 4 == 0 && src_coff % 4 == 0 && dst_cstore % 4 == 0 && dst_coff % 4 == 0 &&
+                 src_coff + channels <= src_cstore && dst_coff + channels <= dst_cstore,
+             DD_ERR_UNSUPPORTED, "copy_channels: channel slices must be 4-aligned and inside their buffers");
+  const long total = npix * (channels / 4);
+  hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 16)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, (long)npix, channels / 4, src_cstore, src_coff, dst_cstore, dst_coff);
+  DD_LAUNCH_CHECK("copy_channels");
   return 0;
 }
 

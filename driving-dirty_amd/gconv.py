@@ -267,6 +267,16 @@ class Layer:
         return dw, db
 
 
+def copy_channels(src, dst):
+    """dst.buf[..., dst.coff : +chans] = src.buf[..., src.coff : +chans] (Views over whole NHWC buffers of equal pixel count)."""
+    assert src.chans == dst.chans and src.buf.shape[:3] == dst.buf.shape[:3]
+    for v in (src, dst):
+        assert v.off_h == 0 and v.off_w == 0 and v.h == v.buf.shape[1] and v.w == v.buf.shape[2]
+    npix = src.buf.shape[0] * src.buf.shape[1] * src.buf.shape[2]
+    check(_lib.lib().dd_copy_channels(_p(_chk(src.buf, "src")), _p(_chk(dst.buf, "dst")), npix, src.chans, src.buf.shape[3], src.coff,
+                                      dst.buf.shape[3], dst.coff, _stream()), "dd_copy_channels")
+
+
 def channel_sum(view, out, accumulate=False):
     """out[c] = sum over all pixels of view.buf[..., view.coff + c] (dense buffers only)."""
     b, mh, mw, cs = view.buf.shape

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .gconv import EPI_BIAS, EPI_BIAS_RELU, Layer, View, _p, _stream, add, view_to_nhwc4
+from .gconv import EPI_BIAS, EPI_BIAS_RELU, Layer, View, _p, _stream, add, copy_channels, view_to_nhwc4
 
 
 # Test hook: when set to a dict, the nodes below leave their ReLU outputs (NHWC) in it so that a checker can replay the
@@ -202,7 +202,7 @@ class MergeFn(torch.autograd.Function):
         assert (ch, cw) == tuple(space.shape[1:3]), "ssr and spatial map must meet at the same size"
         cat = _empty((b, ch, cw, 96 if with_rm else 64), dev)
         cls.SS_DECONV.forward(p_ssd[0], p_ssd[1], View(s1), View(cat, 0, 32), EPI_BIAS_RELU)
-        cat[..., 32:64].copy_(space)
+        copy_channels(View(space.contiguous()), View(cat, 32, 32))
         r1 = None
         if with_rm:
             r1 = ops.conv1ch_fwd(rm4, p_rm1[0], p_rm1[1], relu=True)      # rm_conv_1: taps as the K dimension (csrc/conv1ch.hip)
@@ -256,7 +256,10 @@ class MergeFn(torch.autograd.Function):
             g = gsrc
         g_up.reverse()
         gcat = g                                                                 # [B,256,256,64|96]; slices 0:32 / 64:96 ReLU-masked
-        g_space = gcat[..., 32:64].contiguous() if ctx.needs_input_grad[1] else None      # plain dL/d(spatial_map): no mask
+        g_space = None
+        if ctx.needs_input_grad[1]:                           # plain dL/d(spatial_map): no mask
+            g_space = _empty(gcat.shape[:3] + (32,), dev)
+            copy_channels(View(gcat, 32, 32), View(g_space))
         g_rm2 = g_rm1 = (None, None)
         if with_rm:
             g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))

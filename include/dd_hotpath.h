@@ -377,6 +377,11 @@ int dd_conv1ch_fwd(const float* taps4, const float* w, const float* bias, float*
 int64_t dd_conv1ch_wgrad_workspace_bytes(void);
 int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias, int32_t batch, int32_t sh, int32_t sw,
                      void* workspace, void* stream);
+/* dst[p][dst_coff + c] = src[p][src_coff + c], c < channels, p < npix: a channel slice of one NHWC buffer into a channel slice of
+ * another -- the `torch.cat((ssr, space_rep, rm), dim=1)` of the merging heads (components.py:109,159) and the slice of its
+ * gradient; everything a multiple of 4 channels. */
+int dd_copy_channels(const float* src, float* dst, int64_t npix, int32_t channels, int32_t src_cstore, int32_t src_coff,
+                     int32_t dst_cstore, int32_t dst_coff, void* stream);
 /* out[i] = a[i] + b[i] (gradient fan-in of the shared views / feature), n % 4 == 0. */
 int dd_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* Mean binary cross-entropy on PROBABILITIES (spatial_w_rm.py:131 F.binary_cross_entropy; log clamped at -100 like

@@ -307,3 +307,13 @@ def test_decoder_tail_kernels(dev, shape):
     assert tuple(y.shape) == tuple(y_ref.shape) and rel_err(y, y_ref) < TOL
     lin = ops.deconv2x2_c32_fwd(xb, dc3.weight.detach().float().to(dev), None, relu=False)      # no bias, no ReLU
     assert rel_err(lin.permute(0, 3, 1, 2), F.conv_transpose2d(x, dc3.weight, None, stride=2)) < TOL
+
+
+def test_copy_channels(dev):
+    """dd_copy_channels: a channel slice into a channel slice (the concat of the merging heads and the slice of its gradient)."""
+    from driving_dirty_amd import gconv
+    src = hu((2, 5, 7, 48), "ccs").to(dev)
+    dst = torch.full((2, 5, 7, 96), -1.0, device=dev)
+    gconv.copy_channels(gconv.View(src, 8, 32), gconv.View(dst, 32, 32))
+    assert torch.equal(dst[..., 32:64], src[..., 8:40])
+    assert float((dst[..., :32] + 1).abs().max()) == 0.0 and float((dst[..., 64:] + 1).abs().max()) == 0.0
