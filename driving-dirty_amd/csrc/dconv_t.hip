@@ -64,7 +64,7 @@ struct TfTask {
 template <int K, int D, int NSLOT, int MODE, int IWP>
 __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
-                                                                const dd_gconv_desc d, int epi, int wp_bytes, int dbg_repeat, int dbg_flags) {
+                                                                const dd_gconv_desc d, int epi, int wp_bytes, int dbg_repeat) {
   using G = TfGeom<K, D, MODE, IWP>;
   constexpr bool N16 = G::N16, ONE_MT = MODE == 0;
   constexpr int TW = G::TW, NE = G::NE, P = G::P;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
       constexpr int AR = ONE_MT ? 1 : (N16 ? 4 : 3);        // A fragments are requested AR tiles ahead
       static_assert(ONE_MT || NSLOT % AR == 0, "A ring");
       frag Af[AR];
-      for (int q = 0; q < ((dbg_flags & 8) ? 0 : NC); ++q) {
+      for (int q = 0; q < NC; ++q) {
         const bool more = q + 1 < NC;
         const char* lbase = (const char*)&lds[par][0];
         float* nbuf = &lds[par ^ 1][0];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
     const int c4 = 4 * (tid % LPP), cch = 32 * cur.nt + c4;  // 512 % LPP == 0: a thread always writes the same channel group
     f32x4 bvec = f32x4{0.f, 0.f, 0.f, 0.f};
     if ((epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && cch < d.cout) bvec = *(const f32x4*)&bias[cch];
-    if (!(dbg_flags & 1)) {
+    {
       if (tid < G::HALO * (P / 4)) *(f32x4*)&img[n_mt * TW * P + tid * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
       static_assert(G::HALO * (P / 4) <= TF_THREADS, "one zeroing store per thread");
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
         tf_barrier();
       }
     }
-    if (!(dbg_flags & 2)) {
+    {
       const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
       const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff + cch;
       f32x4 v[WIT];
@@ -545,7 +545,6 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   const int grid = dd_cu_budget_internal() & ~7;
   if (grid < 8) return false;
   static const int dbg_repeat = getenv("DD_DCONV_REPEAT") ? atoi(getenv("DD_DCONV_REPEAT")) : 1;
-  static const int dbg_flags = getenv("DD_DCONV_TFWD_DBG") ? atoi(getenv("DD_DCONV_TFWD_DBG")) : 0;      // timing diagnostics (wrong results)
 #define DD_TF(KK, DD_, NS, MODE_, IWP_)                                                                                        \
   do {                                                                                                                         \
     using G = TfGeom<KK, DD_, MODE_, IWP_>;                                                                                    \
@@ -554,7 +553,7 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
         (MODE_ == 0 && n_mt > 8))                                                                                              \
       return false;                                                                                                            \
     hipLaunchKernelGGL((dconv_tfwd_kernel<KK, DD_, NS, MODE_, IWP_>), dim3(grid), dim3(TF_THREADS), 0, st, x, packed, bias, y, \
-                       *d, epilogue, wp_bytes, dbg_repeat, dbg_flags);                                                                   \
+                       *d, epilogue, wp_bytes, dbg_repeat);                                                                   \
     return true;                                                                                                               \
   } while (0)
   if (k == 7 && dl == 7 && d->cout > 16 && d->in_w <= 256) DD_TF(7, 7, 7, 0, 256);
