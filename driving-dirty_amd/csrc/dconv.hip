@@ -260,6 +260,56 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
           kx = more ? (wrap ? kx0 : kx + 1) : kx;
           ky = (more && wrap) ? ky + 1 : ky;
         };
+        // Every tap valid for this wave (data gradients; interior waves of the padded layers) and at most two column tiles: tap
+        // columns unrolled, the operands of tap (ky + 1, kx) requested into the registers tap (ky, kx) has just been multiplied
+        // from -- no (ky, kx) iterator, no operand-address arithmetic per tap (T(r) of the iterator loop: 17 % over its MFMAs)
+        bool done = false;
+        if constexpr (!N16 && NTR <= 2) {
+          if (nky == K && nkx == K && dbg_repeat == 1) {
+            done = true;
+            f32x4 Aq0[K], Aq1[K], Bq[K][NTR];
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+              const char* p = lbase + (c * D) * 32;
+              Aq0[c] = *(const f32x4*)p;
+              Aq1[c] = *(const f32x4*)(p + 1024);
+#pragma unroll
+              for (int nt = 0; nt < NTR; ++nt)
+                Bq[c][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, ((q * T + c) * NTR + nt) * 1024, 0));
+            }
+            for (int r = 0; r < K; ++r) {
+              const int rn = min(r + 1, K - 1);                  // past the last tap row: harmless reloads of it
+              const char* prow = lbase + (rn * tw) * 32;
+              const int srow = (q * T + rn * K) * NTR * 1024;
+#pragma unroll
+              for (int c = 0; c < K; ++c) {
+#pragma unroll
+                for (int nt = 0; nt < NTR; ++nt) {
+                  acc[0][nt] = DD_MFMA(Aq0[c].x, Bq[c][nt].x, acc[0][nt]);
+                  acc[0][nt] = DD_MFMA(Aq0[c].y, Bq[c][nt].y, acc[0][nt]);
+                  acc[0][nt] = DD_MFMA(Aq0[c].z, Bq[c][nt].z, acc[0][nt]);
+                  acc[0][nt] = DD_MFMA(Aq0[c].w, Bq[c][nt].w, acc[0][nt]);
+                }
+                if (mt1) {
+#pragma unroll
+                  for (int nt = 0; nt < NTR; ++nt) {
+                    acc[1][nt] = DD_MFMA(Aq1[c].x, Bq[c][nt].x, acc[1][nt]);
+                    acc[1][nt] = DD_MFMA(Aq1[c].y, Bq[c][nt].y, acc[1][nt]);
+                    acc[1][nt] = DD_MFMA(Aq1[c].z, Bq[c][nt].z, acc[1][nt]);
+                    acc[1][nt] = DD_MFMA(Aq1[c].w, Bq[c][nt].w, acc[1][nt]);
+                  }
+                }
+                Aq0[c] = *(const f32x4*)(prow + (c * D) * 32);
+                Aq1[c] = *(const f32x4*)(prow + (c * D) * 32 + 1024);
+#pragma unroll
+                for (int nt = 0; nt < NTR; ++nt)
+                  Bq[c][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, srow + (c * NTR + nt) * 1024, 0));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
+        if (!done)
         for (int rep = 0; rep < dbg_repeat; ++rep) {      // dbg_repeat = 1 (DD_DCONV_REPEAT: timing diagnostic only, results are then wrong)
         ky = ky0; kx = kx0; left = ntaps - 1;
         load_tap(0, ky, kx);
