@@ -309,6 +309,43 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
             }
           }
         }
+        if constexpr (N16) {      // the same for the 16-wide form: four 16-pixel A fragments and one weight fragment per tap
+          if (nky == K && nkx == K && dbg_repeat == 1) {
+            done = true;
+            f32x2 Pq[K][4], Qq[K];
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+              const char* p = lbase + (c * D) * 32;
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) Pq[c][t4] = *(const f32x2*)(p + 512 * t4);
+              Qq[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ws, lane * 8, (q * T + c) * 512, 0));
+            }
+            for (int r = 0; r < K; ++r) {
+              const int rn = min(r + 1, K - 1);
+              const char* prow = lbase + (rn * tw) * 32;
+              const int srow = (q * T + rn * K) * 512;
+#pragma unroll
+              for (int c = 0; c < K; ++c) {
+                acc16[0] = DD_MFMA16(Pq[c][0].x, Qq[c].x, acc16[0]);
+                acc16[1] = DD_MFMA16(Pq[c][1].x, Qq[c].x, acc16[1]);
+                if (mt1) {
+                  acc16[2] = DD_MFMA16(Pq[c][2].x, Qq[c].x, acc16[2]);
+                  acc16[3] = DD_MFMA16(Pq[c][3].x, Qq[c].x, acc16[3]);
+                }
+                acc16[0] = DD_MFMA16(Pq[c][0].y, Qq[c].y, acc16[0]);
+                acc16[1] = DD_MFMA16(Pq[c][1].y, Qq[c].y, acc16[1]);
+                if (mt1) {
+                  acc16[2] = DD_MFMA16(Pq[c][2].y, Qq[c].y, acc16[2]);
+                  acc16[3] = DD_MFMA16(Pq[c][3].y, Qq[c].y, acc16[3]);
+                }
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) Pq[c][t4] = *(const f32x2*)(prow + (c * D) * 32 + 512 * t4);
+                Qq[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ws, lane * 8, srow + c * 512, 0));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
         if (!done)
         for (int rep = 0; rep < dbg_repeat; ++rep) {      // dbg_repeat = 1 (DD_DCONV_REPEAT: timing diagnostic only, results are then wrong)
         ky = ky0; kx = kx0; left = ntaps - 1;
