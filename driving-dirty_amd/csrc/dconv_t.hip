@@ -17,37 +17,31 @@
 //   * epilogue: the k partial rows are added into one LDS row image at their shifts (k barrier-separated passes: a fixed
 //     order, deterministic), then bias / ReLU and 16-byte stores.
 //
-// Three forms (MODE):
-//   0  Cout > 16, at most 8 m-tiles of 32 pixels (up_conv_1, 256 wide): wave w owns m-tile w and its k tap columns --
-//      one A fragment per (chunk, tap row) feeds 4k v_mfma_f32_32x32x2_f32;
-//   1  Cout > 16, wider rows (up_conv_2, 298 wide -> 10 m-tiles x 7 = 70 tiles, 9 per wave);
-//   2  Cout <= 16 (up_conv_3, 340 wide): tiles of 16 pixels x 16 channels on v_mfma_f32_16x16x4_f32 (154 tiles, 20 per wave).
+// Two forms (MODE), both for Cout > 16:
+//   0  at most 8 m-tiles of 32 pixels (up_conv_1, 256 wide): wave w owns m-tile w and its k tap columns -- one A fragment
+//      per (chunk, tap row) feeds 4k v_mfma_f32_32x32x2_f32;
+//   1  wider rows (up_conv_2, 298 wide -> 10 m-tiles x 7 = 70 tiles, 9 per wave).
+// (Cout <= 16 -- up_conv_3 -- stays on dconv_fwd_kernel: a 16 x 16-tile form of this kernel measured 2.24 ms against 1.98.)
 //
 // Tasks are dealt to the XCDs in (image, residue class, phase row, column tile) order, so the workgroups resident on one XCD
 // walk neighbouring rows of ONE class and share their input rows (k users each) in that XCD's L2.
 #include <stdlib.h>
-
-#include <type_traits>
 
 #include "dd_common.h"
 
 namespace {
 
 constexpr int TF_THREADS = 512;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define DD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <int K, int D, int MODE, int IWP>
 struct TfGeom {
-  static constexpr bool N16 = MODE == 2;
-  static constexpr int TW = N16 ? 16 : 32;                // pixels of an m-tile
-  static constexpr int NE = N16 ? 4 : 16;                 // accumulator registers of a tile
+  static constexpr int TW = 32;                           // pixels of an m-tile
+  static constexpr int NE = 16;                           // accumulator registers of a tile
   static constexpr int ROWF = IWP * 8;                    // floats of a patch row (IWP pixels x 8 channels)
   static constexpr int BUFF = K * ROWF;                   // floats of one buffer
   static constexpr int NPR = (IWP * 2 + TF_THREADS - 1) / TF_THREADS;      // 16-byte pieces per thread and patch row
-  // floats per pixel of the output row image.  32-wide tiles: lanes 32..63 sit 4 pixels = 160 floats = 32 banks further;
-  // 16-wide tiles: the four lane groups sit 4 pixels = 80 floats = 16 banks apart.
-  static constexpr int P = N16 ? 20 : 40;
+  // floats per pixel of the output row image: lanes 32..63 of a tile sit 4 pixels = 160 floats = 32 banks further
+  static constexpr int P = 40;
   static constexpr int HALO = D * (K - 1);
 };
 
@@ -66,14 +60,14 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 const dd_gconv_desc d, int epi, int wp_bytes, int dbg_repeat) {
   using G = TfGeom<K, D, MODE, IWP>;
-  constexpr bool N16 = G::N16, ONE_MT = MODE == 0;
+  constexpr bool ONE_MT = MODE == 0;
   constexpr int TW = G::TW, NE = G::NE, P = G::P;
-  using frag = typename std::conditional<N16, f32x2, f32x4>::type;
-  using acc_t = typename std::conditional<N16, f32x4, f32x16>::type;
+  using frag = f32x4;
+  using acc_t = f32x16;
   __shared__ __attribute__((aligned(16))) float lds[2][G::BUFF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NC = d.cin >> 3, NTC = N16 ? 1 : (d.cout + 31) >> 5;
+  const int NC = d.cin >> 3, NTC = (d.cout + 31) >> 5;
   const int rows_max = (d.out_h + D - 1) / D;
   const int n_mt = (d.in_w + TW - 1) / TW;
   const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
@@ -101,10 +95,10 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
     const int mt = s_ok[i] ? L / K : 0;
     s_kx[i] = s_ok[i] ? L - mt * K : 0;
     s_mt[i] = mt;
-    aoff[i] = N16 ? ((mt * 16 + (lane & 15)) * 8 + 2 * (lane >> 4)) * 4 : ((mt * 32 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
+    aoff[i] = ((mt * 32 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
   }
   // float index of this lane's accumulator element 0 of m-tile 0 in the output row image
-  const int ioff_lane = N16 ? 4 * (lane >> 4) * P + (lane & 15) : 4 * (lane >> 5) * P + (lane & 31);
+  const int ioff_lane = 4 * (lane >> 5) * P + (lane & 31);
 
   // ---- tasks of this workgroup: XCD = blockIdx % 8 owns the x-th eighth of the (image, residue, phase row, column tile) list
   const int per_x = gridDim.x >> 3;
@@ -131,12 +125,8 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
 
   frag Bf[NSLOT];
   auto bload = [&](int i, int q, int ky, int nt) {
-    if constexpr (N16) {
-      Bf[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ws, lane * 8, ((q * K + ky) * K + s_kx[i]) * 512, 0));
-    } else {
-      const int soff = (((q * K + ky) * K + s_kx[i]) * NTC + nt) * 1024;
-      Bf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff, 0));
-    }
+    const int soff = (((q * K + ky) * K + s_kx[i]) * NTC + nt) * 1024;
+    Bf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, lane * 16, soff, 0));
   };
 
   TfTask cur, nxt;
@@ -178,7 +168,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
         for (int i = 0; i < NSLOT; ++i) bload(i, 0, ky0, cur.nt);
       }
       tf_barrier();
-      constexpr int AR = ONE_MT ? 1 : (N16 ? 4 : 3);        // A fragments are requested AR tiles ahead
+      constexpr int AR = ONE_MT ? 1 : 3;                    // A fragments are requested AR tiles ahead
       static_assert(ONE_MT || NSLOT % AR == 0, "A ring");
       frag Af[AR];
       for (int q = 0; q < NC; ++q) {
@@ -212,15 +202,10 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
           for (int rep = 1; rep < dbg_repeat; ++rep) {      // DD_DCONV_REPEAT: timing diagnostic only (results are then wrong)
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) {
-              if constexpr (N16) {
-                acc[i] = DD_MFMA16(Af[i % AR].x, Bf[i].x, acc[i]);
-                acc[i] = DD_MFMA16(Af[i % AR].y, Bf[i].y, acc[i]);
-              } else {
-                acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
-                acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
-                acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
-                acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
-              }
+              acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
+              acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
+              acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
+              acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -239,15 +224,10 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
           } else {
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) {
-              if constexpr (N16) {
-                acc[i] = DD_MFMA16(Af[i % AR].x, Bf[i].x, acc[i]);
-                acc[i] = DD_MFMA16(Af[i % AR].y, Bf[i].y, acc[i]);
-              } else {
-                acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
-                acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
-                acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
-                acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
-              }
+              acc[i] = DD_MFMA(Af[i % AR].x, Bf[i].x, acc[i]);
+              acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
+              acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
+              acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
               bload(i, qn, kyn, ntn);
               Af[i % AR] = *(const frag*)(lbase + aoff[(i + AR) % NSLOT] + (i + AR < NSLOT ? ky : kya) * (G::ROWF * 4));
               __builtin_amdgcn_sched_barrier(0);
@@ -284,7 +264,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
     // at their shifts.  Tap column K-1 (shift 0) goes first and is STORED (its tiles cover pixels [0, n_mt*TW); the HALO pixels
     // beyond are zeroed in the same phase), the others are added in K-1 barrier-separated passes.
     float* img = &lds[par ^ 1][0];
-    constexpr int LPP = N16 ? 4 : 8;                         // lanes per pixel of the write-out (16 bytes each)
+    constexpr int LPP = 8;                                   // lanes per pixel of the write-out (16 bytes each)
     constexpr int WIT = ((IWP + G::HALO) * LPP + TF_THREADS - 1) / TF_THREADS;      // out_w <= n_mt*TW + HALO <= IWP + HALO
     const int c4 = 4 * (tid % LPP), cch = 32 * cur.nt + c4;  // 512 % LPP == 0: a thread always writes the same channel group
     f32x4 bvec = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -301,7 +281,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
             float* p0 = img + ioff_lane + s_mt[i] * (TW * P);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-              float* pe = p0 + ((N16 ? e : (e & 3) + 8 * (e >> 2)) + shift) * P;
+              float* pe = p0 + ((e & 3) + 8 * (e >> 2) + shift) * P;
               if (pass == K - 1) *pe = acc[i][e]; else *pe += acc[i][e];
             }
           }
@@ -539,7 +519,7 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   const int k = d->kh, dl = d->dil_h;
   if (d->pad_h != dl * (k - 1) || d->pad_w != dl * (k - 1)) return false;                    // the full transposed form only
   if (d->out_h < d->in_h + dl * (k - 1) || d->out_w < d->in_w + dl * (k - 1)) return false;  // every partial lands inside the row
-  if (d->cin % 8 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
+  if (d->cin % 8 || d->cout <= 16 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
   if (((uintptr_t)bias & 15) != 0) return false;
   if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;      // rejected offsets must stay rejected with a row offset added
   const int grid = dd_cu_budget_internal() & ~7;
@@ -558,7 +538,6 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   } while (0)
   if (k == 7 && dl == 7 && d->cout > 16 && d->in_w <= 256) DD_TF(7, 7, 7, 0, 256);
   if (k == 7 && dl == 7 && d->cout > 16 && d->in_w <= 320) DD_TF(7, 7, 9, 1, 320);
-  if (k == 7 && dl == 7 && d->cout <= 16 && d->in_w <= 352) DD_TF(7, 7, 20, 2, 352);
 #undef DD_TF
   return false;
 }
