@@ -63,8 +63,8 @@ CASES = [
     ("up2_257_nine_tiles", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (1, 64, 3, 257)),  # ... 63 tiles, one pixel in the last m-tile
     ("up2_320_ten_full", lambda: nn.ConvTranspose2d(64, 64, 7, dilation=7), (1, 64, 2, 320)),     # ... widest row, two column tiles
     ("up3_352_widest", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 2, 352)),
-    ("up3_17_two_tiles", lambda: nn.ConvTranspose2d(32, 8, 7, dilation=7), (1, 32, 8, 17)),       # Cout 8 on the 16-wide form
-    ("up3_full_width", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 9, 340)),      # ... 16-wide tiles, 154 over 8 waves
+    ("up3_17_two_tiles", lambda: nn.ConvTranspose2d(32, 8, 7, dilation=7), (1, 32, 8, 17)),       # Cout 8 on the 16-wide form, two 16-pixel tiles
+    ("up3_full_width", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 9, 340)),      # Cout 16: the gather kernel's 16-wide form at full width
     ("up2_wide_2img", lambda: nn.ConvTranspose2d(64, 32, 7, dilation=7), (2, 64, 40, 100)),
     ("up3_tall", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 70, 30)),
     ("up4_d3_wide", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (1, 16, 60, 140)),
