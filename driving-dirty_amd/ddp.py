@@ -23,9 +23,19 @@ hide under.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): ONE ring move
 What is then left after the last byte is one 128 MB piece's Adam pass (0.35 ms) plus the small tensors: ~8.3 ms per
 step = 7.5x.  >= 6x needs the 8-GPU step <= 10.4 ms, i.e. at most 2.6 ms of exposed communication.  Constructing a
 GradSync broadcasts rank 0's parameters and buffers, so ranks cannot start from different weights.
+
+Frozen parameters (the reference's fine-tuning modules start with ``self.ae.freeze()`` and call ``self.ae.unfreeze()`` at
+``unfreeze_epoch_no``: roadmap_bce_v2.py:45-47,127-129, spatial_w_rm.py:45-48,148-150, roadmap_pretrain_ae.py:131): torch
+refuses a gradient hook on a tensor that does not require gradients, so only trainable parameters are hooked, and the
+others are hooked the moment they become trainable -- ``LightningModule.unfreeze()`` calls ``refresh()`` on every live
+GradSync (``lightning.on_unfreeze``), and ``finish()`` catches whatever was switched on by hand (``p.requires_grad_(True)``)
+since: such a gradient is reduced there, synchronously, and hooked from then on.  Every rank takes the same decisions (the
+epoch counter is the same everywhere), so the collectives still pair up.
 """
 import torch
 import torch.distributed as dist
+
+from . import lightning
 
 
 class GradSync:
@@ -52,9 +62,18 @@ class GradSync:
         self._by_param = {}
         self._small = []
         self._hooks = []
-        if self.active:
-            for p in self.params:
+        self._hooked = set()
+        self.refresh()
+        lightning.on_unfreeze(self)
+
+    def refresh(self):
+        """Hook every parameter that requires a gradient and has no hook yet (called again after an ``unfreeze()``)."""
+        if not self.active:
+            return
+        for p in self.params:
+            if p.requires_grad and p not in self._hooked:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                self._hooked.add(p)
 
     @property
     def grad_scale(self):
@@ -93,6 +112,18 @@ class GradSync:
 
     def finish(self):
         """Reduce the small gradients in one message and wait for everything in flight."""
+        if self.active:
+            # parameters switched to requires_grad by hand since the last refresh(): their hooks did not exist during this
+            # backward, so their gradients are still local -- reduce them here (with the small tensors, or by themselves when
+            # big) and hook them for the steps to come
+            late = [p for p in self.params if p.requires_grad and p not in self._hooked and p.grad is not None]
+            for p in late:
+                if p.grad.numel() >= self.big_numel:
+                    self._handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:
+                    self._small.append(p)
+            if late:
+                self.refresh()
         if self.active and self._small:
             flat = torch.cat([p.grad.reshape(-1) for p in self._small])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -117,3 +148,5 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._hooked = set()
+        self.active = False

@@ -8,10 +8,19 @@ provided here with the same names and meaning: ``hparams``, ``current_epoch``, `
 Checkpoints are ``{'state_dict': ..., 'hparams': vars(hparams)}`` dicts, the layout Lightning
 0.7.5 writes, so reference ``.ckpt`` files load.
 """
+import weakref
 from argparse import Namespace
 
 import torch
 from torch import nn
+
+# objects with a ``refresh()`` that must hear about parameters becoming trainable: the data-parallel gradient hooks
+# (ddp.GradSync) and the optimizer's early-step hooks (optim.HipAdam) can only be registered on tensors that require gradients
+_UNFREEZE_LISTENERS = weakref.WeakSet()
+
+
+def on_unfreeze(listener):
+    _UNFREEZE_LISTENERS.add(listener)
 
 
 class LightningModule(nn.Module):
@@ -31,6 +40,8 @@ class LightningModule(nn.Module):
         for p in self.parameters():
             p.requires_grad = True
         self.train()
+        for listener in list(_UNFREEZE_LISTENERS):
+            listener.refresh()
 
     # --- reference call sites: roadmap_bce_v2.py:43; spatial_w_rm.py:43
     @classmethod

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from . import ops
+from . import lightning, ops
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -18,6 +18,8 @@ class HipAdam(torch.optim.Optimizer):
         self._pending = []
         self._early = set()
         self._hooks = []
+        self._hooked = set()
+        self._big_numel = 1 << 20
         self._scale = 1.0
         self._sync = None
 
@@ -70,11 +72,23 @@ class HipAdam(torch.optim.Optimizer):
         self._scale = grad_scale
         self._sync = grad_sync
         self._pending = []
+        self._big_numel = big_numel
+        self._hooked = set()
         ops.MFMA_PHASE_HOOKS.append(self._flush_pending)
+        self.refresh()
+        lightning.on_unfreeze(self)
+
+    def refresh(self):
+        """Hook the big parameters that require a gradient and are not hooked yet: a frozen feature extractor
+        (roadmap_bce_v2.py:45-47) gets its hooks when ``LightningModule.unfreeze()`` switches it on.  A big parameter
+        that was never hooked is simply updated in ``step()`` with the small ones."""
+        if self._side is None:
+            return
         for group in self.param_groups:
             for p in group["params"]:
-                if p.requires_grad and p.numel() >= big_numel:
+                if p.requires_grad and p.numel() >= self._big_numel and p not in self._hooked:
                     self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, g=group: self._early_step(q, g)))
+                    self._hooked.add(p)
 
     def close(self):
         """Undo overlap_with_backward: remove the gradient hooks and the backward-phase callback (an optimizer that is dropped
@@ -82,6 +96,7 @@ class HipAdam(torch.optim.Optimizer):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._hooked = set()
         if self._flush_pending in ops.MFMA_PHASE_HOOKS:
             ops.MFMA_PHASE_HOOKS.remove(self._flush_pending)
         if self._side is not None:

@@ -87,6 +87,120 @@ def _bcast_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+# ---- frozen / later-unfrozen parameters (the reference's freeze -> unfreeze flow: roadmap_bce_v2.py:45-47,127-129) ----------------
+class _FineTune(torch.nn.Module):
+    """A frozen feature extractor under a trainable head, as RoadMapBCE / BBSpatialRoadMap build them."""
+
+    def __init__(self):
+        super().__init__()
+        from driving_dirty_amd.lightning import LightningModule
+
+        class _AE(LightningModule):
+            def __init__(self):
+                super().__init__()
+                self.body = torch.nn.Sequential(torch.nn.Linear(12, 512), torch.nn.Tanh(), torch.nn.Linear(512, 16), torch.nn.Tanh())
+
+            def forward(self, x):
+                return self.body(x)
+        torch.manual_seed(11)
+        self.ae = _AE()
+        self.ae.freeze()
+        self.head = torch.nn.Linear(16, 3)
+
+    def forward(self, x):
+        return self.head(self.ae(x))
+
+
+def _ft_batch(step, rank):
+    g = torch.Generator().manual_seed(500 + 10 * step + rank)
+    return torch.randn(4, 12, generator=g), torch.randn(4, 3, generator=g)
+
+
+def _ft_loss(net, step, rank):
+    x, y = _ft_batch(step, rank)
+    return torch.nn.functional.mse_loss(net(x), y)
+
+
+def _unfreeze(net, how):
+    if how == "lightning":
+        net.ae.unfreeze()                      # LightningModule.unfreeze(): notifies the live GradSync (lightning.on_unfreeze)
+    else:
+        for p in net.ae.parameters():          # by hand: no notification, GradSync.finish() has to notice
+            p.requires_grad_(True)
+        net.ae.train()
+
+
+def _frozen_worker(rank, world, port, out, how):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from driving_dirty_amd.ddp import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _FineTune()
+    sync = GradSync(net, big_numel=4096, chunk_numel=5000)      # constructing it over frozen parameters must not raise
+    assert len(sync._hooks) == 2                                  # only the head is hooked
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    for step in range(4):
+        if step == 1:
+            _unfreeze(net, how)
+        net.zero_grad(set_to_none=True)
+        _ft_loss(net, step, rank).backward()
+        if step == 0:
+            assert all(p.grad is None for p in net.ae.parameters())
+        if step >= 1 and how == "lightning":
+            assert sync.pieces(net.ae.body[0].weight) is not None          # already on the asynchronous big-tensor path
+        if step >= 2:
+            assert sync.pieces(net.ae.body[0].weight) is not None          # hooked by finish() of step 1 at the latest
+        sync.finish()
+        for p in net.parameters():
+            if p.grad is not None:
+                p.grad.mul_(sync.grad_scale)
+        opt.step()
+    torch.save(net.state_dict(), f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("how", ["lightning", "by_hand"])
+def test_gradsync_on_a_frozen_model_and_unfreeze_later(tmp_path, how):
+    """GradSync over a model whose feature extractor is frozen (torch refuses gradient hooks there), unfrozen after step 0 --
+    through LightningModule.unfreeze() or by plain requires_grad_(True): the replicas stay bit-identical through step 3 and
+    equal a single process fed the summed gradients."""
+    sys.path.insert(0, ROOT)
+    out = str(tmp_path / "f.pt")
+    port = 36500 + os.getpid() % 2000 + (7 if how == "by_hand" else 0)
+    mp.spawn(_frozen_worker, args=(2, port, out, how), nprocs=2, join=True)
+    sd0, sd1 = torch.load(out + ".0"), torch.load(out + ".1")
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                   # as on the ranks: one summation order
+    try:
+        net = _FineTune()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+        for step in range(4):
+            if step == 1:
+                _unfreeze(net, "by_hand")
+            sums = None
+            for rank in range(2):
+                net.zero_grad(set_to_none=True)
+                _ft_loss(net, step, rank).backward()
+                g = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+                sums = g if sums is None else [None if a is None else a + b for a, b in zip(sums, g)]
+            for p, g in zip(net.parameters(), sums):
+                p.grad = None if g is None else g * 0.5
+            opt.step()
+    finally:
+        torch.set_num_threads(threads)
+    ref = net.state_dict()
+    for k in ref:
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged: {k}"
+        assert torch.equal(sd0[k], ref[k]), f"differs from the single process fed the summed gradients: {k}"
+    moved = (ref["ae.body.0.weight"] - _FineTune().state_dict()["ae.body.0.weight"]).abs().max()
+    assert float(moved) > 0                                                  # the unfrozen extractor did train
+
+
 def test_bench_parent_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus N` without a launcher: the parent starts N children with RANK / WORLD_SIZE / MASTER_* set and
     returns their status without importing torch or touching a GPU itself (here the children stop at the GPU check)."""
@@ -146,9 +260,6 @@ def _adam_worker(rank, world, port, out):
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, f"{out}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
-
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
