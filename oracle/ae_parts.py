@@ -4,8 +4,8 @@ Follows reference ``src/autoencoder/components.py``:
   * ``FcBlock``      <- ``DenseBlock``  (components.py:96-109)
   * ``EncoderNet``   <- ``Encoder``     (components.py:6-52)
   * ``DecoderNet``   <- ``Decoder``     (components.py:55-93)
-and ``src/autoencoder/components_v2.py`` (``EncoderNetV2``: hand-composed, the class cannot construct;
-``DecoderNetV2`` <- ``Decoder`` :59-98, which can).
+and ``src/autoencoder/components_v2.py`` (``EncoderNetV2`` <- ``Encoder.forward`` :43-57, pinned by fixtures the class's own
+forward produced on an instance assembled without the broken constructor; ``DecoderNetV2`` <- ``Decoder`` :59-98).
 
 The classes register their parameters under the SAME attribute names as the
 reference so ``state_dict()`` keys are interchangeable, and they draw from the
@@ -170,9 +170,11 @@ class DecoderNetV2(nn.Module):
 class EncoderNetV2(nn.Module):
     """Conv -> BatchNorm2d -> ReLU variant, reference src/autoencoder/components_v2.py:6-57.
 
-    That class cannot be constructed (``self.bn3 = nn.Conv2d(32)``, components_v2.py:24, raises TypeError), so there is
-    nothing to import: this is a hand-composed F.conv2d -> F.batch_norm -> relu chain with ``bn3 = BatchNorm2d(32)`` as
-    the evident intent.  PARITY UNPINNED for this variant: no reference run exists to capture fixtures from.
+    The class's constructor raises (``self.bn3 = nn.Conv2d(32)``, components_v2.py:24), but only that line is broken: its
+    ``forward`` (:43-57) and ``_calculate_output_dim`` (:36-41) run on an instance assembled without ``__init__`` with
+    ``bn3 = BatchNorm2d(32)``, the one stated interpretation.  tests/golden/make_golden.py does exactly that and commits the
+    outputs (``tiny_encoder_v2.npz``, ``full_encoder_v2.npz``); tests/test_oracle_golden.py holds this restatement to them
+    (fp32 2e-6, fp64 1e-12 / 1e-10 at 256 x 1836).  PINNED.
     """
 
     def __init__(self, hidden_dim, latent_dim, in_channels, input_height, input_width):

@@ -8,7 +8,8 @@ Runs only in the build container (needs /root/reference on disk; the GPU box nev
 It imports the two torch-only reference files
     src/autoencoder/components.py                       (Encoder, Decoder, DenseBlock)
     src/bounding_box_model/spatial_bb/components.py     (SpatialMappingCNN, BoxesMergingCNN, RoadMapBoxesMergingCNN)
-and, for the box rasteriser, src/utils/bb_to_img.py (numpy + Pillow),
+and src/autoencoder/components_v2.py (Decoder; Encoder through its own forward, see _reference_encoder_v2) and, for the
+box rasteriser, src/utils/bb_to_img.py (numpy + Pillow),
 fills their parameters and inputs from the closed-form generator in
 ``driving_dirty_amd.synth`` (so every consumer can rebuild the same tensors without the
 reference), runs forward + backward in fp32 and fp64 and stores outputs / gradients.
@@ -327,6 +328,95 @@ def full_decoder_v2(out):
     np.savez_compressed(out, **res)
 
 
+def _reference_encoder_v2(hidden_dim, latent_dim, in_channels, input_height, input_width):
+    """An instance of the reference's components_v2.Encoder assembled WITHOUT its ``__init__``: that constructor raises at
+    ``self.bn3 = nn.Conv2d(32)`` (components_v2.py:24), the one broken line of the class.  Everything the constructor would have
+    set is set here in its order (components_v2.py:13-33) with ``bn3 = BatchNorm2d(32)`` -- the one stated interpretation --,
+    the FC width comes from the class's own ``_calculate_output_dim`` and the arithmetic is the class's own ``forward``
+    (components_v2.py:43-57), so the fixtures below are outputs of reference code, not of a restatement."""
+    from torch import nn
+    from src.autoencoder.components_v2 import Encoder as EncoderV2, DenseBlock as DenseBlockV2  # reference
+    enc = EncoderV2.__new__(EncoderV2)
+    nn.Module.__init__(enc)
+    enc.hidden_dim, enc.latent_dim = hidden_dim, latent_dim
+    enc.input_height, enc.input_width, enc.in_channels = input_height, input_width, in_channels
+    enc.c1 = nn.Conv2d(in_channels, 32, kernel_size=3, padding=1)
+    enc.bn1 = nn.BatchNorm2d(32)
+    enc.c2 = nn.Conv2d(32, 32, kernel_size=3, padding=1)
+    enc.bn2 = nn.BatchNorm2d(32)
+    enc.c3 = nn.Conv2d(32, 32, kernel_size=3, stride=2, padding=1)
+    enc.bn3 = nn.BatchNorm2d(32)
+    enc.pooling_size = 4
+    conv_out_dim = enc._calculate_output_dim(in_channels, input_height, input_width, enc.pooling_size)
+    enc.fc1 = DenseBlockV2(conv_out_dim, hidden_dim)
+    enc.fc2 = DenseBlockV2(hidden_dim, hidden_dim)
+    enc.fc_z_out = nn.Linear(hidden_dim, latent_dim)
+    enc.c3_only = False
+    for m in enc.modules():
+        if isinstance(m, DenseBlockV2):
+            m.drop_p = 0.0
+    return enc
+
+
+def _encoder_v2_case(res, prefix, h, w, b, seed, xsalt, wzsalt, wfsalt, full):
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        enc = synth.fill_module(_reference_encoder_v2(16, 8, 3, h, w), seed=seed).to(dt)
+        x = synth.hash_uniform((b, 3, h, w), synth.key_salt(xsalt), 0.0, 1.0).to(dt)
+        wz = synth.hash_uniform((b, 8), synth.key_salt(wzsalt)).to(dt)
+        enc.train()
+        z = enc(x)                                               # the reference class's own forward
+        (z * wz).sum().backward()
+        res[f"{prefix}z_{tag}"] = _np(z)
+        for k, g in _grads(enc).items():
+            if g.numel() <= 40000:
+                res[f"{prefix}grad.{k}_{tag}"] = _np(g)
+            else:
+                res[f"{prefix}gradsamp.{k}_{tag}"], res[f"{prefix}gradidx.{k}"] = _sample(g, 512)
+        for k, v in enc.named_buffers():
+            res[f"{prefix}buf.{k}_{tag}"] = _np(v)
+        # feature exit (c3_only) from the same starting state, with an explicit upstream gradient
+        enc = synth.fill_module(_reference_encoder_v2(16, 8, 3, h, w), seed=seed).to(dt)
+        enc.train()
+        enc.c3_only = True
+        feat = enc(x)
+        wf = synth.hash_uniform(tuple(feat.shape), synth.key_salt(wfsalt)).to(dt)
+        (feat * wf).sum().backward()
+        if full:
+            res[f"{prefix}feat_samp_{tag}"], res[f"{prefix}feat_idx"] = _sample(feat, 2048)
+            res[f"{prefix}feat_sum_{tag}"] = np.array([feat.double().sum().item(), feat.double().abs().sum().item()])
+        else:
+            res[f"{prefix}feat_{tag}"] = _np(feat)
+        for k in ("c1.weight", "c1.bias", "bn1.weight", "bn1.bias", "c2.weight", "c2.bias", "bn2.weight", "bn2.bias",
+                  "c3.weight", "c3.bias", "bn3.weight", "bn3.bias"):
+            res[f"{prefix}featgrad.{k}_{tag}"] = _np(dict(enc.named_parameters())[k].grad)
+        for k, v in enc.named_buffers():
+            if k.startswith("bn"):
+                res[f"{prefix}featbuf.{k}_{tag}"] = _np(v)
+        if not full:
+            enc.c3_only = False
+            enc.eval()                                           # running statistics after the one train-mode pass above
+            with torch.no_grad():
+                res[f"{prefix}z_eval_{tag}"] = _np(enc(x))
+        del enc
+
+
+def tiny_encoder_v2(out):
+    """components_v2.Encoder(16, 8, 3, 16, {22, 70}) at B = 4 through the reference class's own forward (Conv2d -> BatchNorm2d
+    -> ReLU x3, ``c3_only`` exit, NCHW-order pool, FC tail): latent exit, feature exit, every gradient, running statistics,
+    eval mode."""
+    res = {}
+    for h, w in ((16, 22), (16, 70)):
+        _encoder_v2_case(res, f"h{h}w{w}.", h, w, 4, 41, "v2x", "v2w", "v2f", full=False)
+    np.savez_compressed(out, **res)
+
+
+def full_encoder_v2(out):
+    """components_v2.Encoder(16, 8, 3, 256, 1836) at B = 4: BatchNorm2d statistics over 1.9 M / 470 k pixels per channel."""
+    res = {}
+    _encoder_v2_case(res, "", 256, 1836, 4, 43, "v2x_full", "v2w_full", "v2f_full", full=True)
+    np.savez_compressed(out, **res)
+
+
 def tiny_ae_ckpt(out):
     """A checkpoint in the layout Lightning 0.7.5 writes for ``BasicAE`` -- ``{'state_dict': {'encoder.*', 'decoder.*'},
     'hparams': {...}}`` -- holding the REFERENCE modules' default init under the reference's seed
@@ -425,6 +515,8 @@ CASES = {
     "merge_signed": merge_signed,
     "tiny_decoder_v2": tiny_decoder_v2,
     "full_decoder_v2": full_decoder_v2,
+    "tiny_encoder_v2": tiny_encoder_v2,
+    "full_encoder_v2": full_encoder_v2,
     "tiny_ae_ckpt": tiny_ae_ckpt,
     "spatial_heads": spatial_heads,
     "box_raster": box_raster,

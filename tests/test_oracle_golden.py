@@ -186,6 +186,80 @@ def _check_grads(g, named, tag, tol, prefix=""):
             _close(_samp(p.grad, g[f"gradidx.{prefix}{k}"]), g[samp], tol, atol=tol * 1e-3)
 
 
+_V2_CONV_KEYS = ("c1.weight", "c1.bias", "bn1.weight", "bn1.bias", "c2.weight", "c2.bias", "bn2.weight", "bn2.bias",
+                 "c3.weight", "c3.bias", "bn3.weight", "bn3.bias")
+
+
+def _zero_grad_floor(g, prefix, kind, k, tag):
+    """A bias in front of a train-mode BatchNorm has an exactly-zero gradient: judged against its layer's weight gradient."""
+    if k.endswith("bias") and (k in ("c1.bias", "c2.bias", "c3.bias") or k.endswith(".fc1.bias")):
+        wk = k[:-4] + "weight"
+        for cand in (f"{prefix}{kind}.{wk}_{tag}", f"{prefix}gradsamp.{wk}_{tag}"):
+            if cand in g.files:
+                return float(np.abs(g[cand]).max())
+    return None
+
+
+def _v2_encoder_case(g, prefix, h, w, b, seed, salts, dt, tag, tol, full):
+    xs, wzs, wfs = salts
+    x = synth.hash_uniform((b, 3, h, w), synth.key_salt(xs), 0.0, 1.0).to(dt)
+    wz = synth.hash_uniform((b, 8), synth.key_salt(wzs)).to(dt)
+    enc = _drop0(synth.fill_module(ae_parts.EncoderNetV2(16, 8, 3, h, w), seed=seed)).to(dt)
+    enc.train()
+    z = enc(x)
+    (z * wz).sum().backward()
+    _close(z.detach(), g[f"{prefix}z_{tag}"], tol)
+    for k, p in enc.named_parameters():
+        floor = _zero_grad_floor(g, prefix, "grad", k, tag)
+        full_key = f"{prefix}grad.{k}_{tag}"
+        got, ref = (p.grad, g[full_key]) if full_key in g.files else (_samp(p.grad, g[f"{prefix}gradidx.{k}"]), g[f"{prefix}gradsamp.{k}_{tag}"])
+        if floor is not None:
+            assert float(np.abs(np.asarray(got, dtype=np.float64)).max()) <= 1e-4 * floor + 1e-30, k
+        else:
+            _close(got, ref, 50 * tol, atol=1e-12 if dt == torch.float64 else 1e-6)
+    for k, v in enc.named_buffers():
+        _close(v, g[f"{prefix}buf.{k}_{tag}"], tol)
+    enc = _drop0(synth.fill_module(ae_parts.EncoderNetV2(16, 8, 3, h, w), seed=seed)).to(dt)
+    enc.train()
+    enc.c3_only = True
+    feat = enc(x)
+    wf = synth.hash_uniform(tuple(feat.shape), synth.key_salt(wfs)).to(dt)
+    (feat * wf).sum().backward()
+    if full:
+        _close(_samp(feat, g[f"{prefix}feat_idx"]), g[f"{prefix}feat_samp_{tag}"], tol)
+    else:
+        _close(feat.detach(), g[f"{prefix}feat_{tag}"], tol)
+    params = dict(enc.named_parameters())
+    for k in _V2_CONV_KEYS:
+        floor = _zero_grad_floor(g, prefix, "featgrad", k, tag)
+        if floor is not None:
+            assert float(params[k].grad.abs().max()) <= 1e-4 * floor + 1e-30, k
+        else:
+            _close(params[k].grad, g[f"{prefix}featgrad.{k}_{tag}"], 50 * tol, atol=1e-12 if dt == torch.float64 else 1e-6)
+    for k, v in enc.named_buffers():
+        if k.startswith("bn"):
+            _close(v, g[f"{prefix}featbuf.{k}_{tag}"], tol)
+    if not full:
+        enc.c3_only = False
+        enc.eval()
+        _close(enc(x).detach(), g[f"{prefix}z_eval_{tag}"], tol)
+
+
+@pytest.mark.parametrize("hw", [(16, 22), (16, 70)])
+@pytest.mark.parametrize("dt,tag,tol", [(torch.float32, "f32", 2e-6), (torch.float64, "f64", 1e-12)])
+def test_tiny_encoder_v2(golden, hw, dt, tag, tol):
+    """oracle.ae_parts.EncoderNetV2 vs the fixture generated by the reference class's OWN forward (components_v2.py:43-57) on an
+    instance assembled without the broken constructor (tests/golden/make_golden.py:_reference_encoder_v2)."""
+    h, w = hw
+    _v2_encoder_case(golden("tiny_encoder_v2"), f"h{h}w{w}.", h, w, 4, 41, ("v2x", "v2w", "v2f"), dt, tag, tol, full=False)
+
+
+@pytest.mark.slow
+def test_oracle_full_size_encoder_v2(golden):
+    """The same at 256 x 1836, B = 4, fp64: BatchNorm2d statistics over 1.9 M pixels per channel."""
+    _v2_encoder_case(golden("full_encoder_v2"), "", 256, 1836, 4, 43, ("v2x_full", "v2w_full", "v2f_full"), torch.float64, "f64", 1e-10, full=True)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("dt,tag,tol", [(torch.float32, "f32", 2e-5), (torch.float64, "f64", 1e-10)])
 def test_oracle_full_size_roadmap(golden, dt, tag, tol):
