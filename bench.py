@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: 6-view scenes/sec, roadmap model, fwd + bwd + Adam, bs = 32 per GPU, fp32.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config C]
+
+``--config`` selects the BASELINE.json entry (default 2 = configs[1], the one the metric is quoted on): 3 = box head on the
+frozen encoder (bs 32 per GPU), 4 = joint roadmap + box step (bs 32 per GPU: 256 on 8 GPUs), 5 = bf16 at 2x resolution (bs 16
+per GPU: 128 on 8 GPUs).  Every config runs on any N and prints the same JSON shape.
 
 One process per GPU.  Started WITHOUT a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the
 parent process starts its N ranks itself -- N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before
@@ -47,6 +51,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json configs[N-1]: 2 roadmap (the headline), "
+                    "3 box head on the frozen encoder, 4 joint roadmap + box, 5 bf16 at 2x resolution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the config-1 / config-3 / config-5 step timings after the headline")
     ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
@@ -73,6 +79,7 @@ def launch_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = list(procs)
+    deadline = None
     while alive:
         for p in list(alive):
             code = p.poll()
@@ -83,6 +90,13 @@ def launch_ranks(n):
                 rc = code
                 for q in alive:              # a rank died: the collective would hang the others
                     q.terminate()
+                deadline = time.monotonic() + 10.0
+        if deadline is not None and alive and time.monotonic() > deadline:
+            for q in alive:                  # a rank blocked inside a collective or a GPU wait ignores SIGTERM: no GPU holder is left behind
+                q.kill()
+            for q in alive:
+                q.wait()
+            alive = []
         time.sleep(0.05)
     return rc
 
@@ -146,6 +160,48 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in p) / len(p) if p else None
 
 
+class AbiTimer:
+    """HIP events around selected C-ABI calls (``libdd_hotpath.so`` entry points), recorded on the stream the call launches on
+    (the current torch stream at the time of the call -- HipAdam's side stream for its early passes).  ``watch`` is
+    {key: (entry point, predicate over the ctypes arguments)}; one entry point = one kernel launch for the ones used here."""
+
+    def __init__(self, watch):
+        self.watch = watch
+        self.pairs = {k: [] for k in watch}
+        self.enabled = False
+
+    def install(self):
+        import torch
+        from driving_dirty_amd import _lib
+        lib = _lib.lib()
+        by_symbol = {}
+        for key, (symbol, pred) in self.watch.items():
+            by_symbol.setdefault(symbol, []).append((key, pred))
+        for symbol, cases in by_symbol.items():
+            inner = getattr(lib, symbol)
+
+            def timed(*a, _inner=inner, _cases=cases):
+                if self.enabled:
+                    for key, pred in _cases:
+                        if pred(*a):
+                            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            s.record()
+                            rc = _inner(*a)
+                            e.record()
+                            self.pairs[key].append((s, e))
+                            return rc
+                return _inner(*a)
+            setattr(lib, symbol, timed)      # every caller looks the entry point up on this CDLL object
+
+    def mean_ms(self, key):
+        p = self.pairs[key]
+        return sum(s.elapsed_time(e) for s, e in p) / len(p) if p else None
+
+
+def _desc(ref):
+    return ref._obj                          # ctypes.byref(struct) -> the struct
+
+
 def measured_traffic(pattern):
     """HBM bytes per launch from a committed rocprofv3 PMC profile (tools/pmc_traffic.py writes these files; PMC collection
     needs the profiler, so it cannot be live inside this process) -> (bytes, "profiles/<file>") or (None, None)."""
@@ -203,6 +259,9 @@ def cpu_baseline(sample_batch=4, steps=5):
         opt.step()
     dt = timed(roadmap_step)
     out = {"value": round(sample_batch / dt, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
+           "port_of": "oracle/ (plain-torch CPU restatement of the reference path; the reference itself never travels to the GPU box): "
+                      "held to the reference's own outputs by tests/golden/*.npz, which tests/golden/make_golden.py generates by "
+                      "importing /root/reference (tests/test_oracle_golden.py: fp32 2e-6, fp64 1e-12)",
            "sample": f"oracle roadmap step (config 2) fwd+bwd+Adam, bs={sample_batch}, {steps} timed steps after 1 warm-up, "
                      f"{dt:.2f} s/step, torch {torch.__version__} CPU"}
     del opt, head
@@ -305,10 +364,8 @@ def other_configs(dev, steps=5, warmup=2):
     ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, input_height=h2, input_width=6 * w2, output_height=h2, output_width=w2))
     m = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
     batch = (tuple(torch.rand(b5, 6, 3, h2, w2, device=dev)), None, tuple(torch.rand(b5, 800, 800, device=dev) < 0.3))
-    m.training_step(batch, 0)["loss"].backward()
-    m.zero_grad(set_to_none=True)
     opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()
+    opt.overlap_with_backward()           # the first step unfreezes the extractor: LightningModule.unfreeze() re-arms the hooks
 
     def bf16_step(i):
         m.zero_grad(set_to_none=True)
@@ -316,7 +373,168 @@ def other_configs(dev, steps=5, warmup=2):
         opt.step()
     finish("config5_bf16_2x_resolution_bs16", time_steps(bf16_step, steps, warmup), b5, {"dtype": "bf16 (fp32 master weights, accumulate, tail)"})
     opt.close()
+    del m, ae, opt, batch
+    torch.cuda.empty_cache()
+    # config 2 at the reference's DEFAULT width (autoencoder.py:33-34,164-166: hidden 256 / latent 128; SURVEY.md 8d "also report 256/128"):
+    # fc1 962 MB, head 328 MB, the encoder tail on the separate Linear / BatchNorm kernels
+    torch.manual_seed(SEED)
+    ae = BasicAE(Namespace(hidden_dim=256, latent_dim=128))
+    m = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500)).to(dev)
+    opt = HipAdam(m.parameters(), lr=1e-3)
+    opt.overlap_with_backward()
+    batch = synthetic_batch(dev, BATCH, 0)
+
+    def wide_step(i):
+        m.zero_grad(set_to_none=True)
+        m.training_step(batch, i)["loss"].backward()
+        opt.step()
+    finish("config2_hidden256_latent128_bs32", time_steps(wide_step, steps, warmup), BATCH, {"dtype": "f32"})
+    opt.close()
     return res
+
+
+UPCONV1_FLOP_PER_SCENE = 2.0 * 256 * 256 * 49 * 96 * 64      # RoadMapBoxesMergingCNN.up_conv_1 (components.py:135), one pass
+
+
+def box_batch(dev, batch, rank):
+    """Config 3 / 4 inputs: views + road masks as in config 2, box targets pre-rasterised (the rasteriser is
+    outside the timed region)."""
+    import torch
+    sample, _, road = synthetic_batch(dev, batch, rank)
+    g = torch.Generator(device=dev).manual_seed(SEED + 1000 + rank)
+    tgt = tuple({"bb_map": (torch.rand(800, 800, generator=g, device=dev) < 0.02).float()} for _ in range(batch))
+    return (sample, tgt, road)
+
+
+def setup_config(a, dev, rank):
+    """-> dict(model, batch, per_gpu_batch, metric, workload, dtype, flop_per_scene, timers): the BASELINE.json entry ``a.config``."""
+    import torch
+    from driving_dirty_amd.autoencoder import BasicAE
+    cfg = a.config
+    if cfg == 2:
+        model = build_model(dev)
+        model.ae.encoder.rows_per_task = a.rows_per_task
+        return dict(model=model, batch=synthetic_batch(dev, BATCH, rank), per_gpu_batch=BATCH, dtype="f32",
+                    metric="6-view scenes/sec fwd+bwd, roadmap model bs=32",
+                    workload="BASELINE configs[1]: roadmap segmentation 6x3x256x306 -> 800x800 mask, bs=32 per GPU, fp32, "
+                             "hidden %d / latent %d, encoder unfrozen, fwd+bwd+Adam" % (HIDDEN, LATENT),
+                    flop_per_scene=step_flop_per_scene())
+    torch.manual_seed(SEED)
+    if cfg in (3, 4):
+        from driving_dirty_amd.joint import JointRoadMapBBox
+        from driving_dirty_amd.spatial import BBSpatialRoadMap
+        ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT))
+        if cfg == 3:
+            model = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=10 ** 9, learning_rate=1e-3, output_img_freq=500,
+                                               mse_loss=False)).to(dev)
+            flop = (69.14 + 138.28 + 11.64) * 1e9          # head fwd + head bwd + frozen encoder fwd (SURVEY.md 8d)
+            what = ("BASELINE configs[2]: bounding-box head (SpatialMappingCNN + RoadMapBoxesMergingCNN) on the frozen AE encoder, "
+                    "6-view input, bs=32 per GPU, fp32, fwd+bwd+Adam on the heads")
+            metric = "6-view scenes/sec fwd+bwd, bbox head on frozen encoder bs=32"
+        else:
+            model = JointRoadMapBBox(Namespace(pretrained_ae=ae, learning_rate=1e-3, output_img_freq=500)).to(dev)
+            flop = step_flop_per_scene() + (69.14 + 138.28) * 1e9      # roadmap step + head fwd + head bwd (ss_conv's 0.8 GF data gradient into the encoder not counted)
+            what = ("BASELINE configs[3]: joint roadmap + bounding-box multi-task step (one shared encoder pass, both heads, summed "
+                    "losses), bs=32 per GPU (256 on 8 GPUs), fp32, fwd+bwd+Adam")
+            metric = "6-view scenes/sec fwd+bwd, joint roadmap+bbox bs=32 per GPU"
+        watch = {"up_conv_1_fwd": ("dd_dconv_fwd", lambda *x: _desc(x[5]).cin == 96 and _desc(x[5]).cout == 64),
+                 "up_conv_1_dgrad": ("dd_dconv_fwd", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96),
+                 "up_conv_1_wgrad": ("dd_dconv_wgrad", lambda *x: x[8] == 96 and x[13] == 64)}
+        return dict(model=model, batch=box_batch(dev, BATCH, rank), per_gpu_batch=BATCH, dtype="f32", metric=metric, workload=what,
+                    flop_per_scene=flop, watch=watch)
+    # config 5: bf16 mixed precision at 2x resolution (6x3x512x612), bs = 16 per GPU (128 on 8 GPUs), roadmap step
+    from driving_dirty_amd.roadmap import RoadMapBCE
+    h2, w2, b5 = 2 * H, 2 * W, 16
+    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, input_height=h2, input_width=6 * w2, output_height=h2, output_width=w2))
+    model = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(SEED + rank)
+    batch = (tuple(torch.rand(b5, 6, 3, h2, w2, generator=g, device=dev)), None, tuple(torch.rand(b5, 800, 800, generator=g, device=dev) < 0.3))
+    pooled2 = 32 * 256 * 1836 // 4
+    flop = 136.448e9 + 6.0 * (pooled2 * HIDDEN + HIDDEN * HIDDEN + HIDDEN * LATENT + LATENT * 640000)
+    is_c2 = lambda d: d.cin_real == 32 and d.stride == 1      # noqa: E731
+    watch = {"adam_fc1": ("dd_adam_step", lambda *x: x[4] >= 100_000_000),
+             "c2_fwd_bf16": ("dd_conv_bf16_fwd", lambda *x: is_c2(_desc(x[5]))),
+             "c2_dgrad_bf16": ("dd_conv_bf16_dgrad", lambda *x: is_c2(_desc(x[4]))),
+             "c2_wgrad_bf16": ("dd_conv_bf16_wgrad", lambda *x: is_c2(_desc(x[4])))}
+    return dict(model=model, batch=batch, per_gpu_batch=b5, dtype="bf16", metric="6-view scenes/sec fwd+bwd, roadmap model bf16 2x resolution bs=16 per GPU",
+                workload="BASELINE configs[4]: bf16 mixed precision (fp32 master weights, accumulation, FC tail), 2x input resolution "
+                         "6x3x512x612, bs=16 per GPU (128 on 8 GPUs), roadmap step fwd+bwd+Adam", flop_per_scene=flop, watch=watch)
+
+
+def config2_roofline(timer, ops_mod):
+    """The two c2 kernels of the headline step -> (dominant-kernel roofline dict)."""
+    wino = bool(ops_mod.WINOGRAD)
+    wino2 = wino and bool(ops_mod.WINOGRAD_2D)
+    issue = 4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0      # share of the direct form's multiplies a Winograd kernel issues
+    fwd_ms, dg_ms = timer.mean_ms("c2_fwd"), timer.mean_ms("c2_dgrad_w1")
+    assert fwd_ms is not None, "the c2 forward kernel was never launched through the timed entry point"
+    kernels = {}
+    algo = C2_FLOP_PER_SCENE * BATCH
+    fwd_bytes = PIXELS_PER_SCENE * BATCH * 260.0       # reads a1 (128 B/pixel), writes a2 (128 B/pixel) + one sign word per pixel
+    kernels["c2_forward"] = {
+        "kernel": "conv_wino2_fwd<BIAS_RELU_BITS>" if wino2 else "conv_wino_fwd" if wino else "conv_strip_fwd<32,1>",
+        "launch_ms": round(fwd_ms, 4), "launches_timed": len(timer.pairs["c2_fwd"]),
+        "issued_TFLOPs": round(algo * issue / (fwd_ms * 1e-3) / 1e12, 2), "algorithmic_equiv_TFLOPs": round(algo / (fwd_ms * 1e-3) / 1e12, 2),
+        "mfma_frac": round(algo * issue / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
+        "hbm_frac_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    if dg_ms is not None:
+        # c2's data gradient by F(2x2,3x3) (4/9 of the direct multiplies) + c1's weight gradient taken from the masked outputs in
+        # registers: 64 more MFMAs on every 256 (DESIGN.md 3.1b).  Reads g2 (128 B/pixel), one sign word and 16 B of image per pixel.
+        issued = algo * issue * (320.0 / 256.0)
+        kernels["c2_dgrad_w1"] = {
+            "kernel": "conv_wino2_fwd<RELU_BITS_W1> (c2 data gradient + fused c1 weight gradient)",
+            "launch_ms": round(dg_ms, 4), "launches_timed": len(timer.pairs["c2_dgrad_w1"]),
+            "issued_TFLOPs": round(issued / (dg_ms * 1e-3) / 1e12, 2),
+            "algorithmic_equiv_TFLOPs": round((algo + C1_WGRAD_FLOP_PER_SCENE * BATCH) / (dg_ms * 1e-3) / 1e12, 2),
+            "mfma_frac": round(issued / (dg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
+            "hbm_frac_algorithmic": round(PIXELS_PER_SCENE * BATCH * 148.0 / (dg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])          # the kernel with the largest in-step time
+    traffic, source = measured_traffic("*_c2_dgrad_w1_traffic.json" if dom == "c2_dgrad_w1" else "*_c2_fwd_traffic.json")
+    k = kernels[dom]
+    # hbm_frac: the MEASURED HBM bytes per launch (rocprofv3 PMC, committed profile) over this run's launch time when a traffic
+    # file exists, the algorithmic bytes otherwise
+    hbm_frac = round(traffic / (k["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else k["hbm_frac_algorithmic"]
+    # achieved = MFMA flops the kernel ISSUES per launch (a Winograd kernel issues 4/9 of the direct form's) / its mean launch
+    # duration from HIP events inside the timed region: frac <= 1 is the share of the fp32 matrix pipe in use.
+    # `algorithmic_equiv` is the direct-convolution flop count over the same time.
+    return {"kernel": k["kernel"], "bound": "mfma", "achieved": k["issued_TFLOPs"], "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+            "frac": k["mfma_frac"], "algorithmic_equiv": k["algorithmic_equiv_TFLOPs"], "hbm_frac": hbm_frac,
+            "hbm_frac_algorithmic": k["hbm_frac_algorithmic"], "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"],
+            "traffic": traffic, "traffic_source": source, "kernels": kernels}
+
+
+def watched_roofline(cfg, timer, per_gpu_batch):
+    """Configs 3 / 4 / 5: the watched C-ABI launches -> the dominant kernel's roofline."""
+    kernels = {}
+    for key in timer.pairs:
+        ms = timer.mean_ms(key)
+        if ms is None:
+            continue
+        entry = {"launch_ms": round(ms, 4), "launches_timed": len(timer.pairs[key])}
+        if cfg in (3, 4):
+            flop = UPCONV1_FLOP_PER_SCENE * per_gpu_batch
+            entry.update(kernel={"up_conv_1_fwd": "dconv_tfwd_kernel (up_conv_1 forward, input-aligned)",
+                                 "up_conv_1_dgrad": "dconv_gfwd_kernel (up_conv_1 data gradient)",
+                                 "up_conv_1_wgrad": "dconv_wgrad_kernel (up_conv_1 weight gradient)"}[key],
+                         bound="mfma", achieved=round(flop / (ms * 1e-3) / 1e12, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                         frac=round(flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4))
+        else:
+            px = 512 * 3672 * per_gpu_batch
+            nbytes = {"adam_fc1": 28.0 * (32 * 256 * 1836 // 4) * HIDDEN,      # p, g, m, v read; p, m, v written: 7 x 4 B per element
+                      "c2_fwd_bf16": px * (64 + 64 + 4.0),                    # bf16 NHWC in + out, one sign word per pixel
+                      "c2_dgrad_bf16": px * (64 + 64 + 4.0),
+                      "c2_wgrad_bf16": px * (64 + 64.0)}[key]
+            entry.update(kernel={"adam_fc1": "adam_kernel (fc1.fc1.weight, 481 M elements, side stream)", "c2_fwd_bf16": "conv_bf16_fwd (c2)",
+                                 "c2_dgrad_bf16": "conv_bf16_dgrad (c2)", "c2_wgrad_bf16": "conv_bf16_wgrad (c2)"}[key],
+                         bound="hbm", achieved=round(nbytes / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                         frac=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+        kernels[key] = entry
+    if not kernels:
+        return None
+    dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])
+    k = kernels[dom]
+    return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
+            "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"], "traffic": None, "kernels": kernels}
 
 
 def run_rank(a):
@@ -366,16 +584,19 @@ def run_rank(a):
         _ops.WINOGRAD = False
     if a.wino_1d:
         _ops.WINOGRAD_2D = False
-    model = build_model(dev)
-    model.ae.encoder.rows_per_task = a.rows_per_task
-    model.training_step(synthetic_batch(dev, 2, rank), 0)["loss"].backward()   # unfreezes the AE (epoch 0 >= 0)
-    model.zero_grad(set_to_none=True)
+    cfg = setup_config(a, dev, rank)
+    model, batch, per_gpu = cfg["model"], cfg["batch"], cfg["per_gpu_batch"]
+    # The optimizer and the gradient synchronisation are built over the model AS CONSTRUCTED -- feature extractor still frozen
+    # (roadmap_bce_v2.py:45-47, spatial_w_rm.py:45-48): the first training_step unfreezes it where the config says so, and
+    # LightningModule.unfreeze() re-arms both (ddp.GradSync.refresh, optim.HipAdam.refresh).
     opt = HipAdam(model.parameters(), lr=1e-3)
     sync = GradSync(model, reserve_cus=reserve, force_collectives=rehearse)          # broadcasts rank 0's parameters and buffers
     if not a.no_adam_overlap:
         opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if (world > 1 or rehearse) else None)
-    batch = synthetic_batch(dev, BATCH, rank)
-    timer = KernelTimer()
+    if a.config == 2:
+        timer = KernelTimer()
+    else:
+        timer = AbiTimer(cfg["watch"])
     timer.install()
 
     def step(i):
@@ -415,61 +636,26 @@ def run_rank(a):
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        value = world * BATCH * a.steps / dt
-        wino = bool(_ops.WINOGRAD)
-        wino2 = wino and bool(_ops.WINOGRAD_2D)
-        issue = 4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0      # share of the direct form's multiplies a Winograd kernel issues
-        fwd_ms, dg_ms = timer.mean_ms("c2_fwd"), timer.mean_ms("c2_dgrad_w1")
-        assert fwd_ms is not None, "the c2 forward kernel was never launched through the timed entry point"
-        kernels = {}
-        algo = C2_FLOP_PER_SCENE * BATCH
-        kernels["c2_forward"] = {
-            "kernel": "conv_wino2_fwd<BIAS_RELU_BITS>" if wino2 else "conv_wino_fwd" if wino else "conv_strip_fwd<32,1>",
-            "launch_ms": round(fwd_ms, 4), "launches_timed": len(timer.pairs["c2_fwd"]),
-            "issued_TFLOPs": round(algo * issue / (fwd_ms * 1e-3) / 1e12, 2), "algorithmic_equiv_TFLOPs": round(algo / (fwd_ms * 1e-3) / 1e12, 2),
-            "mfma_frac": round(algo * issue / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
-            # reads a1 (128 B/pixel), writes a2 (128 B/pixel) + one sign word per pixel
-            "hbm_frac": round(PIXELS_PER_SCENE * BATCH * 260.0 / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        if dg_ms is not None:
-            # c2's data gradient by F(2x2,3x3) (4/9 of the direct multiplies) + c1's weight gradient taken from the masked outputs in
-            # registers: 64 more MFMAs on every 256.  Reads g2 (128 B/pixel), one sign word and 16 B of image per pixel.
-            issued = algo * issue * (320.0 / 256.0)
-            kernels["c2_dgrad_w1"] = {
-                "kernel": "conv_wino2_fwd<RELU_BITS_W1> (c2 data gradient + fused c1 weight gradient)",
-                "launch_ms": round(dg_ms, 4), "launches_timed": len(timer.pairs["c2_dgrad_w1"]),
-                "issued_TFLOPs": round(issued / (dg_ms * 1e-3) / 1e12, 2),
-                "algorithmic_equiv_TFLOPs": round((algo + C1_WGRAD_FLOP_PER_SCENE * BATCH) / (dg_ms * 1e-3) / 1e12, 2),
-                "mfma_frac": round(issued / (dg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
-                "hbm_frac": round(PIXELS_PER_SCENE * BATCH * 148.0 / (dg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])          # the kernel with the largest in-step time
-        traffic, source = measured_traffic("*_c2_dgrad_w1_traffic.json" if dom == "c2_dgrad_w1" else "*_c2_fwd_traffic.json")
-        k = kernels[dom]
+        value = world * per_gpu * a.steps / dt
+        roof = config2_roofline(timer, _ops) if a.config == 2 else watched_roofline(a.config, timer, per_gpu)
         line = {
-            "metric": "6-view scenes/sec fwd+bwd, roadmap model bs=32",
+            "metric": cfg["metric"],
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "n_ranks_seen": n_ranks_seen,
+            "dtype": cfg["dtype"], "data": "synthetic", "n_ranks_seen": n_ranks_seen,
             **({"rehearsal": "N > 1 call pattern on a 1-rank RCCL communicator (DD_REHEARSE_RCCL=1)"} if rehearse else {}),
-            "config": {"workload": "BASELINE configs[1]: roadmap segmentation 6x3x256x306 -> 800x800 mask, "
-                                   "bs=32 per GPU, fp32, hidden %d / latent %d, encoder unfrozen, fwd+bwd+Adam" % (HIDDEN, LATENT),
-                       "global_batch": world * BATCH, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
-            "step_algorithmic_frac_of_fp32_mfma_peak": round(step_flop_per_scene() * BATCH * world / (ms * 1e-3) / 1e12
+            "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
+                       "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
+            "step_algorithmic_frac_of_fp32_mfma_peak": round(cfg["flop_per_scene"] * per_gpu * world / (ms * 1e-3) / 1e12
                                                              / (PEAK_F32_MFMA_TF * world), 4),
-            # the kernel that takes the most time in the step.  achieved = MFMA flops the kernel ISSUES per launch (a Winograd kernel
-            # issues 4/9 of the direct form's) / its mean launch duration from HIP events inside the timed region: frac <= 1 is the
-            # share of the fp32 matrix pipe in use.  `algorithmic_equiv` is the direct-convolution flop count over the same time.
-            "roofline": {"kernel": k["kernel"], "bound": "mfma", "achieved": k["issued_TFLOPs"], "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": k["mfma_frac"], "algorithmic_equiv": k["algorithmic_equiv_TFLOPs"], "hbm_frac": k["hbm_frac"],
-                         "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"],
-                         "traffic": traffic, "traffic_source": source,
-                         "kernels": kernels},
+            "roofline": roof,
         }
-        if world == 1 and not a.no_others:
+        if world == 1 and a.config == 2 and not a.no_others:
             opt.close()
-            del model, opt, sync, batch
+            del model, opt, sync, batch, cfg
             torch.cuda.empty_cache()
             line["others"] = other_configs(dev)
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.config == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1 or rehearse:

@@ -47,6 +47,7 @@ SIGNATURES = {
     "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_subsample_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_subsample_nhwc4_u8_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_copy_channels": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_deconv2x2_c32_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_conv1x1_c32_c3_nchw": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     "dd_deconv2x2_c1_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_deconv2x2_c1_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "dd_view_to_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_view_to_nhwc4_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_add": (_i32, [_p, _p, _p, _i64, _p]),
     "dd_bce_probs": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_linear_workspace_bytes": (_i64, [_i32, _i32, _i32]),
@@ -149,7 +151,7 @@ SIGNATURES = {
     "dd_adam_step_multi": (_i32, [C.POINTER(AdamTensor), _i32, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 
-ABI_VERSION = 2      # include/dd_hotpath.h: DD_ABI_VERSION
+ABI_VERSION = 3      # include/dd_hotpath.h: DD_ABI_VERSION
 _lib = None
 
 

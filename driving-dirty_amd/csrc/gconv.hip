@@ -416,6 +416,28 @@ __global__ __launch_bounds__(256) void view_to_nhwc4_kernel(const float* __restr
   }
 }
 
+// the same from a table of per-sample base pointers (each [6,3,H,W]): the collate's tuple (helper.py:22-23) without torch.stack
+struct ViewSamplePtrs {
+  const float* p[64];
+};
+
+__global__ __launch_bounds__(256) void view_to_nhwc4_ptrs_kernel(const ViewSamplePtrs samples, f32x4* __restrict__ out, int B,
+                                                                 int H, int W, int view, int tf) {
+  const int Ho = (tf == 1 || tf == 2) ? W : H, Wo = (tf == 1 || tf == 2) ? H : W;
+  const long total = (long)B * Ho * Wo, plane = (long)H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(p % Wo), i = (int)((p / Wo) % Ho);
+    const int b = (int)(p / ((long)Wo * Ho));
+    int ys, xs;
+    if (tf == 0) { ys = i; xs = j; }
+    else if (tf == 1) { ys = j; xs = W - 1 - i; }
+    else if (tf == 2) { ys = H - 1 - j; xs = i; }
+    else { ys = H - 1 - i; xs = W - 1 - j; }
+    const float* src = samples.p[b] + ((long)view * 3) * plane + (long)ys * W + xs;
+    out[p] = f32x4{src[0], src[plane], src[2 * plane], 0.f};
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
                                                   f32x4* __restrict__ out, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
@@ -960,6 +982,23 @@ int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t heig
   hipLaunchKernelGGL(view_to_nhwc4_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
                      (hipStream_t)stream, views, (f32x4*)out, batch, height, width, view, transform);
   DD_LAUNCH_CHECK("view_to_nhwc4");
+  return 0;
+}
+
+int dd_view_to_nhwc4_ptrs(const float* const* sample_ptrs, float* out, int32_t batch, int32_t height, int32_t width, int32_t view,
+                          int32_t transform, void* stream) {
+  DD_REQUIRE(sample_ptrs && out && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "view_to_nhwc4_ptrs: bad argument");
+  DD_REQUIRE(view >= 0 && view < 6 && transform >= 0 && transform <= 3, DD_ERR_BAD_ARG, "view_to_nhwc4_ptrs: view %d transform %d", view, transform);
+  for (int b0 = 0; b0 < batch; b0 += 64) {
+    const int nb = min(64, batch - b0);
+    ViewSamplePtrs tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < nb ? sample_ptrs[b0 + i] : nullptr;
+    for (int i = 0; i < nb; ++i) DD_REQUIRE(tab.p[i] != nullptr, DD_ERR_BAD_ARG, "view_to_nhwc4_ptrs: null sample pointer");
+    const long total = (long)nb * height * width;
+    hipLaunchKernelGGL(view_to_nhwc4_ptrs_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
+                       (hipStream_t)stream, tab, (f32x4*)out + (long)b0 * height * width, nb, height, width, view, transform);
+    DD_LAUNCH_CHECK("view_to_nhwc4_ptrs");
+  }
   return 0;
 }
 

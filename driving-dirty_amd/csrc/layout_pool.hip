@@ -299,6 +299,25 @@ __global__ __launch_bounds__(256) void subsample_nhwc4_kernel(const float* __res
   dst[i] = f32x4{val, 0.f, 0.f, 0.f};
 }
 
+// the same from the collate's per-sample masks where they lie: bool / uint8 [h,w] tensors (data_helper.py:137-139 hands the
+// road image over as a bool tensor), read through a pointer table -- no torch.stack, no .float() copy (spatial_w_rm.py:105)
+struct MaskPtrs {
+  const unsigned char* p[64];
+};
+
+__global__ __launch_bounds__(256) void subsample_nhwc4_u8_ptrs_kernel(const MaskPtrs masks, f32x4* __restrict__ dst, int h, int w,
+                                                                      int oh, int ow, int stride, int offset, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int v = (int)(i % ow);
+  const long r = i / ow;
+  const int u = (int)(r % oh), b = (int)(r / oh);
+  const int y = stride * u + offset, x = stride * v + offset;
+  float val = 0.f;
+  if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) val = masks.p[b][(long)y * w + x] ? 1.f : 0.f;
+  dst[i] = f32x4{val, 0.f, 0.f, 0.f};
+}
+
 }  // namespace
 
 extern "C" {
@@ -337,6 +356,23 @@ int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch,
   hipLaunchKernelGGL(stitch6_u8_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, frames, (f32x4*)wide_nhwc4,
                      batch, height, width);
   DD_LAUNCH_CHECK("stitch6_u8");
+  return 0;
+}
+
+int dd_subsample_nhwc4_u8_ptrs(const unsigned char* const* mask_ptrs, float* dst, int32_t batch, int32_t h, int32_t w, int32_t oh,
+                               int32_t ow, int32_t stride, int32_t offset, void* stream) {
+  DD_REQUIRE(mask_ptrs && dst && batch > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && stride > 0, DD_ERR_BAD_ARG,
+             "subsample_nhwc4_u8_ptrs: bad argument");
+  for (int b0 = 0; b0 < batch; b0 += 64) {
+    const int nb = min(64, batch - b0);
+    MaskPtrs tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < nb ? mask_ptrs[b0 + i] : nullptr;
+    for (int i = 0; i < nb; ++i) DD_REQUIRE(tab.p[i] != nullptr, DD_ERR_BAD_ARG, "subsample_nhwc4_u8_ptrs: null mask pointer");
+    const long total = (long)nb * oh * ow;
+    hipLaunchKernelGGL(subsample_nhwc4_u8_ptrs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tab,
+                       (f32x4*)dst + (long)b0 * oh * ow, h, w, oh, ow, stride, offset, total);
+    DD_LAUNCH_CHECK("subsample_nhwc4_u8_ptrs");
+  }
   return 0;
 }
 

@@ -93,6 +93,11 @@ DCONV = os.environ.get("DD_DCONV", "1") != "0"
 PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
 
 
+def _whole(v):
+    """The View covers every pixel of its buffer (the kernels that take whole-buffer dimensions must not be handed a window)."""
+    return v.off_h == 0 and v.off_w == 0 and v.h == v.buf.shape[1] and v.w == v.buf.shape[2]
+
+
 def _dconv_ok(d):
     return DCONV and bool(_lib.lib().dd_dconv_supported(C.byref(d)))
 
@@ -240,7 +245,7 @@ class Layer:
                 d = _desc(b, src, ddst, cs, self.cout, (1, 1), out_hw=(ih, iw), ostride=(2, 2), ooff=(ph // 2, ph % 2))
                 _wgrad(src.buf, ddst.buf, dw, db, d, ph, 4, self.cout * 4, False, self.cout, self.cin, 2 if ph > 0 else 0)
         elif (DCONV and self.k[0] == self.k[1] and self.dil[0] == self.dil[1] and self.pad == (0, 0) and src.chans == self.cin
-              and ddst.chans == self.cout and ddst.off_h == 0 and ddst.off_w == 0
+              and ddst.chans == self.cout and _whole(src) and _whole(ddst)
               and _lib.lib().dd_dconv_wgrad_supported(self.k[0], self.dil[0], self.cin, self.cout)):
             # the box heads' dilated up-convs: LDS-staged weight-gradient kernel (csrc/dconv.hip)
             lib = _lib.lib()
@@ -287,7 +292,19 @@ def channel_sum(view, out, accumulate=False):
 
 
 def view_to_nhwc4(views, view, transform):
-    """views [B,6,3,H,W] -> one view as NHWC4 with SpatialMappingCNN's rot90/flip applied (see dd_view_to_nhwc4)."""
+    """views [B,6,3,H,W] -- or the collate's tuple / list of B per-sample [6,3,H,W] tensors, read through a pointer table
+    (no torch.stack) -- -> one view as NHWC4 with SpatialMappingCNN's rot90/flip applied (see dd_view_to_nhwc4)."""
+    if isinstance(views, (tuple, list)):
+        b = len(views)
+        _, _, h, w = views[0].shape
+        for t in views:
+            if not (_chk(t, "sample").dim() == 4 and tuple(t.shape) == (6, 3, h, w)):
+                raise _lib.HotpathError(f"view_to_nhwc4: expected samples of [6,3,{h},{w}], got {tuple(t.shape)}")
+        oh, ow = (w, h) if transform in (1, 2) else (h, w)
+        out = torch.empty((b, oh, ow, 4), device=views[0].device, dtype=torch.float32)
+        table = (C.c_void_p * b)(*[t.data_ptr() for t in views])
+        check(_lib.lib().dd_view_to_nhwc4_ptrs(table, _p(out), b, h, w, view, transform, _stream()), "dd_view_to_nhwc4_ptrs")
+        return out
     b, _, _, h, w = views.shape
     oh, ow = (w, h) if transform in (1, 2) else (h, w)
     out = torch.empty((b, oh, ow, 4), device=views.device, dtype=torch.float32)

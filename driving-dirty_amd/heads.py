@@ -116,7 +116,8 @@ class SpatialMapFn(torch.autograd.Function):
     def forward(ctx, views, *params):
         cls = SpatialMapFn
         p = {n: (params[2 * i], params[2 * i + 1]) for i, n in enumerate(_ORDER)}
-        b, dev = views.shape[0], views.device
+        per_sample = isinstance(views, (tuple, list))      # the collate's tuple of [6,3,H,W] tensors: read through a pointer table
+        b, dev = (len(views), views[0].device) if per_sample else (views.shape[0], views.device)
         th = tw = None
         mosaic = None
         for name, vi, tf, tr, tc in _TILES:
@@ -132,14 +133,22 @@ class SpatialMapFn(torch.autograd.Function):
         cls.OUT.forward(p["out_conv"][0], p["out_conv"][1], View(mosaic), View(out), EPI_BIAS_RELU)
         if TRACE is not None:
             TRACE.update(mosaic=mosaic, space_out=out, tile=(th, tw))
-        ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
+        if per_sample:
+            ctx.samples = tuple(views)                      # inputs without gradients: plain references keep them alive
+            ctx.save_for_backward(mosaic, out, p["out_conv"][0])
+        else:
+            ctx.samples = None
+            ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
         ctx.tile = (th, tw)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         cls = SpatialMapFn
-        views, mosaic, out, w_out = ctx.saved_tensors
+        if ctx.samples is not None:
+            views, (mosaic, out, w_out) = ctx.samples, ctx.saved_tensors
+        else:
+            views, mosaic, out, w_out = ctx.saved_tensors
         th, tw = ctx.tile
         g = ops.relu_bwd(gout.contiguous(), out)
         grads = {}
@@ -156,9 +165,13 @@ class SpatialMapFn(torch.autograd.Function):
 
 
 def road_map_taps(rm):
-    """rm [B,1,H,W] -> the NHWC4 image of the pixels rm_conv_1 (k7, stride 3, dilation 3, padding 1: components.py:80) reads,
-    (3u - 1, 3v - 1) for u, v in [0, out + 6): on it the layer is a dense 7x7 convolution with the same products in the same
-    order, and neither the forward nor the weight gradient gathers from a 16-byte-per-pixel copy of the full mask."""
+    """rm [B,1,H,W] (or the collate's tuple of B bool / uint8 [H,W] masks, read where they lie) -> the NHWC4 image of the pixels
+    rm_conv_1 (k7, stride 3, dilation 3, padding 1: components.py:80) reads, (3u - 1, 3v - 1) for u, v in [0, out + 6): on it the
+    layer is a dense 7x7 convolution with the same products in the same order, and neither the forward nor the weight gradient
+    gathers from a 16-byte-per-pixel copy of the full mask."""
+    if isinstance(rm, (tuple, list)):
+        oh, ow = MergeFn.RM1.out_hw(rm[0].shape[-2], rm[0].shape[-1])
+        return ops.subsample_masks_nhwc4(rm, 3, -1, oh + 6, ow + 6)
     oh, ow = MergeFn.RM1.out_hw(rm.shape[-2], rm.shape[-1])
     return ops.subsample_nhwc4(rm, 3, -1, oh + 6, ow + 6)
 

@@ -13,7 +13,7 @@ from torch import nn
 from . import ops
 from .autoencoder import BasicAE
 from .lightning import LightningModule, hparam, pretrained_ae
-from .spatial import RoadMapBoxesMergingCNN, SpatialMappingCNN, bb_coord_to_map
+from .spatial import RoadMapBoxesMergingCNN, SpatialMappingCNN, bb_coord_to_map, per_sample_inputs
 
 
 class JointRoadMapBBox(LightningModule):
@@ -28,21 +28,35 @@ class JointRoadMapBBox(LightningModule):
         self.box_merge = RoadMapBoxesMergingCNN()
 
     def forward(self, x, rm):
-        """x [B,6,3,256,306], rm [B,1,800,800] -> (roadmap logits [B,800,800], box probabilities [B,800,800])."""
-        x = x.contiguous()
-        feat, z = self.ae.encoder.forward_both(ops.stitch6(x)[0])
+        """x [B,6,3,256,306], rm [B,1,800,800] -> (roadmap logits [B,800,800], box probabilities [B,800,800]).  Both may also be
+        the collate's tuples (per-sample views, bool road masks), read through pointer tables."""
+        if isinstance(x, (tuple, list)):
+            x = tuple(t.contiguous() for t in x)
+            wide4 = ops.stitch6_samples(list(x))
+        else:
+            x = x.contiguous()
+            wide4 = ops.stitch6(x)[0]
+        feat, z = self.ae.encoder.forward_both(wide4)
         logits = ops.linear(z, self.fc1.weight, self.fc1.bias).reshape(-1, 800, 800)
         boxes = self.box_merge(feat, self.space_map_cnn(x), rm).squeeze(1)
         return logits, boxes
 
     def training_step(self, batch, batch_idx):
         sample, target, road_image = batch
-        sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-        target_rm = torch.stack(tuple(road_image), dim=0).float()
-        target_bb = bb_coord_to_map(target, sample.device).to(sample.device).float()
-        logits, boxes = self(sample, target_rm.unsqueeze(1))
-        b = target_rm.size(0)
-        loss_rm = ops.BceWithLogits.apply(logits.reshape(b, -1), target_rm.reshape(b, -1))
+        if per_sample_inputs(sample, road_image) and all(t.numel() % 4 == 0 for t in road_image) and len(road_image) <= 64:
+            # roadmap_bce_v2.py:87 / spatial_w_rm.py:100-105 without the stacks: views and masks are read where the collate left them
+            dev = sample[0].device
+            b = len(sample)
+            target_bb = bb_coord_to_map(target, dev).to(dev).float()
+            logits, boxes = self(tuple(sample), tuple(road_image))
+            loss_rm, _ = ops.BceWithLogitsProbs.apply(logits.reshape(b, -1), tuple(road_image))
+        else:
+            sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+            target_rm = torch.stack(tuple(road_image), dim=0).float()
+            target_bb = bb_coord_to_map(target, sample.device).to(sample.device).float()
+            logits, boxes = self(sample, target_rm.unsqueeze(1))
+            b = target_rm.size(0)
+            loss_rm = ops.BceWithLogits.apply(logits.reshape(b, -1), target_rm.reshape(b, -1))
         loss_bb = ops.BceProbs.apply(boxes.reshape(b, -1), target_bb.reshape(b, -1))
         loss = loss_rm + loss_bb
         return {"loss": loss, "log": {"train_loss": loss, "roadmap_loss": loss_rm, "bbox_loss": loss_bb}}

@@ -137,6 +137,22 @@ def subsample_nhwc4(x, stride, offset, oh, ow):
     return out
 
 
+def subsample_masks_nhwc4(masks, stride, offset, oh, ow):
+    """Tuple / list of B per-sample bool / uint8 [H,W] masks (the collate's ``road_image`` tuple) -> [B,oh,ow,4] fp32 with
+    channel 0 = float(mask[stride*u + offset, stride*v + offset]) (zero outside): ``subsample_nhwc4`` of
+    ``torch.stack(masks).float()`` without the stack and the cast."""
+    import ctypes
+    b = len(masks)
+    h, w = masks[0].shape[-2], masks[0].shape[-1]
+    for t in masks:
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.bool, torch.uint8) and t.numel() == h * w):
+            raise _lib.HotpathError("subsample_masks_nhwc4: expected contiguous bool / uint8 device masks of one size")
+    out = torch.empty((b, oh, ow, 4), device=masks[0].device, dtype=torch.float32)
+    table = (ctypes.c_void_p * b)(*[t.data_ptr() for t in masks])
+    check(_lib.lib().dd_subsample_nhwc4_u8_ptrs(table, _p(out), b, h, w, oh, ow, stride, offset, _stream()), "dd_subsample_nhwc4_u8_ptrs")
+    return out
+
+
 def deconv2x2_c32_fwd(x, wt, bias, relu=True):
     """x [B,h,w,32] NHWC, wt [32,32,2,2] -> (relu)(ConvTranspose2d k2 s2) [B,2h,2w,32] NHWC, one launch."""
     b, h, w, c = x.shape

@@ -32,13 +32,16 @@ class SpatialMappingCNN(nn.Module):
         self.out_conv = nn.Conv2d(32, 32, kernel_size=(3, 3))
 
     def forward(self, x):
-        """(b, 6, 3, 256, 306) -> (b, 32, 256, 256), returned as an NCHW-shaped view of the NHWC result."""
-        _gpu(x, "SpatialMappingCNN")
+        """(b, 6, 3, 256, 306) -- or the collate's tuple of b [6,3,256,306] tensors, read through a pointer table instead of being
+        stacked first (spatial_w_rm.py:100-103) -- -> (b, 32, 256, 256), returned as an NCHW-shaped view of the NHWC result."""
+        per_sample = isinstance(x, (tuple, list))
+        _gpu(x[0] if per_sample else x, "SpatialMappingCNN")
         params = []
         for n in _ORDER:
             m = getattr(self, n)
             params += [m.weight, m.bias]
-        return SpatialMapFn.apply(x.contiguous(), *params).permute(0, 3, 1, 2)
+        views = tuple(t.contiguous() for t in x) if per_sample else x.contiguous()
+        return SpatialMapFn.apply(views, *params).permute(0, 3, 1, 2)
 
 
 class _Merging(nn.Module):
@@ -95,6 +98,16 @@ class RoadMapBoxesMergingCNN(_Merging):
         return self._run(ssr, spatial_map, rm)
 
 
+def per_sample_inputs(sample, road_image):
+    """True when the collate's tuples (helper.py:22-23) can be read where they lie: fp32 [6,3,H,W] views and bool / uint8 road
+    masks, contiguous, on the GPU, at most 64 x k samples of one size."""
+    if not (isinstance(sample, (tuple, list)) and isinstance(road_image, (tuple, list)) and 0 < len(sample) == len(road_image)):
+        return False
+    shape = tuple(sample[0].shape)
+    return (all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == shape and t.dim() == 4 for t in sample)
+            and all(t.is_cuda and t.is_contiguous() and t.dtype in (torch.bool, torch.uint8) and t.dim() == 2 for t in road_image))
+
+
 def bb_coord_to_map(target, device=None, rasterizer=None):
     """Targets -> [b,800,800] maps: pre-rasterised ``'bb_map'`` entries are taken as they are, a caller-supplied
     ``rasterizer`` is honoured, everything else goes through the HIP rasteriser in one launch."""
@@ -131,11 +144,15 @@ class BBSpatialRoadMap(LightningModule):
         return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
 
     def forward(self, x, rm):
-        """x [b,6,3,256,306], rm [b,1,800,800] -> [b,800,800].  spatial_w_rm.py:67-83."""
+        """x [b,6,3,256,306], rm [b,1,800,800] -> [b,800,800].  spatial_w_rm.py:67-83.  Both may also be the collate's tuples
+        (b x [6,3,256,306] views, b x bool [800,800] masks): the kernels then gather from the per-sample tensors."""
+        per_sample = isinstance(x, (tuple, list))
         space_rep = self.space_map_cnn(x)
         if self.ae.encoder.precision == "bf16":
             from . import ops_bf16
-            wide4 = ops_bf16.stitch6_bf16(x.contiguous())
+            wide4 = ops_bf16.stitch6_bf16((torch.stack(tuple(x), dim=0) if per_sample else x).contiguous())
+        elif per_sample:
+            wide4 = ops.stitch6_samples([t.contiguous() for t in x])
         else:
             wide4 = ops.stitch6(x.contiguous())[0]
         ssr = self.ae.encoder.forward_nhwc4(wide4)
@@ -148,10 +165,17 @@ class BBSpatialRoadMap(LightningModule):
 
     def _run_step(self, batch, batch_idx, step_name):
         sample, target, road_image = batch
-        sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-        target_bb_img = self.bb_coord_to_map(target, sample.device).to(sample.device).type_as(sample)
-        rm = torch.stack(tuple(road_image), dim=0).float().unsqueeze(1)
-        pred_bb_img = self(sample, rm)
+        if per_sample_inputs(sample, road_image):
+            # the collate's tuples are read where they lie (pointer tables): no torch.stack of the 180 MB of views, no stack +
+            # float() of the road masks (spatial_w_rm.py:100-105)
+            dev = sample[0].device
+            target_bb_img = self.bb_coord_to_map(target, dev).to(dev).float()
+            pred_bb_img = self(tuple(sample), tuple(road_image))
+        else:
+            sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+            target_bb_img = self.bb_coord_to_map(target, sample.device).to(sample.device).type_as(sample)
+            rm = torch.stack(tuple(road_image), dim=0).float().unsqueeze(1)
+            pred_bb_img = self(sample, rm)
         batch_size = target_bb_img.size(0)
         target_bb_img = target_bb_img.reshape(batch_size, -1)
         pred_bb_img = pred_bb_img.reshape(batch_size, -1)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 2
+#define DD_ABI_VERSION 3
 
 enum {
   DD_OK = 0,
@@ -362,12 +362,22 @@ int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, f
  * 2 = rot90(k=1, dims [3,2]) (view 1, "f"), 3 = flip([2,3]) (views 5 and 2).  Rotations swap H and W. */
 int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t height, int32_t width, int32_t view,
                      int32_t transform, void* stream);
+/* The same from a HOST array of `batch` per-sample DEVICE base pointers (each [6,3,H,W] contiguous), as dd_stitch6_ptrs:
+ * BBSpatialRoadMap._run_step receives the collate's tuple (helper.py:22-23) and torch.stack()s it (spatial_w_rm.py:100-103);
+ * this skips that 180 MB copy. */
+int dd_view_to_nhwc4_ptrs(const float* const* sample_ptrs, float* out, int32_t batch, int32_t height, int32_t width,
+                          int32_t view, int32_t transform, void* stream);
 /* rm_conv_1 (spatial_bb/components.py:80, Conv2d(1, 32, 7, stride=3, dilation=3, padding=1)) reads only the road-map pixels
  * (3u - 1, 3v - 1): dst[b][u][v] = (src[b][stride*u + offset][stride*v + offset], 0, 0, 0) (zero outside the image) is the
  * NHWC4 image on which the same taps form a DENSE k x k convolution -- same products, same order, 1/9 of the bytes.
  * src [batch,h,w] (one channel), dst [batch,oh,ow,4]. */
 int dd_subsample_nhwc4(const float* src, float* dst, int32_t batch, int32_t h, int32_t w, int32_t oh, int32_t ow,
                        int32_t stride, int32_t offset, void* stream);
+/* The same from a HOST array of `batch` per-sample DEVICE pointers to the road masks as the dataset hands them over --
+ * bool / uint8 [h,w] (data_helper.py:137-139), nonzero = 1.0: replaces torch.stack(road_image).float() of
+ * spatial_w_rm.py:105 (a stack and a 4x widening cast of the batch's masks) for the one layer that reads the mask. */
+int dd_subsample_nhwc4_u8_ptrs(const unsigned char* const* mask_ptrs, float* dst, int32_t batch, int32_t h, int32_t w,
+                               int32_t oh, int32_t ow, int32_t stride, int32_t offset, void* stream);
 /* ... and that dense convolution itself, 1 -> 32 channels, 7x7: y [batch,sh-6,sw-6,32] = (relu)(conv(taps4 channel 0) + bias),
  * w [32,1,7,7] (the parameter as it is), sw <= 320.  The taps are the K dimension of the GEMM (28 MFMAs per 32 x 32 tile
  * instead of the 98 of a channel padded to 4).  dd_conv1ch_wgrad: dw [32,1,7,7] and dbias [32] (may be NULL) from

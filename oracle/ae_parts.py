@@ -96,6 +96,10 @@ class EncoderNet(nn.Module):
         feat = self.conv_stack(x, branch)
         if self.c3_only:                      # components.py:44-45
             return feat
+        return self.tail(feat, masks, branch)
+
+    def tail(self, feat, masks=(None, None), branch=PLAIN):
+        """conv feature -> pool -> two FcBlocks -> Linear (components.py:46-52)."""
         h = self.fc1(self.pool(feat, branch), masks[0], branch, "fc1")
         h = self.fc2(h, masks[1], branch, "fc2")
         return self.fc_z_out(h)

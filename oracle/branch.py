@@ -36,6 +36,60 @@ class Branch:
         return out
 
 
+class Census:
+    """A FREE-running branch (its own F.relu / F.max_pool1d decisions, like ``PLAIN``) that compares every decision with the
+    ones another run recorded (``theirs``: name -> bool mask / winner index, e.g. taken from the product's activations) and
+    keeps the tally in ``report``.  This is what makes the same-branch comparisons checkable: replaying the product's
+    decisions proves the arithmetic on the product's linear piece; the census proves that piece is the right one -- the two
+    runs may only differ at units whose fp64 pre-activation is within rounding of zero (pool: windows whose two candidates
+    are within rounding of each other).  A kernel that wrongly zeroes a region of a ReLU layer shows up here as units that
+    differ at a large fp64 pre-activation.
+
+    report[name] = {"kind", "units", "differ", "worst", "peak"}: ``worst`` is the largest |fp64 pre-activation| among the
+    differing ReLU units (pool: the largest gap between this run's winner and the other run's winner), ``peak`` the
+    largest |pre-activation| of the layer (pool: the largest |entry|)."""
+    replay = False
+
+    def __init__(self, theirs):
+        self.theirs = theirs
+        self.report = {}
+        self.masks = {}
+
+    def relu(self, x, name):
+        own = x > 0
+        diff = own != self.theirs[name].to(device=x.device)
+        n = int(diff.sum())
+        xd = x.detach()
+        self.report[name] = {"kind": "relu", "units": x.numel(), "differ": n, "peak": float(xd.abs().max()),
+                             "worst": float(xd[diff].abs().max()) if n else 0.0}
+        self.masks[name] = own
+        return F.relu(x)
+
+    def max_pool1d(self, flat, kernel, name):
+        out, idx = F.max_pool1d(flat, kernel, return_indices=True)
+        theirs = self.theirs[name].to(flat.device)
+        diff = idx != theirs
+        n = int(diff.sum())
+        gap = (out - torch.gather(flat, 2, theirs)).detach()
+        self.report[name] = {"kind": "pool", "units": idx.numel(), "differ": n, "peak": float(flat.detach().abs().max()),
+                             "worst": float(gap[diff].abs().max()) if n else 0.0}
+        self.masks[name] = idx
+        return out
+
+    def check(self, max_frac=1e-5, eps=2e-5, per_layer=None):
+        """Every layer: at most ``max_frac`` of its units (and never more than a handful when the layer is small) decided
+        differently, and none of those at more than ``eps`` x the layer's peak.  ``per_layer``: name -> (max_frac, eps)
+        overrides.  Returns the report; raises AssertionError naming the offending layers."""
+        bad = {}
+        for name, r in self.report.items():
+            mf, e = (per_layer or {}).get(name, (max_frac, eps))
+            allowed = max(4, int(mf * r["units"]))
+            if r["differ"] > allowed or r["worst"] > e * max(r["peak"], 1e-300):
+                bad[name] = dict(r, allowed=allowed, eps_abs=e * r["peak"])
+        assert not bad, f"decisions differ beyond rounding: {bad}\nall: {self.report}"
+        return self.report
+
+
 class _Plain:
     """No recording: plain F.relu / F.max_pool1d (what the modules do when no branch is given)."""
 

@@ -95,6 +95,27 @@ def bbox_loss(encoder, space_map, box_merge, views, rm, target_img, mse=False):
     return (F.mse_loss(p, t) if mse else F.binary_cross_entropy(p, t)), pred
 
 
+def joint_loss(encoder, head, space_map, box_merge, batch, target_img, masks=(None, None), branch=None, box_branch=None):
+    """BASELINE config 4, the joint roadmap + bounding-box step.  The reference has no joint model (its ``c3_only`` switch,
+    components.py:44-45, makes the two heads exclusive users of the encoder): per SURVEY.md 8(d) this is the composition of
+    RoadMapBCE._run_step (roadmap_bce_v2.py:66-108) and BBSpatialRoadMap._run_step (spatial_w_rm.py:67-131) on ONE pass of the
+    encoder's conv stack, losses added -- so every encoder gradient is the sum of the two single-head gradients.
+    -> (loss, loss_roadmap, loss_boxes)."""
+    from .branch import PLAIN
+    branch = PLAIN if branch is None else branch
+    box_branch = branch if box_branch is None else box_branch
+    sample, _target, road_image = batch
+    views = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+    target_rm = torch.stack(tuple(road_image), dim=0).to(head.weight.dtype)
+    b = target_rm.size(0)
+    feat = encoder.conv_stack(wide_stitch(views), branch)                              # one pass, two consumers
+    logits = F.linear(encoder.tail(feat, masks, branch), head.weight, head.bias)       # roadmap_bce_v2.py:75-81
+    loss_rm = F.binary_cross_entropy_with_logits(logits.reshape(b, -1), target_rm.reshape(b, -1))
+    pred = box_merge(feat, space_map(views, branch=box_branch), target_rm.unsqueeze(1), branch=box_branch).squeeze(1)   # spatial_w_rm.py:67-83
+    loss_bb = F.binary_cross_entropy(pred.reshape(b, -1), target_img.reshape(b, -1))   # spatial_w_rm.py:131
+    return loss_rm + loss_bb, loss_rm, loss_bb
+
+
 def threat_score(a, b):
     """helper.py:74-77."""
     tp = (a * b).sum()

@@ -126,7 +126,7 @@ def default_init(out):
     np.savez_compressed(out, **res)
 
 
-def full_roadmap(out, b=2):
+def full_roadmap(out, b=2, hidden=128, latent=64):
     """Config-2 shapes at B = 2 (``full_roadmap``: the ill-conditioned edge case, train-mode BatchNorm1d over two rows) and
     at B = 32 (``full_roadmap_b32``: the headline batch): Encoder(128, 64, 3, 256, 1836) + Linear(64, 640000) +
     BCE-with-logits.
@@ -138,9 +138,9 @@ def full_roadmap(out, b=2):
     views = synth.camera_batch(b, seed=3)
     road = synth.road_maps(b, seed=3)
     for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
-        enc = synth.fill_module(Encoder(128, 64, 3, 256, 1836), seed=3).to(dt)
+        enc = synth.fill_module(Encoder(hidden, latent, 3, 256, 1836), seed=3).to(dt)
         _set_drop(enc, 0.0)
-        head = synth.fill_module(torch.nn.Linear(64, 640000), seed=4).to(dt)
+        head = synth.fill_module(torch.nn.Linear(latent, 640000), seed=4).to(dt)
         enc.train()
         x = views.to(dt)[:, [0, 1, 2, 5, 4, 3]]
         x = x.permute(0, 2, 3, 1, 4).reshape(b, 3, 256, -1)
@@ -174,6 +174,11 @@ def full_roadmap(out, b=2):
 
 def full_roadmap_b32(out):
     full_roadmap(out, b=32)
+
+
+def full_roadmap_w256(out):
+    """The reference's DEFAULT width (autoencoder.py:33-34,164-166: hidden 256 / latent 128), config-2 shapes, B = 8."""
+    full_roadmap(out, b=8, hidden=256, latent=128)
 
 
 def full_decoder(out):
@@ -510,6 +515,7 @@ CASES = {
     "default_init": default_init,
     "full_roadmap": full_roadmap,
     "full_roadmap_b32": full_roadmap_b32,
+    "full_roadmap_w256": full_roadmap_w256,
     "full_decoder": full_decoder,
     "full_ae_step": full_ae_step,
     "merge_signed": merge_signed,

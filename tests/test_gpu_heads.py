@@ -110,76 +110,107 @@ def test_autoencoder_step_against_oracle(dev):
     assert torch.equal(x.cpu(), xr) and torch.equal(y.cpu(), yr)
 
 
-def test_spatial_heads_against_reference_golden(dev, golden):
-    """SpatialMappingCNN + RoadMapBoxesMergingCNN (and BoxesMergingCNN forward) at the reference's sizes, B = 1."""
+def test_spatial_heads_three_way(dev, golden):
+    """SpatialMappingCNN + RoadMapBoxesMergingCNN (and BoxesMergingCNN forward) at the reference's sizes, B = 1, three ways
+    (tests/_branch_check.py): fp64 oracle on the product's branch (2e-4), flip census over the chain's 8 ReLU layers, and the
+    reference-generated fixture spatial_heads.npz with per-tensor budgets (each layer alone is held to 2e-5 in test_gpu_gconv.py)."""
+    from _branch_check import fixture_entry, grads_of, merge_masks, spatial_masks, three_way
+    from driving_dirty_amd import heads
     from driving_dirty_amd.spatial import BoxesMergingCNN, RoadMapBoxesMergingCNN, SpatialMappingCNN
+    from oracle import spatial_parts
     g = golden("spatial_heads")
     sm = synth.fill_module(SpatialMappingCNN(), seed=5).to(dev)
     rb = synth.fill_module(RoadMapBoxesMergingCNN(), seed=6).to(dev)
     bm = synth.fill_module(BoxesMergingCNN(), seed=7).to(dev)
+    smr = synth.fill_module(spatial_parts.SpatialMapNet(), seed=5).double().to(dev)
+    rbr = synth.fill_module(spatial_parts.RoadBoxMergeNet(), seed=6).double().to(dev)
     views = synth.camera_batch(1, seed=5).to(dev)
     rm = synth.road_maps(1, seed=5).float().unsqueeze(1).to(dev)
     ssr = synth.hash_uniform((1, 32, 128, 918), synth.key_salt("ssr"), 0.0, 1.0).to(dev).requires_grad_(True)
-    space = sm(views)
-    assert space.shape == (1, 32, 256, 256)
-    pred = rb(ssr, space, rm)
-    assert pred.shape == (1, 1, 800, 800)
+    heads.TRACE = {}
+    try:
+        space = sm(views)
+        pred = rb(ssr, space, rm)
+        tr = heads.TRACE
+    finally:
+        heads.TRACE = None
+    assert space.shape == (1, 32, 256, 256) and pred.shape == (1, 1, 800, 800)
     wy = synth.hash_uniform(tuple(pred.shape), synth.key_salt("sp_wy")).to(dev)
     (pred * wy).sum().backward()
-    assert rel_err(_samp(space.contiguous(), g["space_idx"]), torch.from_numpy(g["space_samp_f64"])) < _budget(g, "space_samp")
-    s = g["space_sum_f64"]
-    assert abs(float(space.double().abs().sum()) - s[1]) / s[1] < CHAIN_TOL
-    assert rel_err(_samp(pred, g["pred_idx"]), torch.from_numpy(g["pred_samp_f64"])) < _budget(g, "pred_samp")
-    s = g["pred_sum_f64"]
-    assert abs(float(pred.double().abs().sum()) - s[1]) / s[1] < CHAIN_TOL
-    assert rel_err(_samp(ssr.grad, g["ssrgrad_idx"]), torch.from_numpy(g["ssrgrad_samp_f64"])) < max(1e-2, _budget(g, "ssrgrad_samp"))
-    # Gradients: this chain has 8 ReLU layers and 13 M activations; ONE activation whose fp32 value lands on the
-    # other side of zero than the fp64 value (tools/diag_chain.py finds exactly one such pixel in u4) switches a
-    # whole gradient path on or off and moves the weight gradients upstream of it by 2e-3..4e-3 of their peak.
-    # That is a property of ReLU, not of the kernels (each layer's fwd/dgrad/wgrad is held to 2e-5 in
-    # test_gpu_gconv.py, also at these full sizes: tools/diag_layer.py), so the chain is held to 5e-3 here.
-    for name, m in (("space", sm), ("rboxm", rb)):
-        for k, p in m.named_parameters():
-            key = f"grad.{name}.{k}" if f"grad.{name}.{k}_f64" in g.files else f"gradsamp.{name}.{k}"
-            ref = torch.from_numpy(g[key + "_f64"])
-            got = p.grad if key.startswith("grad.") else _samp(p.grad, g[f"gradidx.{name}.{k}"])
-            assert rel_err(got, ref) < max(5e-3, _budget(g, key)), (name, k)
+    product = dict(grads_of(sm, "space."), **grads_of(rb, "rboxm."), space=space.detach().contiguous(), pred=pred.detach(), dssr=ssr.grad)
+
+    def run_oracle(branch):
+        smr.zero_grad(set_to_none=True)
+        rbr.zero_grad(set_to_none=True)
+        a64 = ssr.detach().double().requires_grad_(True)
+        s64 = smr(views.double(), branch=branch)
+        p64 = rbr(a64, s64, rm.double(), branch=branch)
+        (p64 * wy.double()).sum().backward()
+        return dict(grads_of(smr, "space."), **grads_of(rbr, "rboxm."), space=s64.detach(), pred=p64.detach(), dssr=a64.grad)
+
+    fixture = {k: fixture_entry(g, k) for k in product if fixture_entry(g, k) is not None}
+    for name, key in (("space", "space"), ("pred", "pred"), ("dssr", "ssrgrad")):
+        fixture[name] = (g[f"{key}_samp_f64"], g[f"{key}_samp_f32"], g[f"{key}_idx"])
+    assert sorted(fixture) == sorted(product)
+    three_way("spatial_heads_b1", product, run_oracle, dict(spatial_masks(tr), **merge_masks(tr, True)), fixture)
+    for key, t in (("space", space), ("pred", pred)):
+        s = g[f"{key}_sum_f64"]
+        assert abs(float(t.double().abs().sum()) - s[1]) / s[1] < CHAIN_TOL
     with torch.no_grad():
         pred2 = bm(ssr.detach(), space.detach())
     assert rel_err(_samp(pred2, g["pred_nomap_idx"]), torch.from_numpy(g["pred_nomap_samp_f64"])) < _budget(g, "pred_nomap_samp")
 
 
-def test_bbox_training_step_against_oracle(dev):
-    """BBSpatialRoadMap.training_step (frozen encoder, BCE on probabilities) vs the CPU oracle, reference sizes, B = 1."""
+@pytest.mark.parametrize("mse", [False, True])
+def test_bbox_training_step_three_way(dev, mse):
+    """BBSpatialRoadMap.training_step (spatial_w_rm.py:97-133,146-154; frozen encoder = config 3; BCE on probabilities or the
+    ``mse_loss=True`` branch :128-129), reference sizes, B = 2, against the fp64 oracle on the product's branch (loss 1e-6,
+    every head gradient 2e-4 of peak) + flip census (encoder conv stack, SpatialMappingCNN, RoadMapBoxesMergingCNN)."""
+    from _branch_check import encoder_masks, grads_of, merge_masks, spatial_masks, three_way
+    from driving_dirty_amd import heads, ops
     from driving_dirty_amd.autoencoder import BasicAE
     from driving_dirty_amd.spatial import BBSpatialRoadMap
     from oracle import ae_parts, spatial_parts, steps
+    b = 2
     ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8))
-    model = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=5, learning_rate=1e-3, output_img_freq=500, mse_loss=False))
-    synth.fill_module(model, seed=17)
-    enc = ae_parts.EncoderNet(16, 8, 3, 256, 1836)
+    model = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=5, learning_rate=1e-3, output_img_freq=500, mse_loss=mse))
+    synth.fill_module(model, seed=19 if mse else 17)
+    enc = ae_parts.EncoderNet(16, 8, 3, 256, 1836).double()
     enc.load_state_dict(model.ae.encoder.state_dict())
     enc.c3_only = True
-    smr, rbr = spatial_parts.SpatialMapNet(), spatial_parts.RoadBoxMergeNet()
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    enc.eval()                                   # freeze() = eval mode + no grads (lightning.py)
+    smr, rbr = spatial_parts.SpatialMapNet().double(), spatial_parts.RoadBoxMergeNet().double()
     smr.load_state_dict(model.space_map_cnn.state_dict())
     rbr.load_state_dict(model.box_merge.state_dict())
-    model = model.to(dev)
-    views = synth.camera_batch(1, seed=17)
-    road = synth.road_maps(1, seed=17)
-    tgt = (synth.hash_uniform((1, 800, 800), synth.key_salt("bbt"), 0.0, 1.0) < 0.02).float()
-    batch = (tuple(views.to(dev)), ({"bb_map": tgt[0].to(dev)},), tuple(road.to(dev)))
-    out = model.training_step(batch, 0)          # epoch 0 < unfreeze_epoch_no: encoder stays frozen (config 3)
+    model, enc, smr, rbr = model.to(dev), enc.to(dev), smr.to(dev), rbr.to(dev)
+    views, road = synth.camera_batch(b, seed=17).to(dev), synth.road_maps(b, seed=17).to(dev)
+    tgt = (synth.hash_uniform((b, 800, 800), synth.key_salt("bbt"), 0.0, 1.0) < 0.02).float().to(dev)
+    batch = (tuple(views), tuple({"bb_map": tgt[i]} for i in range(b)), tuple(road))
+    ops.TRACE, heads.TRACE = {}, {}
+    try:
+        out = model.training_step(batch, 0)          # epoch 0 < unfreeze_epoch_no: the encoder stays frozen
+        tr = dict(ops.TRACE, **heads.TRACE)
+    finally:
+        ops.TRACE = heads.TRACE = None
     out["loss"].backward()
-    assert all(p.grad is None for p in model.ae.parameters())
-    with torch.no_grad():
-        for p in enc.parameters():
-            p.requires_grad_(False)
-    ref_loss, _ = steps.bbox_loss(enc, smr, rbr, views, road.float().unsqueeze(1), tgt)
-    ref_loss.backward()
-    assert abs(float(out["loss"].detach()) - float(ref_loss.detach())) / float(ref_loss.detach()) < 1e-4
-    for (k, p), (_, q) in zip(list(model.space_map_cnn.named_parameters()) + list(model.box_merge.named_parameters()),
-                              list(smr.named_parameters()) + list(rbr.named_parameters())):
-        assert rel_err(p.grad, q.grad) < 5e-3, k     # fp32 torch CPU is the yardstick here (not fp64)
+    assert model.frozen and all(p.grad is None for p in model.ae.parameters())
+    product = dict(grads_of(model.space_map_cnn, "space."), **grads_of(model.box_merge, "rboxm."), loss=out["loss"].detach())
+
+    def run_oracle(branch):
+        smr.zero_grad(set_to_none=True)
+        rbr.zero_grad(set_to_none=True)
+        space_rep = smr(views.double(), branch=branch)
+        ssr = enc(steps.wide_stitch(views).double(), branch=branch)
+        pred = rbr(ssr, space_rep, road.double().unsqueeze(1), branch=branch).squeeze(1)
+        p, t = pred.reshape(b, -1), tgt.double().reshape(b, -1)
+        loss = torch.nn.functional.mse_loss(p, t) if mse else torch.nn.functional.binary_cross_entropy(p, t)      # spatial_w_rm.py:128-131
+        loss.backward()
+        return dict(grads_of(smr, "space."), **grads_of(rbr, "rboxm."), loss=loss.detach())
+
+    masks = dict(encoder_masks(tr, pool=False), **spatial_masks(tr), **merge_masks(tr, True))
+    three_way(f"bbox_step_b2[{'mse' if mse else 'bce'}]", product, run_oracle, masks)
 
 
 def test_joint_model_equals_sum_of_heads(dev):
