@@ -72,6 +72,8 @@ class EncoderV2ConvStack(torch.autograd.Function):
         a3, m3, i3 = _finalize(s3, b * ho * wo, enc.bn3, training)
         ctx.save_for_backward(x4, u1, u2, u3, a1, a2, a3, m1, i1, m2, i2, m3, i3, w2, w3, g1, g2, g3)
         ctx.cfg = (bool(training), bool(pool))
+        if ops.TRACE is not None:      # test hook: the pre-normalisation tensors and their (scale, shift) tables -- relu(u * scale + shift) is
+            ops.TRACE.update(v2=((u1, a1), (u2, a2), (u3, a3)))      # never written, the checker recomputes it with dd_bn2d_apply_relu
         if pool:
             pooled = torch.empty((b, (32 * ho * wo) // 4), device=x4.device, dtype=torch.float32)
             check(_lib.lib().dd_pool4_bn_fwd(_p(u3), _p(a3), _p(pooled), b, ho, wo, _stream()), "dd_pool4_bn_fwd")

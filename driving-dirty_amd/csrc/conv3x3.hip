@@ -1441,46 +1441,46 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
 
   // The workgroup's four partials are added in LDS, ((w0 + w1) + (w2 + w3)), before anything goes to HBM: 16 MB of
   // partials instead of 67 (the reduce kernel reads them beside the overlapped optimizer pass, at a fraction of the
-  // HBM rate).  Two 64 KB staging areas over the rings, which nobody reads any more.
+  // HBM rate).  Two 65 KB staging areas over the rings, which nobody reads any more.  The accumulators only ever flow OUT of
+  // their registers: waves 1 and 3 store theirs, waves 0 and 2 add theirs on top with LDS float adds (one contributor per
+  // address and phase: w1 + w0 is the same number whoever arrives first, so the result stays bit-reproducible), then all 256
+  // threads add the two areas and write the block's partial.  (Reading partial sums back INTO the 256 accumulators under
+  // wave-uniform branches, as this epilogue first did, made the register allocator spill 48 registers to scratch.)
   static_assert(WPB == 4, "conv_wino2_wgrad: the in-LDS reduction is written for four waves");
-  f32x4* stage = (f32x4*)smem + (wave >> 1) * W2W_STAGE4;      // [chunk = 4p + r/4][lane] float4, + one row for the bias sums
-  auto put = [&]() {
+  const int lane_e = dd_fresh_lane();                          // the epilogue's own: no lane-derived register crosses the tile loop
+  float* stage = (float*)((f32x4*)smem + (wave >> 1) * W2W_STAGE4 + lane_e);      // [chunk = 4p + r/4][lane] float4, + one row for the bias sums
+  __syncthreads();
+  if (wave & 1) {
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) stage[(4 * p + c) * 64 + lane] = f32x4{acc[p][4 * c], acc[p][4 * c + 1], acc[p][4 * c + 2], acc[p][4 * c + 3]};
-    stage[64 * 64 + lane] = f32x4{bsum, 0.f, 0.f, 0.f};
-  };
-  auto get = [&]() {
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 v = stage[(4 * p + c) * 64 + lane];
-        acc[p][4 * c] += v.x;
-        acc[p][4 * c + 1] += v.y;
-        acc[p][4 * c + 2] += v.z;
-        acc[p][4 * c + 3] += v.w;
-      }
-    bsum += stage[64 * 64 + lane].x;
-  };
-  __syncthreads();
-  if (wave & 1) put();
-  __syncthreads();
-  if (!(wave & 1)) get();
-  __syncthreads();
-  if (wave == 2) {
-    stage = (f32x4*)smem;
-    put();
+      for (int c = 0; c < 4; ++c)
+        *(f32x4*)(stage + (4 * p + c) * 256) = f32x4{acc[p][4 * c], acc[p][4 * c + 1], acc[p][4 * c + 2], acc[p][4 * c + 3]};
+    *(f32x4*)(stage + 64 * 256) = f32x4{bsum, 0.f, 0.f, 0.f};
   }
   __syncthreads();
-  if (wave != 0) return;
-  get();
+  if (!(wave & 1)) {
 #pragma unroll
-  for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 16; ++p)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[(((long)blockIdx.x * 16 + p) * 16 + r) * 64 + lane] = acc[p][r];
-  bpart[(long)blockIdx.x * 64 + lane] = bsum;
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_fetch_add(stage + (4 * p + (r >> 2)) * 256 + (r & 3), acc[p][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(stage + 64 * 256, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  {
+    const f32x4* sa = (const f32x4*)smem;
+    const f32x4* sb = sa + W2W_STAGE4;
+    const int tid_e = lane_e + 64 * wave;
+    float* out = part + (long)blockIdx.x * 256 * 64;
+    for (int i = tid_e; i < 64 * 64; i += WPB * 64) {      // float4 i = chunk * 64 + lane holds rows 4 chunk .. + 3 of lane's column
+      const f32x4 a = sa[i], b = sb[i];
+      const int chunk = i >> 6, ln = i & 63;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[(chunk * 4 + k) * 64 + ln] = a[k] + b[k];
+    }
+    if (tid_e < 64) bpart[(long)blockIdx.x * 64 + tid_e] = sa[64 * 64 + tid_e].x + sb[64 * 64 + tid_e].x;
+  }
 }
 
 // Second stage of conv_wino2_wgrad, in two launches (one block per accumulator row would leave 17 blocks to read 64 MB):

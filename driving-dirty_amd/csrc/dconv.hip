@@ -96,7 +96,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) float lds[2][G::PX * 8];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, n = lane & 31;
+  const int n = lane & 31;
   const DcPlan plan = dc_plan(d, D);
   const int NC = d.cin >> 3;
   const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
@@ -110,9 +110,13 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
     bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && ch < d.cout) ? bias[ch] : 0.f;
   }
 
-  // ---- fill state: the 16-byte pieces this thread fetches for a tile (piece p = pixel p >> 1, channel half p & 1)
-  int voff[G::NP];
+  // ---- fill state: the 16-byte pieces this thread fetches for a tile (piece p = pixel p >> 1, channel half p & 1).  The
+  // offsets live in LDS, each thread's own column: they are computed once per tile and read once per chunk, and as NP
+  // registers held across the whole tap loop they were what the register allocator spilled to scratch (ISA: 9 scratch
+  // reloads per chunk in dconv_fwd_kernel<7,7,2>).
+  __shared__ int voff[G::NP * DC_THREADS];
   auto plan_fill = [&](const DcTile& tl) {
+    const int tid = dd_fresh_lane() + 64 * wave;
     const int tw = tl.xt + G::HALO, npc = (tl.ra + K - 1) * tw * 2;
     const int iy0 = tl.r + D * tl.a0 - d.pad_h, ix0 = tl.x0 - d.pad_w;
 #pragma unroll
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
       const int l = px / tw, lam = px - l * tw;
       const int iy = iy0 + D * l, ix = ix0 + lam;
       const bool ok = p < npc && (unsigned)iy < (unsigned)d.in_h && (unsigned)ix < (unsigned)d.in_w;
-      voff[i] = ok ? ((iy * d.in_w + ix) * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : -16;
+      voff[i * DC_THREADS + tid] = ok ? ((iy * d.in_w + ix) * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : -16;
     }
   };
 
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
     const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)tile.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
 #pragma unroll
     for (int i = 0; i < G::NP; ++i) {
-      const f32x4 v = dd_bload4(xs, voff[i]);
+      const f32x4 v = dd_bload4(xs, voff[i * DC_THREADS + tid]);
       if (tid + DC_THREADS * i < 2 * G::PX) *(f32x4*)&lds[0][(tid + DC_THREADS * i) * 4] = v;      // pieces past the tile: zeros into the slack
     }
   }
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
   for (; t < plan.total; t += gridDim.x) {
     const int tnext = t + gridDim.x;
     // ---- this wave's share of the tile
+    const int lane = dd_fresh_lane(), h = lane >> 5, n = lane & 31;      // per tile: see dd_fresh_lane
     const int tw = tile.xt + G::HALO;
     const int row = tile.ra == 4 ? (wave & 3) : wave, xh = tile.ra == 4 ? (wave >> 2) : 0;
     const int a = tile.a0 + row, oy = tile.r + D * a;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
         const int soff = last ? 0 : 32 * (q + 1);
 #pragma unroll
         for (int i = 0; i < G::NP; ++i)
-          stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, voff[i], soff, 0));
+          stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, voff[i * DC_THREADS + tid], soff, 0));
       }
       // ---- multiply chunk q out of lds[par]
       if (ntaps > 0) {
@@ -264,7 +269,10 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
         // columns unrolled, the operands of tap (ky + 1, kx) requested into the registers tap (ky, kx) has just been multiplied
         // from -- no (ky, kx) iterator, no operand-address arithmetic per tap (T(r) of the iterator loop: 17 % over its MFMAs)
         bool done = false;
-        if constexpr (!N16 && NTR <= 2) {
+        // (a whole tap row of operands is K * (8 + 4 * NTR) registers: 112 for K = 7 with two column tiles, 128 for K = 8 -- the
+        // latter, beside 64 accumulators and the staged fill, spilled to scratch INSIDE the tap loop (448 B per lane): K = 8 with
+        // two column tiles -- BoxesMergingCNN's up_conv_1 data gradient -- stays on the iterator loop below)
+        if constexpr (!N16 && NTR <= 2 && K * (8 + 4 * NTR) <= 112) {
           if (nky == K && nkx == K && dbg_repeat == 1) {
             done = true;
             f32x4 Aq0[K], Aq1[K], Bq[K][NTR];
@@ -365,6 +373,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
       }
       // ---- retire the staged pieces into the other buffer (read last one step ago, a barrier since)
       if (have_next) {
+        const int tid = dd_fresh_lane() + 64 * wave;
 #pragma unroll
         for (int i = 0; i < G::NP; ++i)
           if (tid + DC_THREADS * i < 2 * G::PX) *(f32x4*)&lds[par ^ 1][(tid + DC_THREADS * i) * 4] = stage[i];
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
       // 1.0 .. 1.2 ms of a 5.7 .. 11 ms data-gradient launch (measured by repeating the tap loop, DD_DCONV_REPEAT).
       const bool masked = epi == DD_EPI_RELU_MASK;
       const int base = ((oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
+      const int lane = dd_fresh_lane(), h = lane >> 5, n = lane & 31;      // shadows the kernel's: nothing lane-derived crosses the tap loop
       if constexpr (N16) {
         const int ch = lane & 15;
         const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
@@ -417,11 +427,20 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const float* __re
             const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
             int off[16];
             float mv[16];
+            // Element r of the 32 x 32 tile sits at pixel xw + 32j + 4h + c_r, c_r = (r & 3) + 8 (r >> 2): its byte offset is a
+            // per-lane part (one register) plus a wave-uniform part (scalar registers).  Written as one expression the
+            // lane-variant, tile-invariant terms ((4h + c_r) * cstore + ch) * 4 of all 16 elements were hoisted out of the
+            // persistent tile loop and lived across it: 16 registers the tap loop does not have (scratch spills).  The asm
+            // makes the per-lane part opaque to that hoisting.
+            int lane_off = ((4 * h) * d.out_cstore + ch) * 4;
+            int lim = d.out_w - (xw + 32 * j + 4 * h);                    // element r is inside the row iff c_r < lim
+            asm volatile("" : "+v"(lane_off), "+v"(lim));
+            lim = ch < d.cout ? lim : 0;
+            const int tile_off = (base + (xw + 32 * j) * d.out_cstore) * 4;      // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int xo = xw + 32 * j + dd_acc_row(r, lane);
-              const bool ok = xo < d.out_w && ch < d.cout;
-              off[r] = ok ? (base + xo * d.out_cstore + ch) * 4 : -16;
+              const int cr = (r & 3) + 8 * (r >> 2);
+              off[r] = cr < lim ? lane_off + (tile_off + cr * d.out_cstore * 4) : -16;
               mv[r] = 1.f;
             }
             if (masked) {      // lanes of an exempt channel ask a zero-size resource (no memory request) and keep 1
@@ -497,6 +516,8 @@ bool dc_supported(const dd_gconv_desc* d) {
 
 }  // namespace
 
+bool dd_dconv_desc_ok(const dd_gconv_desc* d) { return dc_supported(d); }      // for the launchers in dconv_t.hip
+
 extern "C" {
 
 int32_t dd_dconv_supported(const dd_gconv_desc* d) { return dc_supported(d) ? 1 : 0; }
@@ -534,7 +555,11 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
   hipStream_t st = (hipStream_t)stream;
   const int nt = d->cout <= 16 ? 0 : (d->cout + 31) / 32;
   const int wp_bytes = (int)(dd_dconv_packed_floats(d) * 4);
+#ifdef DD_TIMING_DIAG      // diagnostic builds only (hipcc -DDD_TIMING_DIAG): repeating the tap loop times it, the results are then wrong
   static const int dbg_repeat = getenv("DD_DCONV_REPEAT") ? atoi(getenv("DD_DCONV_REPEAT")) : 1;
+#else
+  constexpr int dbg_repeat = 1;
+#endif
   // the full transposed forward of the wide layers: input-aligned tiles, no border zero multiplied (dconv_t.hip)
   if (dd_dconv_tfwd_launch(x, packed, bias, y, d, epilogue, wp_bytes, st)) {
     DD_LAUNCH_CHECK("dconv_tfwd");

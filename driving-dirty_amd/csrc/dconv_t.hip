@@ -101,7 +101,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
   const int ioff_lane = 4 * (lane >> 5) * P + (lane & 31);
 
   // ---- tasks of this workgroup: XCD = blockIdx % 8 owns the x-th eighth of the (image, residue, phase row, column tile) list
-  const int per_x = gridDim.x >> 3;
+  const int per_x = gridDim.x >> 3;      // the launchers round the grid down to a multiple of 8 (one segment per XCD)
   const int xcd = blockIdx.x & 7;
   const int per_img = D * rows_max * NTC;
   const long len = (long)d.batch * per_img;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_gfwd_kernel(const float* __r
     bv[nt] = (bias && (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && ch < d.cout) ? bias[ch] : 0.f;
   }
 
-  const int per_x = gridDim.x >> 3;
+  const int per_x = gridDim.x >> 3;      // the launchers round the grid down to a multiple of 8 (one segment per XCD)
   const int xcd = blockIdx.x & 7;
   const int per_img = D * rows_max;
   const long len = (long)d.batch * per_img;
@@ -514,7 +514,8 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
                           int wp_bytes, hipStream_t st) {
   static const bool off = getenv("DD_DCONV_TFWD_OFF") && atoi(getenv("DD_DCONV_TFWD_OFF")) != 0;
   if (off) return false;
-  if (epilogue == DD_EPI_RELU_MASK) return false;
+  if (!dd_dconv_desc_ok(d)) return false;                // the shared eligibility test (stride, div, ostride, channel bounds, sizes)
+  if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU) return false;
   if (d->kh != d->kw || d->dil_h != d->dil_w) return false;
   const int k = d->kh, dl = d->dil_h;
   if (d->pad_h != dl * (k - 1) || d->pad_w != dl * (k - 1)) return false;                    // the full transposed form only
@@ -524,7 +525,11 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
   if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;      // rejected offsets must stay rejected with a row offset added
   const int grid = dd_cu_budget_internal() & ~7;
   if (grid < 8) return false;
+#ifdef DD_TIMING_DIAG      // diagnostic builds only (hipcc -DDD_TIMING_DIAG): repeating the tap loop times it, the results are then wrong
   static const int dbg_repeat = getenv("DD_DCONV_REPEAT") ? atoi(getenv("DD_DCONV_REPEAT")) : 1;
+#else
+  constexpr int dbg_repeat = 1;
+#endif
 #define DD_TF(KK, DD_, NS, MODE_, IWP_)                                                                                        \
   do {                                                                                                                         \
     using G = TfGeom<KK, DD_, MODE_, IWP_>;                                                                                    \
@@ -547,6 +552,9 @@ bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias
                           int epilogue, int wp_bytes, hipStream_t st) {
   static const bool off = getenv("DD_DCONV_GFWD_OFF") && atoi(getenv("DD_DCONV_GFWD_OFF")) != 0;
   if (off) return false;
+  if (!dd_dconv_desc_ok(d)) return false;
+  if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU && epilogue != DD_EPI_RELU_MASK) return false;
+  if (epilogue == DD_EPI_RELU_MASK && !mask) return false;
   if (d->kh != d->kw || d->dil_h != d->dil_w || d->pad_h != 0 || d->pad_w != 0) return false;
   const int k = d->kh, dl = d->dil_h, halo = dl * (k - 1);
   if (d->out_h > d->in_h - halo || d->out_w > d->in_w - halo || d->cin % 8) return false;

@@ -34,6 +34,15 @@ static inline int dd_conv_out(int in, int stride) { return (in + 2 - 3) / stride
 
 __device__ __forceinline__ int dd_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// The lane id, recomputed where it is needed: a `volatile` asm is neither hoisted nor shared, so code after a long MFMA loop
+// (an epilogue's addresses, the next tile's fill plan) does not keep lane-derived registers alive across that loop -- which is
+// what the register allocator otherwise spills to scratch in kernels that use the whole register file.
+__device__ __forceinline__ int dd_fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // Raw buffer access: the descriptor (wave-uniform base + byte count) makes the hardware range-check every lane:
 // an out-of-range load returns zeros, an out-of-range store is dropped.  A negative offset is a huge unsigned
 // one, i.e. out of range.  Used for zero padding and ragged edges without branches, and as a guard against faults.
@@ -59,6 +68,7 @@ __device__ __forceinline__ void dd_range(long total, int i, int n, long& idx, lo
 }
 
 // dconv_t.hip: the input-aligned forward of the dilated transposed layers; false = not one of its layers, nothing launched.
+bool dd_dconv_desc_ok(const dd_gconv_desc* d);      // dconv.hip: the eligibility test of dd_dconv_fwd, for its two specialised launchers
 bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias, float* y, const dd_gconv_desc* d, int epilogue,
                           int wp_bytes, hipStream_t st);
 bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,

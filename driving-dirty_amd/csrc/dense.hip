@@ -357,6 +357,22 @@ __global__ __launch_bounds__(64) void threat_final_kernel(const double* __restri
   if (k == 0) out[0] = (float)(tp / (sa + sb - tp));
 }
 
+// One element of torch.optim.Adam, written with explicit fused multiply-adds and contraction off: the vector kernel, its scalar
+// tail and the multi-tensor kernel must produce the SAME bits for the same inputs (left to the compiler, `a * b + c` was
+// contracted differently in the float4 loop and in the scalar kernels, so a tensor updated by one kernel or the other -- the
+// overlapped optimizer picks by size and timing -- ended a last bit apart).
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float gscale, float b1, float b2, float eps,
+                                          float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
+  const float gg = g * gscale;
+  const float mm = __builtin_fmaf(b1, m, (1.f - b1) * gg);
+  const float vv = __builtin_fmaf(b2, v, ((1.f - b2) * gg) * gg);
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  m = mm;
+  v = vv;
+  p = __builtin_fmaf(-step_size, mm / denom, p);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2_sqrt,
@@ -370,10 +386,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const f32x4 gv = __builtin_nontemporal_load((const f32x4*)g + i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gg = gv[k] * gscale;
-      mv[k] = b1 * mv[k] + (1.f - b1) * gg;
-      vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
-      pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
+      float pe = pv[k], me = mv[k], ve = vv[k];
+      adam_elem(pe, me, ve, gv[k], gscale, b1, b2, eps, step_size, bc2_sqrt);
+      pv[k] = pe; mv[k] = me; vv[k] = ve;
     }
     __builtin_nontemporal_store(pv, (f32x4*)p + i);
     __builtin_nontemporal_store(mv, (f32x4*)m + i);
@@ -381,12 +396,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
     const long i = 4 * n4 + threadIdx.x;
-    const float gg = g[i] * gscale;
-    const float mm = b1 * m[i] + (1.f - b1) * gg;
-    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-    m[i] = mm;
-    v[i] = vv;
-    p[i] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    float pe = p[i], me = m[i], ve = v[i];
+    adam_elem(pe, me, ve, g[i], gscale, b1, b2, eps, step_size, bc2_sqrt);
+    p[i] = pe; m[i] = me; v[i] = ve;
   }
 }
 
@@ -413,12 +425,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tab, float lr
   const int i = ((int)blockIdx.x - tab.first[t]) * 256 + threadIdx.x;
   if (i >= tab.n[t]) return;
   const float step_size = lr / bc1;
-  const float gg = g[i] * gscale;
-  const float mm = b1 * m[i] + (1.f - b1) * gg;
-  const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-  m[i] = mm;
-  v[i] = vv;
-  p[i] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  float pe = p[i], me = m[i], ve = v[i];
+  adam_elem(pe, me, ve, g[i], gscale, b1, b2, eps, step_size, bc2_sqrt);
+  p[i] = pe; m[i] = me; v[i] = ve;
 }
 
 constexpr int kLossBlocks = DD_NUM_CU * 8;

@@ -704,7 +704,9 @@ WgradPlan wgrad_plan(const dd_gconv_desc* d) {
   p.no = p.nto <= 3 ? p.nto : 2;
   p.nog = (p.nto + p.no - 1) / p.no;
   p.nj = (d->kh * d->kw * d->cin + 31) / 32;
-  static const int nb3 = getenv("DD_WGRAD_NB3") ? atoi(getenv("DD_WGRAD_NB3")) : 3, nb2 = getenv("DD_WGRAD_NB2") ? atoi(getenv("DD_WGRAD_NB2")) : 4;      // measured at bs 32: up_conv_1 12.19 -> 11.39 ms, up_conv_2 6.37 -> 6.24
+  // tuning knobs (results unchanged), clamped to the tilings the launch switch below instantiates: (2, 1..4) and (3, 1..3)
+  static const int nb3 = min(3, max(1, getenv("DD_WGRAD_NB3") ? atoi(getenv("DD_WGRAD_NB3")) : 3)),
+                   nb2 = min(4, max(1, getenv("DD_WGRAD_NB2") ? atoi(getenv("DD_WGRAD_NB2")) : 4));      // measured at bs 32: up_conv_1 12.19 -> 11.39 ms, up_conv_2 6.37 -> 6.24
   p.nb = pick_nb(p.nj, p.no, p.no == 1 ? 4 : (p.no == 2 ? nb2 : nb3));
   p.njg = (p.nj + p.nb - 1) / p.nb;
   p.njobs = p.nog * p.njg;
@@ -880,8 +882,10 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
     case 23: DD_GW(2, 3); break;
     case 24: DD_GW(2, 4); break;
     case 31: DD_GW(3, 1); break;
+    case 32: DD_GW(3, 2); break;
     case 33: DD_GW(3, 3); break;
-    default: DD_GW(3, 2); break;
+    default:      // a plan this switch has no kernel for: refuse instead of launching one built for another tiling
+      DD_REQUIRE(false, DD_ERR_UNSUPPORTED, "gconv_wgrad: no kernel for the tiling (%d, %d)", p.no, p.nb);
   }
 #undef DD_GW
   DD_LAUNCH_CHECK("gconv_wgrad");

@@ -198,12 +198,13 @@ class EncoderNetV2(nn.Module):
     def _bn(self, bn, x):
         return bn(x)      # nn.BatchNorm2d: batch statistics + running-stat update in train mode, running stats in eval
 
-    def forward(self, x, masks=(None, None)):
-        x = F.relu(self._bn(self.bn1, F.conv2d(x, self.c1.weight, self.c1.bias, padding=1)))
-        x = F.relu(self._bn(self.bn2, F.conv2d(x, self.c2.weight, self.c2.bias, padding=1)))
-        x = F.relu(self._bn(self.bn3, F.conv2d(x, self.c3.weight, self.c3.bias, stride=2, padding=1)))
+    def forward(self, x, masks=(None, None), branch=PLAIN):
+        """``branch`` (oracle.branch) records / replays / censuses the ReLU and max-pool decisions; default: plain F.relu."""
+        x = branch.relu(self._bn(self.bn1, F.conv2d(x, self.c1.weight, self.c1.bias, padding=1)), "relu1")
+        x = branch.relu(self._bn(self.bn2, F.conv2d(x, self.c2.weight, self.c2.bias, padding=1)), "relu2")
+        x = branch.relu(self._bn(self.bn3, F.conv2d(x, self.c3.weight, self.c3.bias, stride=2, padding=1)), "relu3")
         if self.c3_only:
             return x
         flat = x.reshape(x.size(0), 1, -1)
-        h = self.fc1(F.max_pool1d(flat, POOL).squeeze(1), masks[0])
-        return self.fc_z_out(self.fc2(h, masks[1]))
+        h = self.fc1(branch.max_pool1d(flat, POOL, "pool").squeeze(1), masks[0], branch, "fc1")
+        return self.fc_z_out(self.fc2(h, masks[1], branch, "fc2"))

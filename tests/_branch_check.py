@@ -47,22 +47,30 @@ def fixture_entry(g, name, prefix="", sample_prefix=None):
 
 
 def three_way(label, product, run_oracle, masks, fixture=None, floors=None, census_args=None, same_tol=SAME_BRANCH_TOL,
-              pin_tol=PIN_TOL, exact=("loss",)):
+              pin_tol=PIN_TOL, exact=("loss",), run_oracle32=None):
     """product: name -> tensor (the HIP path's results).  run_oracle(branch) -> name -> fp64 tensor, evaluated with the given
     ``oracle.branch`` object.  masks: the product's decisions (name -> bool mask / pool index).  fixture: name -> (f64, f32, idx)
     from the reference-generated file (``fixture_entry``), for the tensors it holds.  floors: name -> denominator floor for tensors
-    that are zero by construction.  Returns the table it asserted on."""
+    that are zero by construction.  run_oracle32 (ill-conditioned cases only: train-mode BatchNorm1d over a handful of rows):
+    the same oracle in fp32 -- plain torch arithmetic, the reference's own -- replaying the same branch; a tensor may then be as
+    far from the fp64 result ON THE SAME BRANCH as twice what that fp32 run is (measured per tensor; 2e-4 otherwise).
+    Returns the table it asserted on."""
     from oracle.branch import Branch, Census
     fixture, floors = fixture or {}, floors or {}
     census = Census(masks)
     free = {k: v.detach().clone() for k, v in run_oracle(census).items()}
     report = census.check(**(census_args or {}))
-    same = {k: v.detach() for k, v in run_oracle(Branch(masks)).items()}
+    same = {k: v.detach().clone() for k, v in run_oracle(Branch(masks)).items()}
+    same32 = {k: v.detach().clone() for k, v in run_oracle32(Branch(masks)).items()} if run_oracle32 is not None else None
     table, bad = {}, {}
     for k, got in product.items():
         fl = floors.get(k, 1e-30)
         row = {"same_branch": rel_err(got, same[k], fl), "branch_effect": rel_err(same[k], free[k], fl)}
         tol = 1e-6 if k in exact else same_tol
+        if same32 is not None and k not in exact:
+            row["torch_fp32_same_branch"] = rel_err(same32[k], same[k], fl)
+            tol = max(tol, 2.0 * row["torch_fp32_same_branch"])
+        row["same_branch_tol"] = tol
         if not row["same_branch"] < tol:
             bad[k] = dict(row, why=f"beyond {tol:g} of peak on the product's own branch")
         if k in fixture:
@@ -71,7 +79,11 @@ def three_way(label, product, run_oracle, masks, fixture=None, floors=None, cens
             row["oracle_vs_fixture"] = rel_err(pick(free[k]), f64, fl)
             row["ref_fp32_vs_fp64"] = float(np.abs(f64 - f32).max() / max(np.abs(f64).max(), fl))
             row["vs_fixture"] = rel_err(pick(torch.as_tensor(got)), f64, fl)
-            row["budget"] = max(TOL, 2.0 * row["ref_fp32_vs_fp64"], 1.05 * row["branch_effect"] + same_tol) if k not in exact else 1e-5
+            # the effect of the differing decisions on exactly what the fixture holds (its sample, its normalisation)
+            effect = rel_err(pick(same[k]), pick(free[k]), fl) if idx is not None else row["branch_effect"]
+            if idx is not None:
+                row["branch_effect_on_sample"] = effect
+            row["budget"] = max(TOL, 2.0 * row["ref_fp32_vs_fp64"], 1.05 * effect + tol) if k not in exact else 1e-5
             if not row["oracle_vs_fixture"] < pin_tol:
                 bad[k] = dict(row, why="the fp64 oracle run here differs from the reference-generated fixture")
             elif not row["vs_fixture"] < row["budget"]:

@@ -1,0 +1,29 @@
+"""No register spills in the shipped kernels: read from the AMDGPU metadata of the gfx950 code objects embedded in the built
+library (tools/kernel_resources.py; no GPU, no recompilation).  A kernel that uses the whole register file and then spills
+inside its MFMA loop loses more than the occupancy it bought -- and DESIGN.md rejects variants for exactly that, so the shipped
+ones are held to it too."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_kernel_spills_registers():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    ks = kernel_resources.kernels()
+    assert len(ks) > 150
+    spilled = {k[".name"]: (k.get(".vgpr_spill_count", 0), k.get(".sgpr_spill_count", 0)) for k in ks if k.get(".vgpr_spill_count", 0)}
+    assert not spilled, f"VGPR spills: {spilled}"
+    # scratch (private segment) at all: only the box rasteriser, whose per-thread span list is a genuinely indexed local array
+    scratch = {k[".name"]: k[".private_segment_fixed_size"] for k in ks if k[".private_segment_fixed_size"]}
+    assert all("raster_kernel" in n for n in scratch), scratch
+    # the kernels VERDICT r02 named
+    by = {k[".name"]: k for k in ks}
+    for frag in ("conv_wino2_wgradILi4", "dconv_fwd_kernelILi7ELi7ELi2", "dconv_fwd_kernelILi7ELi3ELi2", "dconv_fwd_kernelILi6ELi6ELi2",
+                 "dconv_fwd_kernelILi8ELi8ELi2"):
+        hit = [k for n, k in by.items() if frag in n]
+        assert hit and all(k[".private_segment_fixed_size"] == 0 for k in hit), frag
