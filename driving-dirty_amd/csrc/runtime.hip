@@ -1,5 +1,6 @@
 // Error reporting of the C ABI (thread-local message; see include/dd_hotpath.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dd_common.h"
@@ -17,6 +18,11 @@ int dd_fail(int code, const char* fmt, ...) {
 static int g_cu_budget = DD_NUM_CU;
 
 int dd_cu_budget_internal() { return g_cu_budget; }
+
+int dd_mfma_wave_priority() {      // DD_MFMA_PRIO=0..3 (A/B knob; results unchanged)
+  static const int prio = getenv("DD_MFMA_PRIO") ? max(0, min(3, atoi(getenv("DD_MFMA_PRIO")))) : DD_MFMA_PRIO_DEFAULT;
+  return prio;
+}
 
 extern "C" {
 int dd_abi_version(void) { return DD_ABI_VERSION; }
