@@ -39,6 +39,7 @@ _GP = C.POINTER(GConvDesc)
 SIGNATURES = {
     "dd_abi_version": (_i32, []),
     "dd_last_error": (C.c_char_p, []),
+    "dd_clock_probe": (_i32, [_p, _i32, _i32, _p]),
     "dd_set_cu_budget": (_i32, [_i32]),
     "dd_get_cu_budget": (_i32, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),

@@ -812,12 +812,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
                                                            const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
                                                            float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
                                                            int W, int nstrips, const float* __restrict__ x4 = nullptr,
-                                                           float* __restrict__ w1part = nullptr, int prio = 0) {
+                                                           float* __restrict__ w1part = nullptr) {
   using C = StripCfg<32, 1>;
   using C4 = StripCfg<4, 1>;
   constexpr int RINGB = 4 * C::SLOTB + C::SPILLB;
   constexpr bool W1 = (EPI == EPI_RELU_BITS_W1);
-  dd_set_wave_priority(prio);
   constexpr bool MASKED = (EPI == EPI_RELU_BITS) || W1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -1305,11 +1304,10 @@ constexpr int W2W_STAGE4 = 65 * 64;      // float4s per staging area of the fina
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                              float* __restrict__ part, float* __restrict__ bpart, int B,
-                                                             int H, int W, int nstrips, int prio = 0) {
+                                                             int H, int W, int nstrips) {
   using C = StripCfg<32, 1>;
   constexpr int RINGB = 4 * C::SLOTB + C::SPILLB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dd_set_wave_priority(prio);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1694,7 +1692,7 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
   auto k = conv_wino2_fwd<EPI, WPB>;
   if (int rc = allow_lds(k, lds)) return rc;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips,
-                     x4, w1part, dd_mfma_wave_priority());
+                     x4, w1part);
   DD_LAUNCH_CHECK("conv_wino2_fwd");
   return 0;
 }
@@ -2026,8 +2024,7 @@ int dd_conv_wino2_wgrad_partials(const float* x, const float* dy, void* workspac
   auto k = conv_wino2_wgrad<WPB>;
   const size_t lds = max((size_t)WPB * (4 * StripCfg<32, 1>::SLOTB + StripCfg<32, 1>::SPILLB), (size_t)2 * W2W_STAGE4 * 16);
   if (int rc = allow_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, (hipStream_t)stream, x, dy, part, bpart, d->batch, d->height, d->width, nstrips,
-                     dd_mfma_wave_priority());
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, (hipStream_t)stream, x, dy, part, bpart, d->batch, d->height, d->width, nstrips);
   DD_LAUNCH_CHECK("conv_wino2_wgrad");
   return 0;
 }

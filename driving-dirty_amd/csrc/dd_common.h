@@ -34,17 +34,6 @@ static inline int dd_conv_out(int in, int stride) { return (in + 2 - 3) / stride
 
 __device__ __forceinline__ int dd_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// Wave priority of the MFMA-bound c2 kernels (s_setprio takes an immediate).  They run one wave per SIMD beside the optimizer's
-// streaming pass (optim.HipAdam.overlap_with_backward), whose waves share the SIMD's issue port and vector ALUs: at a higher
-// priority the matrix wave issues whenever it is ready and the optimizer's instructions fill its gaps.
-__device__ __forceinline__ void dd_set_wave_priority(int prio) {
-  if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (prio >= 3) __builtin_amdgcn_s_setprio(3);
-}
-constexpr int DD_MFMA_PRIO_DEFAULT = 0;
-int dd_mfma_wave_priority();      // runtime.hip: DD_MFMA_PRIO (0..3)
-
 // The lane id, recomputed where it is needed: a `volatile` asm is neither hoisted nor shared, so code after a long MFMA loop
 // (an epilogue's addresses, the next tile's fill plan) does not keep lane-derived registers alive across that loop -- which is
 // what the register allocator otherwise spills to scratch in kernels that use the whole register file.

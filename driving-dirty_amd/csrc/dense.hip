@@ -361,33 +361,24 @@ __global__ __launch_bounds__(64) void threat_final_kernel(const double* __restri
 // tail and the multi-tensor kernel must produce the SAME bits for the same inputs (left to the compiler, `a * b + c` was
 // contracted differently in the float4 loop and in the scalar kernels, so a tensor updated by one kernel or the other -- the
 // overlapped optimizer picks by size and timing -- ended a last bit apart).
-template <bool FAST>
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float gscale, float b1, float b2, float eps,
-                                          float step_size, float bc2_sqrt, float inv_bc2_sqrt) {
+                                          float step_size, float bc2_sqrt) {
 #pragma clang fp contract(off)
   const float gg = g * gscale;
   const float mm = __builtin_fmaf(b1, m, (1.f - b1) * gg);
   const float vv = __builtin_fmaf(b2, v, ((1.f - b2) * gg) * gg);
   m = mm;
   v = vv;
-  if constexpr (FAST) {
-    // hardware sqrt / reciprocal (1 ulp each) instead of the correctly rounded sequences (~10 vector instructions apiece):
-    // this pass runs on the vector ALUs the fp32 matrix instructions of the conv backward beside it also use
-    const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv), inv_bc2_sqrt, eps);
-    p = __builtin_fmaf(-step_size * mm, __builtin_amdgcn_rcpf(denom), p);
-  } else {
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    p = __builtin_fmaf(-step_size, mm / denom, p);
-  }
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  p = __builtin_fmaf(-step_size, mm / denom, p);
 }
 
-template <bool FAST>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2_sqrt,
                                                    float gscale) {
   const long n4 = n / 4;
-  const float step_size = lr / bc1, inv_bc2_sqrt = 1.f / bc2_sqrt;
+  const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     // streaming accesses: this pass runs beside the conv backward and should not push its 4.5 GB through the caches
     f32x4 pv = __builtin_nontemporal_load((f32x4*)p + i), mv = __builtin_nontemporal_load((f32x4*)m + i),
@@ -396,7 +387,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float pe = pv[k], me = mv[k], ve = vv[k];
-      adam_elem<FAST>(pe, me, ve, gv[k], gscale, b1, b2, eps, step_size, bc2_sqrt, inv_bc2_sqrt);
+      adam_elem(pe, me, ve, gv[k], gscale, b1, b2, eps, step_size, bc2_sqrt);
       pv[k] = pe; mv[k] = me; vv[k] = ve;
     }
     __builtin_nontemporal_store(pv, (f32x4*)p + i);
@@ -406,7 +397,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
     const long i = 4 * n4 + threadIdx.x;
     float pe = p[i], me = m[i], ve = v[i];
-    adam_elem<FAST>(pe, me, ve, g[i], gscale, b1, b2, eps, step_size, bc2_sqrt, inv_bc2_sqrt);
+    adam_elem(pe, me, ve, g[i], gscale, b1, b2, eps, step_size, bc2_sqrt);
     p[i] = pe; m[i] = me; v[i] = ve;
   }
 }
@@ -423,7 +414,6 @@ struct AdamTable {
   int first[ADAM_MULTI_MAX + 1];
   int count;
 };
-template <bool FAST>
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tab, float lr, float b1, float b2, float eps, float bc1,
                                                          float bc2_sqrt, float gscale) {
   int t = 0;
@@ -434,19 +424,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tab, float lr
   float* __restrict__ v = tab.v[t];
   const int i = ((int)blockIdx.x - tab.first[t]) * 256 + threadIdx.x;
   if (i >= tab.n[t]) return;
-  const float step_size = lr / bc1, inv_bc2_sqrt = 1.f / bc2_sqrt;
+  const float step_size = lr / bc1;
   float pe = p[i], me = m[i], ve = v[i];
-  adam_elem<FAST>(pe, me, ve, g[i], gscale, b1, b2, eps, step_size, bc2_sqrt, inv_bc2_sqrt);
+  adam_elem(pe, me, ve, g[i], gscale, b1, b2, eps, step_size, bc2_sqrt);
   p[i] = pe; m[i] = me; v[i] = ve;
 }
 
 constexpr int kLossBlocks = DD_NUM_CU * 8;
-
-// DD_ADAM_FAST=0/1: hardware sqrt / reciprocal in the optimizer pass (A/B knob)
-bool adam_fast() {
-  static const bool fast = getenv("DD_ADAM_FAST") ? atoi(getenv("DD_ADAM_FAST")) != 0 : false;
-  return fast;
-}
 
 }  // namespace
 
@@ -615,7 +599,7 @@ int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   // wait for an Adam block to finish its whole share (measured: 5 us kernels taking 300-700 us).
   static const int per_cu = getenv("DD_ADAM_BLOCKS_PER_CU") ? max(1, atoi(getenv("DD_ADAM_BLOCKS_PER_CU"))) : 4;      // measured 1 / 2 / 3 / 4 / 6 / 8: 9.51 / 9.20 / 9.04 / 9.05 / 9.44 / 9.49 ms per step
   const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)DD_NUM_CU * per_cu);
-  hipLaunchKernelGGL(adam_fast() ? adam_kernel<true> : adam_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
                      eps, (float)bc1, (float)sqrt(bc2), grad_scale);
   DD_LAUNCH_CHECK("adam");
   return 0;
@@ -642,7 +626,7 @@ int dd_adam_step_multi(const dd_adam_tensor* tensors, int32_t count, float lr, f
       blocks += (int)((t.n + 255) / 256);
     }
     tab.first[tab.count] = blocks;
-    hipLaunchKernelGGL(adam_fast() ? adam_multi_kernel<true> : adam_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, lr, beta1, beta2, eps, (float)bc1,
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2), grad_scale);
     DD_LAUNCH_CHECK("adam_multi");
   }

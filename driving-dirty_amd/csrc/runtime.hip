@@ -19,13 +19,27 @@ static int g_cu_budget = DD_NUM_CU;
 
 int dd_cu_budget_internal() { return g_cu_budget; }
 
-int dd_mfma_wave_priority() {      // DD_MFMA_PRIO=0..3 (A/B knob; results unchanged)
-  static const int prio = getenv("DD_MFMA_PRIO") ? max(0, min(3, atoi(getenv("DD_MFMA_PRIO")))) : DD_MFMA_PRIO_DEFAULT;
-  return prio;
+// One wave that samples the shader-clock counter (s_memtime: counts at the clock the CUs actually run at) against the constant
+// 100 MHz reference counter (s_memrealtime) every ~`spin` sleeps: the clock the part delivers WHILE other kernels run, which no
+// per-kernel profiler counter shows for kernels that overlap on different streams.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ samples, int nsamples, int spin) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < nsamples; ++i) {
+    samples[2 * i] = __builtin_readcyclecounter();
+    samples[2 * i + 1] = wall_clock64();
+    for (int k = 0; k < spin; ++k) __builtin_amdgcn_s_sleep(127);
+  }
 }
 
 extern "C" {
 int dd_abi_version(void) { return DD_ABI_VERSION; }
+
+int dd_clock_probe(uint64_t* samples, int32_t nsamples, int32_t spin, void* stream) {
+  DD_REQUIRE(samples && nsamples > 0 && spin >= 0, DD_ERR_BAD_ARG, "clock_probe: bad argument");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)samples, nsamples, spin);
+  DD_LAUNCH_CHECK("clock_probe");
+  return 0;
+}
 
 int dd_set_cu_budget(int32_t compute_units) {
   DD_REQUIRE(compute_units >= 1 && compute_units <= DD_NUM_CU, DD_ERR_BAD_ARG, "set_cu_budget: %d not in 1..%d", compute_units, DD_NUM_CU);

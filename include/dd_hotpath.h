@@ -57,6 +57,12 @@ typedef struct dd_conv_desc {
 int dd_abi_version(void);
 const char* dd_last_error(void);
 
+/* Measurement aid (no reference counterpart): ONE wave writes `nsamples` pairs (shader-clock counter, 100 MHz reference counter)
+ * into samples[2 * nsamples] (device memory), sleeping `spin` x 127 x 64 clocks between two samples.  Launched on its own stream it
+ * records the shader clock the part delivers while kernels on other streams run -- the power-management effect that per-kernel
+ * profiler counters (which serialise kernels) cannot show for overlapped launches.  tools/clock_probe.py. */
+int dd_clock_probe(uint64_t* samples, int32_t nsamples, int32_t spin, void* stream);
+
 /* The conv kernels launch exactly as many workgroups as fit on the chip at once and give every wave an equal,
  * contiguous share of the work.  When another kernel must run BESIDE them for milliseconds (the RCCL all-reduce
  * of data-parallel training: its workgroups need LDS the conv workgroups do not leave free), hand it a few

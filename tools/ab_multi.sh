@@ -3,7 +3,7 @@
 # "" = default.  Prints ms/step and the in-step launch times of the two c2 kernels.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for i in 1 2 3; do
+for i in 1 2; do
   for v in "$@"; do
     tag=$(echo "$v" | tr -c 'A-Za-z0-9' '_')
     log=gpurun_out/abm_${tag}_$i.log
