@@ -215,6 +215,45 @@ def measured_traffic(pattern):
         return None, None
 
 
+def live_traffic(case, kernel_pattern, timeout_s=150):
+    """HBM bytes per launch of one kernel, measured NOW on this box: two child runs of `rocprofv3 --kernel-trace --pmc <counter>
+    -- python3 tools/bench_one.py <case>` (FETCH_SIZE, WRITE_SIZE: separate passes, MI355X_MICROARCH.md HBM section; FETCH_SIZE
+    doubled: gfx950 tallies 128-byte requests as 64).  The children are ordinary child processes (no exec from this process).
+    -> (bytes, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if os.environ.get("DD_BENCH_LIVE_TRAFFIC", "1") == "0":
+        return None, "disabled (DD_BENCH_LIVE_TRAFFIC=0)"
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    med = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="dd_pmc_", dir="/tmp")
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "bench_one.py"), case]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if kernel_pattern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            shutil.rmtree(d, ignore_errors=True)
+            if not per:
+                return None, f"no launch of {kernel_pattern} in the {counter} pass"
+            vals = sorted(per.values())
+            med[counter] = vals[len(vals) // 2] * 1024.0
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return None, f"live PMC pass failed: {type(e).__name__}"
+    return 2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"], (f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes in this run) over "
+                                                         f"tools/bench_one.py {case}; FETCH_SIZE x 2 (gfx950), median over launches")
+
+
 def host_cores():
     """CPU threads this job may really use: affinity, capped by the cgroup quota and by the GPU box's
     per-GPU CPU share (16); DD_CPU_THREADS overrides."""
@@ -489,18 +528,32 @@ def config2_roofline(timer, ops_mod):
             "mfma_frac": round(issued / (dg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
             "hbm_frac_algorithmic": round(PIXELS_PER_SCENE * BATCH * 148.0 / (dg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
     dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])          # the kernel with the largest in-step time
-    traffic, source = measured_traffic("*_c2_dgrad_w1_traffic.json" if dom == "c2_dgrad_w1" else "*_c2_fwd_traffic.json")
+    traffic, source = measured_traffic("*_c2_dgrad_w1_traffic.json" if dom == "c2_dgrad_w1" else "*_c2_fwd_traffic.json")      # committed profile
     k = kernels[dom]
+    k["_pmc"] = ("wino2_dgrad_w1", "conv_wino2_fwd<9, 4") if dom == "c2_dgrad_w1" else ("wino2_fwd", "conv_wino2_fwd<5, 4")
     # hbm_frac: the MEASURED HBM bytes per launch (rocprofv3 PMC, committed profile) over this run's launch time when a traffic
     # file exists, the algorithmic bytes otherwise
     hbm_frac = round(traffic / (k["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else k["hbm_frac_algorithmic"]
     # achieved = MFMA flops the kernel ISSUES per launch (a Winograd kernel issues 4/9 of the direct form's) / its mean launch
     # duration from HIP events inside the timed region: frac <= 1 is the share of the fp32 matrix pipe in use.
     # `algorithmic_equiv` is the direct-convolution flop count over the same time.
-    return {"kernel": k["kernel"], "bound": "mfma", "achieved": k["issued_TFLOPs"], "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+    pmc = k.pop("_pmc")
+    roof = {"kernel": k["kernel"], "bound": "mfma", "achieved": k["issued_TFLOPs"], "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
             "frac": k["mfma_frac"], "algorithmic_equiv": k["algorithmic_equiv_TFLOPs"], "hbm_frac": hbm_frac,
             "hbm_frac_algorithmic": k["hbm_frac_algorithmic"], "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"],
             "traffic": traffic, "traffic_source": source, "kernels": kernels}
+    return roof, pmc
+
+
+def refresh_traffic(roof, pmc):
+    """Replace the committed-profile traffic figure by one measured in this run (after every model of this process is gone)."""
+    live, how = live_traffic(*pmc)
+    if live is not None:
+        roof["traffic_committed_profile"] = roof["traffic"]
+        roof["traffic"], roof["traffic_source"] = live, how
+        roof["hbm_frac"] = round(live / (roof["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    else:
+        roof["traffic_live"] = how
 
 
 def watched_roofline(cfg, timer, per_gpu_batch):
@@ -637,7 +690,11 @@ def run_rank(a):
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * per_gpu * a.steps / dt
-        roof = config2_roofline(timer, _ops) if a.config == 2 else watched_roofline(a.config, timer, per_gpu)
+        pmc = None
+        if a.config == 2:
+            roof, pmc = config2_roofline(timer, _ops)
+        else:
+            roof = watched_roofline(a.config, timer, per_gpu)
         line = {
             "metric": cfg["metric"],
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -655,6 +712,9 @@ def run_rank(a):
             del model, opt, sync, batch, cfg
             torch.cuda.empty_cache()
             line["others"] = other_configs(dev)
+        if world == 1 and a.config == 2 and pmc is not None and not a.no_others:
+            torch.cuda.empty_cache()      # this process's models are gone by now (deleted before `others`): the children get the GPU to themselves
+            refresh_traffic(roof, pmc)
         if not a.no_cpu_baseline and world == 1 and a.config == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
