@@ -642,7 +642,11 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __
   const long nsteps = (r1 - r0) * nxt;
 
   // LDS byte offsets of this wave's tiles: A = x piece (+ Cin tile), B = g piece (+ tap column, Cout tile)
-  const int px0 = prt * (G::XT / G::PARTS);                          // first pixel of this wave's part of the piece
+  // The piece's pixel pairs are dealt round-robin to the PARTS pixel parts: pair j = pp * PARTS + prt, pixels 2j, 2j + 1.  A row's
+  // last piece is only partly inside the image (298 = 2 x 128 + 42): dealt this way every part holds an equal share of the VALID
+  // pairs and the pair loop skips the rest (contiguous parts left the first ones full and the last ones empty: the step took a
+  // full piece's time whatever it held).
+  const int px0 = 2 * prt;
   int aoff[G::TPW], boff[G::TPW];
 #pragma unroll
   for (int i = 0; i < G::TPW; ++i) {
@@ -718,6 +722,10 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __
       // MFMA: every MFMA exposed to the LDS latency)
       const char* lb = (const char*)&lds[par][0];
       constexpr int NP = G::UNITS * 8;
+      constexpr int PSTRIDE = 2 * G::PARTS;                                   // pixels between two pairs of one part
+      // valid pairs of this wave's part in this step's piece (pairs past the row end would multiply zeros)
+      const int valid_px = min(G::XT, W - (int)(s % nxt) * G::XT);
+      const int npp = G::BAL ? NP : max(0, min(NP, ((valid_px + 1) / 2 - prt + G::PARTS - 1) / G::PARTS));
       float av[2][G::OWN], bw[2][G::OWN];
       // shared tiles: this wave's eighth of the pixel pairs, all operands requested up front
       constexpr int NSP = G::BAL ? NP / 8 : 0;
@@ -741,11 +749,12 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const float* __
       }
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
+        if (pp >= npp) continue;                                              // wave-uniform (a `break` would defeat the unrolling)
         if (pp + 1 < NP) {
 #pragma unroll
           for (int i = 0; i < G::OWN; ++i) {
-            av[(pp + 1) & 1][i] = *(const float*)(lb + aoff[i] + (pp + 1) * 2 * C * 4);
-            bw[(pp + 1) & 1][i] = *(const float*)(lb + boff[i] + (pp + 1) * 2 * O * 4);
+            av[(pp + 1) & 1][i] = *(const float*)(lb + aoff[i] + (pp + 1) * PSTRIDE * C * 4);
+            bw[(pp + 1) & 1][i] = *(const float*)(lb + boff[i] + (pp + 1) * PSTRIDE * O * 4);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -964,7 +973,7 @@ int dw_variant(int k, int d, int c, int o) {
 #define DD_DW_DISPATCH(V, F, F16)                 \
   switch (V) {                                    \
     case 0: F(7, 7, 96, 64, 64, 0); break;        \
-    case 1: F(7, 7, 64, 32, 64, 2); break;        \
+    case 1: F(7, 7, 64, 32, 128, 2); break;       \
     case 2: F16(7, 7, 32, 16, 68); break;         \
     case 3: F16(7, 3, 16, 8, 64); break;          \
     case 4: F(8, 8, 64, 32, 128, 2); break;       \
