@@ -138,6 +138,7 @@ SIGNATURES = {
     "dd_conv_wino_wgrad_workspace_bytes": (_i64, [_p]),
     "dd_conv_wino_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "dd_stitch6_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "dd_stitch6_bf16_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_conv_bf16_packed_elems": (_i64, [_p]),
     "dd_conv_bf16_pack": (_i32, [_p, _p, _i32, _p, _p]),
     "dd_conv_bf16_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _p]),

@@ -32,6 +32,20 @@ def stitch6_bf16(views):
     return out
 
 
+def stitch6_bf16_samples(samples):
+    """Tuple of B per-sample [6,3,H,W] fp32 tensors (the reference's collate, helper.py:22-23) -> wide NHWC4 bf16, no stack copy."""
+    b = len(samples)
+    n, c, h, w = samples[0].shape
+    if n != 6 or c != 3:
+        raise _lib.HotpathError(f"stitch6_bf16_samples: expected samples of [6,3,H,W], got {tuple(samples[0].shape)}")
+    for t in samples:
+        ops._dev(t, "sample", (6, 3, h, w))
+    table = (C.c_void_p * b)(*[t.data_ptr() for t in samples])
+    out = torch.empty((b, h, 6 * w, 4), device=samples[0].device, dtype=torch.bfloat16)
+    check(_lib.lib().dd_stitch6_bf16_ptrs(table, _p(out), b, h, w, _stream()), "dd_stitch6_bf16_ptrs")
+    return out
+
+
 def to_bf16(t):
     ops._dev(t, "t")
     if t.numel() % 4:

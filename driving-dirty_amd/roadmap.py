@@ -45,8 +45,10 @@ class RoadMapBCE(LightningModule):
     def _encode(self, sample, keeps=(None, None)):
         if self.ae.encoder.precision == "bf16":         # hparams.precision = "bf16" (BASELINE config 5)
             from . import ops_bf16
-            x = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-            wide4 = ops_bf16.stitch6_bf16(x.contiguous())
+            if isinstance(sample, (tuple, list)):       # the collate's tuple: gather straight from the samples
+                wide4 = ops_bf16.stitch6_bf16_samples([t.contiguous() for t in sample])
+            else:
+                wide4 = ops_bf16.stitch6_bf16(sample.contiguous())
         elif isinstance(sample, (tuple, list)):         # the collate's tuple: gather straight from the samples
             wide4 = ops.stitch6_samples([t.contiguous() for t in sample])
         else:

@@ -150,7 +150,7 @@ class BBSpatialRoadMap(LightningModule):
         space_rep = self.space_map_cnn(x)
         if self.ae.encoder.precision == "bf16":
             from . import ops_bf16
-            wide4 = ops_bf16.stitch6_bf16((torch.stack(tuple(x), dim=0) if per_sample else x).contiguous())
+            wide4 = ops_bf16.stitch6_bf16_samples([t.contiguous() for t in x]) if per_sample else ops_bf16.stitch6_bf16(x.contiguous())
         elif per_sample:
             wide4 = ops.stitch6_samples([t.contiguous() for t in x])
         else:

@@ -494,6 +494,10 @@ int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* d
  * contract is "torch autocast equivalent" -- a conv evaluated on bf16-rounded inputs and weights with fp32
  * accumulation, its output rounded to bf16 (oracle: oracle/bf16_parts.py). */
 int dd_stitch6_bf16(const float* views, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width, void* stream);
+/* The same from a HOST array of `batch` per-sample DEVICE base pointers (each [6,3,H,W] fp32 contiguous), as dd_stitch6_ptrs:
+ * no torch.stack of the collate's tuple (roadmap_bce_v2.py:55) in front of the bf16 path either. */
+int dd_stitch6_bf16_ptrs(const float* const* sample_ptrs, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
+                         void* stream);
 int64_t dd_conv_bf16_packed_elems(const dd_conv_desc* d);                 /* uint16 elements of an operand image */
 /* kind as dd_conv_pack: 0 forward, 1 stride-1 data gradient, 2 stride-2 data gradient */
 int dd_conv_bf16_pack(const float* weight, const dd_conv_desc* d, int32_t kind, uint16_t* packed, void* stream);

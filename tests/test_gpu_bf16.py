@@ -122,6 +122,9 @@ def test_pool_and_stitch(dev, b, h, w):
     wide = ob.stitch6_bf16(v.to(dev))
     assert torch.equal(wide[..., :3].float().cpu().permute(0, 3, 1, 2), bf16r(steps.wide_stitch(v)))
     assert float(wide[..., 3].float().abs().max()) == 0.0
+    # the collate's tuple (one allocation per sample) through the pointer table: the same image, no torch.stack
+    vd = v.to(dev)
+    assert torch.equal(ob.stitch6_bf16_samples([vd[i].clone() for i in range(b)]), wide)
 
 
 def test_conv_stack_against_oracle(dev):
