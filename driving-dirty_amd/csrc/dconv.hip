@@ -975,7 +975,7 @@ int dw_variant(int k, int d, int c, int o) {
     case 0: F(7, 7, 96, 64, 64, 0); break;        \
     case 1: F(7, 7, 64, 32, 128, 2); break;       \
     case 2: F16(7, 7, 32, 16, 68); break;         \
-    case 3: F16(7, 3, 16, 8, 64); break;          \
+    case 3: F16(7, 3, 16, 8, 128); break;         \
     case 4: F(8, 8, 64, 32, 128, 2); break;       \
     case 5: F16(8, 8, 32, 16, 52); break;         \
     default: F16(6, 6, 16, 8, 92); break;         \
