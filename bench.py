@@ -215,7 +215,7 @@ def measured_traffic(pattern):
         return None, None
 
 
-def live_traffic(case, kernel_pattern, timeout_s=150):
+def live_traffic(case, kernel_pattern, timeout_s=60):
     """HBM bytes per launch of one kernel, measured NOW on this box: two child runs of `rocprofv3 --kernel-trace --pmc <counter>
     -- python3 tools/bench_one.py <case>` (FETCH_SIZE, WRITE_SIZE: separate passes, MI355X_MICROARCH.md HBM section; FETCH_SIZE
     doubled: gfx950 tallies 128-byte requests as 64).  The children are ordinary child processes (no exec from this process).
