@@ -235,10 +235,19 @@ def live_traffic(case, kernel_pattern, timeout_s=60):
             d = tempfile.mkdtemp(prefix="dd_pmc_", dir="/tmp")
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.join(ROOT, "tools", "bench_one.py"), case]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            # its own process group: on a timeout the profiler AND the program it started are killed (no GPU holder left behind)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                rc = child.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)
+                child.wait()
+                return None, f"rocprofv3 --pmc {counter} pass killed after {timeout_s} s"
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {rc})"
             per = {}
             for row in csv.DictReader(open(files[0])):
                 if kernel_pattern in row["Kernel_Name"] and row["Counter_Name"] == counter:
