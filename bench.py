@@ -38,6 +38,7 @@ SEED = 20200505                     # reference autoencoder.py:16-18
 BATCH, H, W = 32, 256, 306
 HIDDEN, LATENT = 128, 64
 PEAK_F32_MFMA_TF = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_BF16_MFMA_TF = 2500.0          # same guide: dense bf16 matrix peak (config 5 is HBM-bound far below it)
 PEAK_HBM_GBS = 8000.0               # same guide: HBM3E peak
 # algorithmic work per scene: the 32 -> 32 stride-1 layer, one pass = 2 * 256*1836 pixels * 32 * (9*32) flop;
 # the 3 -> 32 layer's weight gradient = 2 * 256*1836 * 32 * 27
@@ -712,8 +713,10 @@ def run_rank(a):
             **({"rehearsal": "N > 1 call pattern on a 1-rank RCCL communicator (DD_REHEARSE_RCCL=1)"} if rehearse else {}),
             "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
-            "step_algorithmic_frac_of_fp32_mfma_peak": round(cfg["flop_per_scene"] * per_gpu * world / (ms * 1e-3) / 1e12
-                                                             / (PEAK_F32_MFMA_TF * world), 4),
+            # the step's algorithmic flops over its time, against the dense matrix peak of the dtype its convolutions run in
+            ("step_algorithmic_frac_of_bf16_mfma_peak" if cfg["dtype"] == "bf16" else "step_algorithmic_frac_of_fp32_mfma_peak"):
+                round(cfg["flop_per_scene"] * per_gpu * world / (ms * 1e-3) / 1e12
+                      / ((PEAK_BF16_MFMA_TF if cfg["dtype"] == "bf16" else PEAK_F32_MFMA_TF) * world), 4),
             "roofline": roof,
         }
         if world == 1 and a.config == 2 and not a.no_others:
