@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
               }
               float v = a == 0 ? (z[0] + z[1]) + z[2] : (z[1] - z[2]) - z[3];
               if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v, 0.f);      // the bias came in through the accumulator
-              if (MASKED) v = ((mw[a][2 * r + e] >> (t16 + 16 * hf)) & 1u) ? v : 0.f;
+              // (sign-extended 1-bit field = all ones or zero, then one AND: two vector instructions per element instead of the
+              // and / compare / select of `bit ? v : 0`)
+              if (MASKED) v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe((int)mw[a][2 * r + e], (unsigned)(t16 + 16 * hf), 1u));
               o[hf] = v;
               if (!W1) bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
             }

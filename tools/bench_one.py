@@ -3,7 +3,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from driving_dirty_amd import ops
+from driving_dirty_amd import _lib, ops
+if os.environ.get("DD_AB_LIB"):      # A/B of two builds on one box (tools only): load another build of the library
+    _lib.LIB = os.environ["DD_AB_LIB"]
 from tools.bench_kernels import timeit
 dev = torch.device("cuda:0")
 b, h, w = 32, 256, 1836
