@@ -632,6 +632,15 @@ __device__ __forceinline__ f32x2p pk_sub2(f32x2p a, f32x2p b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ f32x2p pk_add2(f32x2p a, f32x2p b) {      // always packed (hipcc splits a 2-vector add whose operands are not register pairs yet)
+  f32x2p r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 pk_add4a(f32x4 a, f32x4 b) {
+  const f32x2p lo = pk_add2(f32x2p{a.x, a.y}, f32x2p{b.x, b.y}), hi = pk_add2(f32x2p{a.z, a.w}, f32x2p{b.z, b.w});
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
   const f32x2p lo = f32x2p{a.x, a.y} + f32x2p{b.x, b.y}, hi = f32x2p{a.z, a.w} + f32x2p{b.z, b.w};
   return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -1000,7 +1009,26 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
         __builtin_amdgcn_sched_barrier(0);
       }
 
-      // output transform + epilogue: lane = channel t16 (+16 per half), register r = tile 4q + r
+      // output transform + epilogue: lane = channel t16 (+16 per half), register r = tile 4q + r.  The transform A^T M A runs
+      // packed over the register pairs (r, r+1) of an accumulator: 96 v_pk_add_f32 instead of 192 scalar adds (same operands,
+      // same order of additions: the same bits).
+      f32x2p o2[2][2][2][2];      // [row a][register pair][column e][channel half]
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            f32x2p z[4];      // z[u] = x-direction output transform of position row u
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const f32x2p m0 = {acc[u * 4 + 0][hf][2 * rp], acc[u * 4 + 0][hf][2 * rp + 1]}, m1 = {acc[u * 4 + 1][hf][2 * rp], acc[u * 4 + 1][hf][2 * rp + 1]};
+              const f32x2p m2 = {acc[u * 4 + 2][hf][2 * rp], acc[u * 4 + 2][hf][2 * rp + 1]}, m3 = {acc[u * 4 + 3][hf][2 * rp], acc[u * 4 + 3][hf][2 * rp + 1]};
+              z[u] = e == 0 ? (m0 + m1) + m2 : pk_sub2(pk_sub2(m1, m2), m3);
+            }
+            o2[0][rp][e][hf] = (z[0] + z[1]) + z[2];
+            o2[1][rp][e][hf] = pk_sub2(pk_sub2(z[1], z[2]), z[3]);
+          }
       unsigned keep[2][8];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -1025,13 +1053,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
             float o[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-              float z[4];      // z[u] = x-direction output transform of position row u
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float m0 = acc[u * 4 + 0][hf][r], m1 = acc[u * 4 + 1][hf][r], m2 = acc[u * 4 + 2][hf][r], m3 = acc[u * 4 + 3][hf][r];
-                z[u] = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
-              }
-              float v = a == 0 ? (z[0] + z[1]) + z[2] : (z[1] - z[2]) - z[3];
+              float v = o2[a][r >> 1][e][hf][r & 1];
               if (EPI == EPI_BIAS_RELU_BITS) v = fmaxf(v, 0.f);      // the bias came in through the accumulator
               // (sign-extended 1-bit field = all ones or zero, then one AND: two vector instructions per element instead of the
               // and / compare / select of `bit ? v : 0`)
@@ -1066,6 +1088,342 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
         store_row<4, 1, false>(xring + ((2 * tr + 4) & 3) * C4::SLOTB, xspill, lane, xpre[0]);
         store_row<4, 1, false>(xring + ((2 * tr + 5) & 3) * C4::SLOTB, xspill, lane, xpre[1]);
       }
+    }
+  }
+  if (W1) {
+    const long gw = (long)blockIdx.x * WPB + wave;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1part[((gw * 2 + hf) * 2 + nh) * 256 + i * 64 + lane] = wacc[hf][nh][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same arithmetic with the input rows held in REGISTERS (default; conv_wino2_fwd above is the LDS-ring form kept for A/B).
+// A lane's x-stage results of one input row (its tile, its 8 channels: 8 float4) serve two tile-rows -- rows 2tr+1, 2tr+2 are
+// r = 2, 3 of tile-row tr and r = 0, 1 of tile-row tr+1 -- so four such rows (128 VGPRs) rotate and every input row is loaded
+// (straight from global memory: 16 bytes a lane, the row's 4.3 KB twice out of L1) and x-transformed ONCE, not twice; no ring,
+// no LDS writes, LDS holds only U.  The stages run u-major (s = 2u + g): position row u is complete after stage 2u+1, so the
+// accumulators are two rows of 32 registers, and the output transform of row u -- A^T along x, then its term of the y sum --
+// sits in the shadow of the next row's MFMAs; output row 2tr leaves in stage 7, output row 2tr+1 in stages 0-1 of the NEXT
+// tile-row (the first pass of a column sees an empty store window and zero mask words).  Same operands in the same order as
+// conv_wino2_fwd: the same bits.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int WPB>
+__global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restrict__ x, const float* __restrict__ up,
+                                                            const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
+                                                            float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
+                                                            int W, int nstrips, const float* __restrict__ x4 = nullptr,
+                                                            float* __restrict__ w1part = nullptr) {
+  using C4 = StripCfg<4, 1>;
+  constexpr bool W1 = (EPI == EPI_RELU_BITS_W1);
+  constexpr bool MASKED = (EPI == EPI_RELU_BITS) || W1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    f32x4* ul4 = (f32x4*)smem;
+    const f32x4* ug4 = (const f32x4*)up;
+    for (int i = tid; i < WINO2_UFLOATS / 4; i += WPB * 64) ul4[i] = ug4[i];
+  }
+  constexpr int W2_XRINGB = 4 * C4::SLOTB + C4::SPILLB;
+  constexpr int W2_XBASE = WINO2_UFLOATS * 4;
+  if (W1 && tid < 32) ((float*)(smem + W2_XBASE + WPB * W2_XRINGB))[tid] = 1.f;
+  if (W1)      // the first pass of a column multiplies masked-out zeros with whatever the image ring holds: keep that finite
+    for (int i = tid; i < WPB * W2_XRINGB / 16; i += WPB * 64) ((f32x4*)(smem + W2_XBASE))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  char* xring = smem + W2_XBASE + wave * W2_XRINGB;      // W1: 4-row ring of the NHWC4 image, slot of row iy = (iy + 1) & 3
+  char* xspill = xring + 4 * C4::SLOTB;
+  f32x4v wacc[2][2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) wacc[hf][nh] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const int ulane = (int)(unsigned long)(__attribute__((address_space(3))) char*)smem + lane * 16;      // LDS byte address of U[..][lane]
+  const int t16 = lane & 15, q4 = lane >> 4;
+  int xky[2], xlane[2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int c = min(t16 + 16 * nh, 26), tap = c / 3, ci = c - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+    xky[nh] = ky;
+    xlane[nh] = (8 * q4 + kx) * 16 + ci * 4;
+  }
+  const float bv0 = (EPI == EPI_BIAS_RELU_BITS) ? bias[t16] : 0.f, bv1 = (EPI == EPI_BIAS_RELU_BITS) ? bias[16 + t16] : 0.f;
+  const f32x4v bias0 = {bv0, bv0, bv0, bv0}, bias1 = {bv1, bv1, bv1, bv1};
+  const int HT = (H + 1) / 2;
+
+  f32x4v accr[2][4][2];      // [position row u & 1][v][channel half]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) accr[i][v][hf] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  f32x2p o1[2][2][2];        // [register pair][column e][channel half]: output row 2tr+1 on its way (z1 - z2 - z3)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o1[i >> 2][(i >> 1) & 1][i & 1] = f32x2p{0.f, 0.f};
+
+  long idx, end;
+  wave_range((long)B * nstrips * HT, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
+  while (idx < end) {
+    const long col = idx / HT;
+    const int r0 = (int)(idx - col * HT);
+    const int r1 = (int)min((long)HT, r0 + (end - idx));
+    idx += r1 - r0;
+    const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+    const float* xb = x + (long)b * H * W * 32;
+    const float* x4b = x4 + (long)b * H * W * 4;
+    const int gx0 = x0 - 1;
+    int poff[4];      // byte offset of this lane's patch column c inside an input row (negative left of the image: out of range -> 0)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) poff[c] = (gx0 + 2 * t16 + c) * 128 + q4 * 32;
+
+    auto row_load = [&](int iy, f32x4 (&R)[2][4]) {      // input row iy: patch columns 2 t16 .. + 3, channels 8 q4 .. + 7
+      const bool rowok = (iy >= 0) && (iy < H);
+      const __amdgpu_buffer_rsrc_t rs = rsrc(xb + (long)(rowok ? iy : 0) * W * 32, rowok ? W * 128 : 0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[g][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[c] + g * 16, 0, 0));
+    };
+    auto xstage = [&](const f32x4 (&L)[2][4], f32x4 (&R)[2][4]) {      // landing registers -> row registers (or in place)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 d0 = L[g][0], d1 = L[g][1], d2 = L[g][2], d3 = L[g][3];
+        R[g][0] = pk_sub4(d0, d2);
+        R[g][1] = pk_add4a(d1, d2);
+        R[g][2] = pk_sub4(d2, d1);
+        R[g][3] = pk_sub4(d1, d3);
+      }
+    };
+    auto ystage = [&](int u, int g, const f32x4 (&A0)[2][4], const f32x4 (&A1)[2][4], const f32x4 (&A2)[2][4], const f32x4 (&A3)[2][4],
+                      f32x4 (&v)[4]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (u == 0) v[c] = pk_sub4(A0[g][c], A2[g][c]);
+        else if (u == 1) v[c] = pk_add4a(A1[g][c], A2[g][c]);
+        else if (u == 2) v[c] = pk_sub4(A2[g][c], A1[g][c]);
+        else v[c] = pk_sub4(A1[g][c], A3[g][c]);
+      }
+    };
+    // U vectors go from LDS straight into ACCUMULATION registers and from there into the MFMAs' B operand: they never hold a
+    // VGPR (64 of them in the ring form).  The compiler does not see these reads: u_wait() below stands between them and their use.
+    auto uread = [&](int g, int u, f32x4 (&uu)[4][2]) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(uu[v][hf]) : "v"(ulane), "n"(((((u * 4 + v) * 2 + hf) * 2 + g) * 1024)));
+    };
+    auto u_wait = [&](f32x4 (&uu)[4][2]) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+a"(uu[0][0]), "+a"(uu[0][1]), "+a"(uu[1][0]), "+a"(uu[1][1]), "+a"(uu[2][0]), "+a"(uu[2][1]), "+a"(uu[3][0]), "+a"(uu[3][1]));
+    };
+    auto mask_load = [&](int oy, unsigned (&m)[8]) {      // sign words of this lane's 8 output pixels (tiles 4q .. 4q+3) of row oy
+      const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * H + min(oy, H - 1)) * W, (oy < H) ? W * 4 : 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = __builtin_amdgcn_raw_buffer_load_b32(ms, (x0 + 8 * q4 + i) * 4, 0, 0);
+    };
+    auto acc_read2 = [&](float a0, float a1, f32x2p& d) {
+      float lo, hi;
+      asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(lo), "=v"(hi) : "a"(a0), "a"(a1));
+      d = f32x2p{lo, hi};
+    };
+    // x-direction output transform of position row u (accumulators accr[u & 1]) and its term of the two y sums.  The reads are
+    // pinned to the stage that calls this (volatile): left to itself the compiler puts each one right behind the MFMA that
+    // finishes the accumulator, a stage earlier, and waits there for the result.
+    auto transform_row = [&](int u, f32x2p (&o0)[2][2][2]) {
+      asm volatile("s_nop 7\n\ts_nop 7");      // the last MFMA of accr[u & 1] is >= 11 wait states away (the compiler cannot count for us)
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4v(&m)[4][2] = accr[u & 1];
+          f32x2p mm[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc_read2(m[v][hf][2 * rp], m[v][hf][2 * rp + 1], mm[v]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const f32x2p z = e == 0 ? pk_add2(pk_add2(mm[0], mm[1]), mm[2]) : pk_sub2(pk_sub2(mm[1], mm[2]), mm[3]);
+            if (u == 0) o0[rp][e][hf] = z;
+            if (u == 1) { o0[rp][e][hf] = pk_add2(o0[rp][e][hf], z); o1[rp][e][hf] = z; }
+            if (u == 2) { o0[rp][e][hf] = pk_add2(o0[rp][e][hf], z); o1[rp][e][hf] = pk_sub2(o1[rp][e][hf], z); }
+            if (u == 3) o1[rp][e][hf] = pk_sub2(o1[rp][e][hf], z);
+          }
+        }
+    };
+    // output row oy leaves: ReLU / mask, store, sign words, the c1 weight gradient's MFMAs
+    auto emit_row = [&](int oy, const f32x2p (&o)[2][2][2], const unsigned (&mw)[8]) {
+      const long opix = (long)(b * H + min(oy, H - 1)) * W;
+      const __amdgpu_buffer_rsrc_t ys = rsrc(y + (W1 ? 0 : opix * 32), (!W1 && oy < H) ? W * 128 : 0);
+      const char* xa[2];
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const char* in_ring = xring + ((oy + xky[nh]) & 3) * C4::SLOTB + xlane[nh];
+        xa[nh] = (t16 + 16 * nh >= 27) ? smem + W2_XBASE + WPB * W2_XRINGB : in_ring;
+      }
+      unsigned keep[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) keep[i] = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int opx = x0 + 2 * (4 * q4 + r) + e;
+          float ov[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            float v = o[r >> 1][e][hf][r & 1];
+            if (EPI == EPI_BIAS_RELU_BITS) v = (v > 0.f) ? v : 0.f;      // one compare serves the ReLU and the sign ballot
+            if (MASKED) v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe((int)mw[2 * r + e], (unsigned)(t16 + 16 * hf), 1u));
+            ov[hf] = v;
+#ifdef DD_EXP_NOSTORE
+            if (!W1 && v == 123.456f) bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
+#else
+            if (!W1) bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
+#endif
+          }
+          if (W1) {
+            const float b0 = *(const float*)(xa[0] + (2 * r + e) * 16), b1 = *(const float*)(xa[1] + (2 * r + e) * 16);
+            wacc[0][0] = DD_MFMA16(ov[0], b0, wacc[0][0]);
+            wacc[0][1] = DD_MFMA16(ov[0], b1, wacc[0][1]);
+            wacc[1][0] = DD_MFMA16(ov[1], b0, wacc[1][0]);
+            wacc[1][1] = DD_MFMA16(ov[1], b1, wacc[1][1]);
+          }
+          if (EPI == EPI_BIAS_RELU_BITS) {
+            const unsigned long long b0 = __ballot(ov[0] > 0.f), b1 = __ballot(ov[1] > 0.f);
+            const int G = (lane & 31) >> 3;
+            keep[2 * r + e] = (unsigned)((b0 >> (16 * G)) & 0xffffull) | ((unsigned)((b1 >> (16 * G)) & 0xffffull) << 16);
+          }
+        }
+      }
+      if (EPI == EPI_BIAS_RELU_BITS) {
+        const int P = lane & 31, sel = P & 7;
+        unsigned word = keep[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) word = (sel == i) ? keep[i] : word;
+        const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + opix, (oy < H) ? W * 4 : 0);
+        __builtin_amdgcn_raw_buffer_store_b32(word, bs, (lane < 32) ? (x0 + P) * 4 : -16, 0, 0);
+      }
+    };
+
+    f32x4 R0[2][4], R1[2][4], R2[2][4], R3[2][4];      // x-stage results of four input rows
+    f32x4 vq[4], uq[4][2];                             // V row and U vectors of the current stage
+    unsigned m1w[8];                                   // sign words of output row 2tr+1 (loaded in stage 7, used in the next stage 1)
+    f32x4 xpre[2][C4::NLOAD];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m1w[i] = 0;
+    row_load(2 * r0 - 1, R0);
+    row_load(2 * r0, R1);
+    row_load(2 * r0 + 1, R2);
+    row_load(2 * r0 + 2, R3);
+    if (W1) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {      // image rows 2 r0 - 1, 2 r0 into the ring; 2 r0 + 1, 2 r0 + 2 follow in the first pass
+        f32x4 t4[C4::NLOAD];
+        load_row<4, 1>(x4b, H, W, 2 * r0 - 1 + d, gx0, lane, t4);
+        store_row<4, 1, false>(xring + ((2 * r0 + d) & 3) * C4::SLOTB, xspill, lane, t4);
+      }
+      load_row<4, 1>(x4b, H, W, 2 * r0 + 1, gx0, lane, xpre[0]);
+      load_row<4, 1>(x4b, H, W, 2 * r0 + 2, gx0, lane, xpre[1]);
+    }
+    xstage(R0, R0);
+    xstage(R1, R1);
+    xstage(R2, R2);
+    int oy_prev = H;      // nothing to emit in the first pass
+
+    // One tile-row.  A0 .. A3 = the register rows holding input rows 2tr-1 .. 2tr+2; A0 is refilled with row 2tr+3 and A1 with
+    // row 2tr+4 (the next tile-row's r = 2, 3).  mp = sign words of the previous tile-row's second output row, mn = this one's.
+    auto step = [&](int tr, f32x4 (&A0)[2][4], f32x4 (&A1)[2][4], f32x4 (&A2)[2][4], f32x4 (&A3)[2][4]) {
+      f32x2p o0[2][2][2];
+      unsigned m0w[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int u = st >> 1, g = st & 1;
+        // this stage's U vectors leave first thing (a region of their own: the scheduler cannot classify these reads and
+        // would sink them to the end); they arrive under the vector work below
+        __builtin_amdgcn_sched_barrier(0);
+        uread(g, u, uq);
+        __builtin_amdgcn_sched_barrier(0);
+        ystage(u, g, A0, A1, A2, A3, vq);
+        // ---- work for other stages / tile-rows ----
+        if (st == 0) transform_row(3, o0);                       // the previous tile-row's last position row (o0 untouched)
+        if (st == 1) {
+          emit_row(oy_prev, o1, m1w);
+          row_load(2 * tr + 3, A0);                              // A0 is dead: V(u = 0, g = 1) has just been formed
+        }
+        if (st == 2) {
+          transform_row(0, o0);
+          if (W1) {
+            store_row<4, 1, false>(xring + ((2 * tr + 2) & 3) * C4::SLOTB, xspill, lane, xpre[0]);
+            store_row<4, 1, false>(xring + ((2 * tr + 3) & 3) * C4::SLOTB, xspill, lane, xpre[1]);
+          }
+        }
+        if (st == 3) {
+          xstage(A3, A3);                                        // input row 2tr+2, in flight since the previous tile-row's stage 7
+          if (W1) {
+            load_row<4, 1>(x4b, H, W, 2 * tr + 3, gx0, lane, xpre[0]);
+            load_row<4, 1>(x4b, H, W, 2 * tr + 4, gx0, lane, xpre[1]);
+          }
+        }
+        if (st == 4) transform_row(1, o0);
+        if (st == 5) {
+          xstage(A0, A0);                                        // input row 2tr+3, in flight since stage 1
+          if (MASKED) mask_load(2 * tr, m0w);
+        }
+        if (st == 6) transform_row(2, o0);
+        if (st == 7) {
+          emit_row(2 * tr, o0, m0w);
+          if (MASKED) mask_load(2 * tr + 1, m1w);
+          row_load(2 * tr + 4, A1);                              // A1 is dead: V(u = 3, g = 1) has just been formed
+        }
+        // ---- this stage's 32 MFMAs: back to back in a region of their own.  Every switch between vector and matrix
+        // instructions costs the wave ~5 cycles on top of the instructions themselves (tools/ubench/mfma_issue.hip: 48.7
+        // cycles per MFMA with two v_pk_add_f32 behind each, 43.5 with 64 behind 32) and with one wave per SIMD nothing
+        // overlaps anyway; written as volatile asm because the scheduler interleaves whatever it is allowed to move.
+        // (Operands: V was formed at the top of the stage, U has arrived by u_wait(), the accumulators are read a stage later.)
+        __builtin_amdgcn_sched_barrier(0);
+        u_wait(uq);
+        const f32x4(&vv)[4] = vq;
+        const f32x4(&uu)[4][2] = uq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              f32x4v& acc = accr[u & 1][v][hf];
+              if (g == 0 && j == 0) {
+                // the first MFMA of an accumulator takes a literal zero -- or, at position (1,1), the bias: A^T e11 A = all
+                // ones, so a constant in M[1][1] reaches all four outputs of the tile once
+                if (EPI == EPI_BIAS_RELU_BITS && u == 1 && v == 1)
+                  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=a"(acc) : "v"(vv[v][j]), "a"(uu[v][hf][j]), "a"(hf ? bias1 : bias0));
+                else
+                  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(vv[v][j]), "a"(uu[v][hf][j]));
+              } else {
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(vv[v][j]), "a"(uu[v][hf][j]));
+              }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      oy_prev = 2 * tr + 1;
+    };
+
+    int tr = r0;
+    for (;;) {
+      step(tr, R0, R1, R2, R3);
+      if (++tr >= r1) break;
+      step(tr, R2, R3, R0, R1);
+      if (++tr >= r1) break;
+    }
+    {      // the column's last output row
+      f32x2p unused[2][2][2];
+      transform_row(3, unused);
+      emit_row(oy_prev, o1, m1w);
     }
   }
   if (W1) {
@@ -1687,11 +2045,12 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
   using C4 = StripCfg<4, 1>;
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
-  const size_t lds = (size_t)WINO2_UFLOATS * 4 + (size_t)WPB * (4 * C::SLOTB + C::SPILLB) +
+  static const bool ring = getenv("DD_WINO2_RING") != nullptr;      // A/B: the LDS-ring form
+  const size_t lds = (size_t)WINO2_UFLOATS * 4 + (ring ? (size_t)WPB * (4 * C::SLOTB + C::SPILLB) : 0) +
                      (EPI == EPI_RELU_BITS_W1 ? (size_t)WPB * (4 * C4::SLOTB + C4::SPILLB) + 128 : 0);
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
   if (nw_out) *nw_out = grid * WPB;
-  auto k = conv_wino2_fwd<EPI, WPB>;
+  auto k = ring ? conv_wino2_fwd<EPI, WPB> : conv_wino2r_fwd<EPI, WPB>;
   if (int rc = allow_lds(k, lds)) return rc;
   hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips,
                      x4, w1part);
