@@ -57,6 +57,12 @@ struct StripCfg {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+// The same descriptor as rsrc() as four words (an inline-asm "s" operand): base, num_records = bytes, raw dword access.
+__device__ __forceinline__ i32x4s rsrc_words(const void* base, int bytes) {
+  const unsigned long a = (unsigned long)base;
+  return i32x4s{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffff), bytes, 0x00020000};
+}
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2));
 }
@@ -1219,6 +1225,9 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         for (int hf = 0; hf < 2; ++hf)
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(uu[v][hf]) : "v"(ulane), "n"(((((u * 4 + v) * 2 + hf) * 2 + g) * 1024)));
     };
+    auto uread1 = [&](int g, int u, int v, int hf, f32x4& d) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(ulane), "n"(((((u * 4 + v) * 2 + hf) * 2 + g) * 1024)));
+    };
     auto u_wait = [&](f32x4 (&uu)[4][2]) {
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+a"(uu[0][0]), "+a"(uu[0][1]), "+a"(uu[1][0]), "+a"(uu[1][1]), "+a"(uu[2][0]), "+a"(uu[2][1]), "+a"(uu[3][0]), "+a"(uu[3][1]));
@@ -1257,9 +1266,9 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         }
     };
     // output row oy leaves: ReLU / mask, store, sign words, the c1 weight gradient's MFMAs
-    auto emit_row = [&](int oy, const f32x2p (&o)[2][2][2], const unsigned (&mw)[8]) {
+    auto emit_row = [&](int oy, const f32x2p (&o)[2][2][2], const unsigned (&mw)[8], float (&pend)[16], i32x4s& ys) {
       const long opix = (long)(b * H + min(oy, H - 1)) * W;
-      const __amdgpu_buffer_rsrc_t ys = rsrc(y + (W1 ? 0 : opix * 32), (!W1 && oy < H) ? W * 128 : 0);
+      ys = rsrc_words(y + (W1 ? 0 : opix * 32), (!W1 && oy < H) ? W * 128 : 0);
       const char* xa[2];
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
@@ -1273,7 +1282,6 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int opx = x0 + 2 * (4 * q4 + r) + e;
           float ov[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
@@ -1281,11 +1289,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
             if (EPI == EPI_BIAS_RELU_BITS) v = (v > 0.f) ? v : 0.f;      // one compare serves the ReLU and the sign ballot
             if (MASKED) v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe((int)mw[2 * r + e], (unsigned)(t16 + 16 * hf), 1u));
             ov[hf] = v;
-#ifdef DD_EXP_NOSTORE
-            if (!W1 && v == 123.456f) bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
-#else
-            if (!W1) bstore1(ys, (opx * 32 + t16 + 16 * hf) * 4, v);
-#endif
+            pend[(2 * r + e) * 2 + hf] = v;      // stored from inside the MFMA block (store_pending)
           }
           if (W1) {
             const float b0 = *(const float*)(xa[0] + (2 * r + e) * 16), b1 = *(const float*)(xa[1] + (2 * r + e) * 16);
@@ -1311,8 +1315,15 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
       }
     };
 
+    // Output element (2r+e, hf) of this lane: pixel x0 + 8 q4 + 2r + e, channel t16 + 16 hf.  A 64-lane dword store costs the wave
+    // ~16 issue cycles in the vector block and nothing behind an MFMA (the matrix pipe is busy for 32): the stores of a row are
+    // issued one per MFMA.  (The compiler does not see them; it can only over-wait for its own loads because of that.)
+    const int pbase = (x0 + 8 * q4) * 128 + t16 * 4;
+    auto store_pending = [&](int i, const float (&pend)[16], const i32x4s& ys) {
+      asm volatile("buffer_store_dword %0, %1, %2, 0 offen offset:%3 nt" : : "v"(pend[i]), "v"(pbase), "s"(ys), "n"((i >> 1) * 128 + (i & 1) * 64) : "memory");
+    };
     f32x4 R0[2][4], R1[2][4], R2[2][4], R3[2][4];      // x-stage results of four input rows
-    f32x4 vq[4], uq[4][2];                             // V row and U vectors of the current stage
+    f32x4 vq[4], uq[2][4][2];                          // V row of the current stage; U vectors of the current / next stage (AGPRs)
     unsigned m1w[8];                                   // sign words of output row 2tr+1 (loaded in stage 7, used in the next stage 1)
     f32x4 xpre[2][C4::NLOAD];
 #pragma unroll
@@ -1334,6 +1345,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     xstage(R0, R0);
     xstage(R1, R1);
     xstage(R2, R2);
+    uread(0, 0, uq[0]);
     int oy_prev = H;      // nothing to emit in the first pass
 
     // One tile-row.  A0 .. A3 = the register rows holding input rows 2tr-1 .. 2tr+2; A0 is refilled with row 2tr+3 and A1 with
@@ -1341,19 +1353,17 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     auto step = [&](int tr, f32x4 (&A0)[2][4], f32x4 (&A1)[2][4], f32x4 (&A2)[2][4], f32x4 (&A3)[2][4]) {
       f32x2p o0[2][2][2];
       unsigned m0w[8];
+      float pend[16];      // the outputs of a row between the vector block that forms them and their stores
+      i32x4s ys;
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         const int u = st >> 1, g = st & 1;
-        // this stage's U vectors leave first thing (a region of their own: the scheduler cannot classify these reads and
-        // would sink them to the end); they arrive under the vector work below
-        __builtin_amdgcn_sched_barrier(0);
-        uread(g, u, uq);
         __builtin_amdgcn_sched_barrier(0);
         ystage(u, g, A0, A1, A2, A3, vq);
         // ---- work for other stages / tile-rows ----
         if (st == 0) transform_row(3, o0);                       // the previous tile-row's last position row (o0 untouched)
         if (st == 1) {
-          emit_row(oy_prev, o1, m1w);
+          emit_row(oy_prev, o1, m1w, pend, ys);
           row_load(2 * tr + 3, A0);                              // A0 is dead: V(u = 0, g = 1) has just been formed
         }
         if (st == 2) {
@@ -1377,7 +1387,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         }
         if (st == 6) transform_row(2, o0);
         if (st == 7) {
-          emit_row(2 * tr, o0, m0w);
+          emit_row(2 * tr, o0, m0w, pend, ys);
           if (MASKED) mask_load(2 * tr + 1, m1w);
           row_load(2 * tr + 4, A1);                              // A1 is dead: V(u = 3, g = 1) has just been formed
         }
@@ -1387,9 +1397,9 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         // overlaps anyway; written as volatile asm because the scheduler interleaves whatever it is allowed to move.
         // (Operands: V was formed at the top of the stage, U has arrived by u_wait(), the accumulators are read a stage later.)
         __builtin_amdgcn_sched_barrier(0);
-        u_wait(uq);
+        u_wait(uq[st & 1]);
         const f32x4(&vv)[4] = vq;
-        const f32x4(&uu)[4][2] = uq;
+        const f32x4(&uu)[4][2] = uq[st & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1407,6 +1417,10 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
               } else {
                 asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(vv[v][j]), "a"(uu[v][hf][j]));
               }
+              // behind the MFMA, for free: the next stage's U vectors (one read each behind the first eight), a row's stores
+              const int i = (j * 4 + v) * 2 + hf;
+              if (i < 8) uread1((st + 1) & 1, ((st + 1) & 7) >> 1, i >> 1, i & 1, uq[(st + 1) & 1][i >> 1][i & 1]);
+              if (!W1 && (st == 1 || st == 7) && i >= 8 && i < 24) store_pending(i - 8, pend, ys);
             }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1422,8 +1436,13 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     }
     {      // the column's last output row
       f32x2p unused[2][2][2];
+      float pend[16];
+      i32x4s ys;
       transform_row(3, unused);
-      emit_row(oy_prev, o1, m1w);
+      emit_row(oy_prev, o1, m1w, pend, ys);
+      if (!W1)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) store_pending(q, pend, ys);
     }
   }
   if (W1) {
