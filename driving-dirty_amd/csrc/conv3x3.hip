@@ -1132,9 +1132,16 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
+    // U image -> LDS with the input channels regrouped: here lane group q4 and quad g hold channels 16 g + 4 q4 .. + 3 (the
+    // packed image has 8 q4 + 4 g .. + 3), so that the four lane groups of a patch load read 64 contiguous bytes of a pixel.
+    // [pos][half][g][lane = 16 q4 + t16]  <-  [pos][half][q4 & 1][16 (2 g + (q4 >> 1)) + t16]
     f32x4* ul4 = (f32x4*)smem;
     const f32x4* ug4 = (const f32x4*)up;
-    for (int i = tid; i < WINO2_UFLOATS / 4; i += WPB * 64) ul4[i] = ug4[i];
+#pragma unroll 4
+    for (int i = tid; i < WINO2_UFLOATS / 4; i += WPB * 64) {
+      const int ln = i & 63, gq = (i >> 6) & 1, hi = i >> 7, qq = ln >> 4;
+      ul4[i] = ug4[(hi * 2 + (qq & 1)) * 64 + (2 * gq + (qq >> 1)) * 16 + (ln & 15)];
+    }
   }
   constexpr int W2_XRINGB = 4 * C4::SLOTB + C4::SPILLB;
   constexpr int W2_XBASE = WINO2_UFLOATS * 4;
@@ -1183,18 +1190,42 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
     const float* xb = x + (long)b * H * W * 32;
     const float* x4b = x4 + (long)b * H * W * 4;
+    // Descriptors: ONE per tensor and column -- base = the image, num_records = the whole image; the row goes into the scalar
+    // offset (range-checked together with the lane offset on this part: tools/ubench/soffset_probe.hip), so rows -1 and H fall
+    // out of range by themselves, and the pixels left and right of a row are put out of range by the LANE offsets, which do not
+    // change down a column (poff, pst, boff below).  A descriptor per row (base + row * pitch in 64 bits, the 16-bit split of the
+    // address, the size select) cost the wave ~500 of its ~11,700 cycles per tile-row.
+    float* yb = y + (W1 ? 0 : (long)b * H * W * 32);
+    unsigned* bob = bits_out + (EPI == EPI_BIAS_RELU_BITS ? (long)b * H * W : 0);
+    const unsigned* bib = bits_in + (MASKED ? (long)b * H * W : 0);
+    const int pitch = W * 128, pitchb = W * 4;
+    constexpr int FAR = 1 << 30;      // beyond any image (the launcher checks H * W * 128 < 2^30), no wrap with a row offset on top
+    const __amdgpu_buffer_rsrc_t xrs = rsrc(xb, H * pitch), bors = rsrc(bob, H * pitchb), birs = rsrc(bib, H * pitchb);
+    const i32x4s yrs = rsrc_words(yb, W1 ? 0 : H * pitch);
     const int gx0 = x0 - 1;
-    int poff[4];      // byte offset of this lane's patch column c inside an input row (negative left of the image: out of range -> 0)
+    int poff[4];      // byte offset of this lane's patch column c inside an input row (left / right of the image: out of range -> 0)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) poff[c] = (gx0 + 2 * t16 + c) * 128 + q4 * 32;
+    for (int c = 0; c < 4; ++c) {
+      const int px = gx0 + 2 * t16 + c;
+      poff[c] = (px >= 0 && px < W) ? px * 128 + q4 * 16 : FAR;
+    }
+    int pst[8];       // byte offset of this lane's output pixel 2r + e of a tile-row's 8, channel t16 (+ 16 hf: the instruction offset)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int px = x0 + 8 * q4 + q;
+      pst[q] = (px < W) ? px * 128 + t16 * 4 : FAR;
+    }
+    int pmk[8];       // ... and of its sign word (zero right of the row: with W1 the masked gradient of such a pixel meets image pixels W-1)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pmk[q] = (MASKED && x0 + 8 * q4 + q < W) ? (x0 + 8 * q4 + q) * 4 : FAR;
+    const int boff = (lane < 32 && x0 + (lane & 31) < W) ? (x0 + (lane & 31)) * 4 : FAR;      // the sign word lane P < 32 stores
 
-    auto row_load = [&](int iy, f32x4 (&R)[2][4]) {      // input row iy: patch columns 2 t16 .. + 3, channels 8 q4 .. + 7
-      const bool rowok = (iy >= 0) && (iy < H);
-      const __amdgpu_buffer_rsrc_t rs = rsrc(xb + (long)(rowok ? iy : 0) * W * 32, rowok ? W * 128 : 0);
+    auto row_load = [&](int iy, f32x4 (&R)[2][4]) {      // input row iy: patch columns 2 t16 .. + 3, channels 16 g + 4 q4 .. + 3
+      const int so = iy * pitch;      // row -1: a huge unsigned offset, out of range like row H
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) R[g][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[c] + g * 16, 0, 0));
+        for (int c = 0; c < 4; ++c) R[g][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[c] + g * 64, so, 0));
     };
     auto xstage = [&](const f32x4 (&L)[2][4], f32x4 (&R)[2][4]) {      // landing registers -> row registers (or in place)
 #pragma unroll
@@ -1233,9 +1264,9 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
                    : "+a"(uu[0][0]), "+a"(uu[0][1]), "+a"(uu[1][0]), "+a"(uu[1][1]), "+a"(uu[2][0]), "+a"(uu[2][1]), "+a"(uu[3][0]), "+a"(uu[3][1]));
     };
     auto mask_load = [&](int oy, unsigned (&m)[8]) {      // sign words of this lane's 8 output pixels (tiles 4q .. 4q+3) of row oy
-      const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * H + min(oy, H - 1)) * W, (oy < H) ? W * 4 : 0);
+      const int so = oy * pitchb;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) m[i] = __builtin_amdgcn_raw_buffer_load_b32(ms, (x0 + 8 * q4 + i) * 4, 0, 0);
+      for (int i = 0; i < 8; ++i) m[i] = __builtin_amdgcn_raw_buffer_load_b32(birs, pmk[i], so, 0);
     };
     auto acc_read2 = [&](float a0, float a1, f32x2p& d) {
       float lo, hi;
@@ -1266,9 +1297,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         }
     };
     // output row oy leaves: ReLU / mask, store, sign words, the c1 weight gradient's MFMAs
-    auto emit_row = [&](int oy, const f32x2p (&o)[2][2][2], const unsigned (&mw)[8], float (&pend)[16], i32x4s& ys) {
-      const long opix = (long)(b * H + min(oy, H - 1)) * W;
-      ys = rsrc_words(y + (W1 ? 0 : opix * 32), (!W1 && oy < H) ? W * 128 : 0);
+    auto emit_row = [&](int oy, const f32x2p (&o)[2][2][2], const unsigned (&mw)[8], float (&pend)[16], int& yso) {
+      yso = oy * pitch;
       const char* xa[2];
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
@@ -1310,17 +1340,16 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         unsigned word = keep[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) word = (sel == i) ? keep[i] : word;
-        const __amdgpu_buffer_rsrc_t bs = rsrc(bits_out + opix, (oy < H) ? W * 4 : 0);
-        __builtin_amdgcn_raw_buffer_store_b32(word, bs, (lane < 32) ? (x0 + P) * 4 : -16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(word, bors, boff, oy * pitchb, 0);
       }
     };
 
     // Output element (2r+e, hf) of this lane: pixel x0 + 8 q4 + 2r + e, channel t16 + 16 hf.  A 64-lane dword store costs the wave
     // ~16 issue cycles in the vector block and nothing behind an MFMA (the matrix pipe is busy for 32): the stores of a row are
     // issued one per MFMA.  (The compiler does not see them; it can only over-wait for its own loads because of that.)
-    const int pbase = (x0 + 8 * q4) * 128 + t16 * 4;
-    auto store_pending = [&](int i, const float (&pend)[16], const i32x4s& ys) {
-      asm volatile("buffer_store_dword %0, %1, %2, 0 offen offset:%3 nt" : : "v"(pend[i]), "v"(pbase), "s"(ys), "n"((i >> 1) * 128 + (i & 1) * 64) : "memory");
+    auto store_pending = [&](int i, const float (&pend)[16], int yso) {
+      if (i & 1) asm volatile("buffer_store_dword %0, %1, %2, %3 offen offset:64 nt" : : "v"(pend[i]), "v"(pst[i >> 1]), "s"(yrs), "s"(yso) : "memory");
+      else asm volatile("buffer_store_dword %0, %1, %2, %3 offen nt" : : "v"(pend[i]), "v"(pst[i >> 1]), "s"(yrs), "s"(yso) : "memory");
     };
     f32x4 R0[2][4], R1[2][4], R2[2][4], R3[2][4];      // x-stage results of four input rows
     f32x4 vq[4], uq[2][4][2];                          // V row of the current stage; U vectors of the current / next stage (AGPRs)
@@ -1354,7 +1383,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
       f32x2p o0[2][2][2];
       unsigned m0w[8];
       float pend[16];      // the outputs of a row between the vector block that forms them and their stores
-      i32x4s ys;
+      int yso;
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         const int u = st >> 1, g = st & 1;
@@ -1363,7 +1392,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         // ---- work for other stages / tile-rows ----
         if (st == 0) transform_row(3, o0);                       // the previous tile-row's last position row (o0 untouched)
         if (st == 1) {
-          emit_row(oy_prev, o1, m1w, pend, ys);
+          emit_row(oy_prev, o1, m1w, pend, yso);
           row_load(2 * tr + 3, A0);                              // A0 is dead: V(u = 0, g = 1) has just been formed
         }
         if (st == 2) {
@@ -1387,7 +1416,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         }
         if (st == 6) transform_row(2, o0);
         if (st == 7) {
-          emit_row(2 * tr, o0, m0w, pend, ys);
+          emit_row(2 * tr, o0, m0w, pend, yso);
           if (MASKED) mask_load(2 * tr + 1, m1w);
           row_load(2 * tr + 4, A1);                              // A1 is dead: V(u = 3, g = 1) has just been formed
         }
@@ -1420,7 +1449,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
               // behind the MFMA, for free: the next stage's U vectors (one read each behind the first eight), a row's stores
               const int i = (j * 4 + v) * 2 + hf;
               if (i < 8) uread1((st + 1) & 1, ((st + 1) & 7) >> 1, i >> 1, i & 1, uq[(st + 1) & 1][i >> 1][i & 1]);
-              if (!W1 && (st == 1 || st == 7) && i >= 8 && i < 24) store_pending(i - 8, pend, ys);
+              if (!W1 && (st == 1 || st == 7) && i >= 8 && i < 24) store_pending(i - 8, pend, yso);
             }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1437,12 +1466,12 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     {      // the column's last output row
       f32x2p unused[2][2][2];
       float pend[16];
-      i32x4s ys;
+      int yso;
       transform_row(3, unused);
-      emit_row(oy_prev, o1, m1w, pend, ys);
+      emit_row(oy_prev, o1, m1w, pend, yso);
       if (!W1)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) store_pending(q, pend, ys);
+        for (int q = 0; q < 16; ++q) store_pending(q, pend, yso);
     }
   }
   if (W1) {
@@ -2065,6 +2094,8 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
   static const bool ring = getenv("DD_WINO2_RING") != nullptr;      // A/B: the LDS-ring form
+  DD_REQUIRE((long)d->height * d->width * 128 < (1L << 30), DD_ERR_UNSUPPORTED, "conv_wino2: image of %d x %d pixels: the kernel addresses an image with 30-bit offsets",
+             d->height, d->width);
   const size_t lds = (size_t)WINO2_UFLOATS * 4 + (ring ? (size_t)WPB * (4 * C::SLOTB + C::SPILLB) : 0) +
                      (EPI == EPI_RELU_BITS_W1 ? (size_t)WPB * (4 * C4::SLOTB + C4::SPILLB) + 128 : 0);
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
