@@ -69,6 +69,9 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) {
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 2));
 }
+__device__ __forceinline__ float bload1s(__amdgpu_buffer_rsrc_t r, int off, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+}
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 2);
 }
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
                                                             const float* __restrict__ bias, const unsigned* __restrict__ bits_in,
                                                             float* __restrict__ y, unsigned* __restrict__ bits_out, int B, int H,
                                                             int W, int nstrips, const float* __restrict__ x4 = nullptr,
-                                                            float* __restrict__ w1part = nullptr) {
+                                                            float* __restrict__ w1part = nullptr, int pf_rows = 0) {
   using C4 = StripCfg<4, 1>;
   constexpr bool W1 = (EPI == EPI_RELU_BITS_W1);
   constexpr bool MASKED = (EPI == EPI_RELU_BITS) || W1;
@@ -1180,6 +1183,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) o1[i >> 2][(i >> 1) & 1][i & 1] = f32x2p{0.f, 0.f};
 
+  float pfacc = 0.f;
   long idx, end;
   wave_range((long)B * nstrips * HT, blockIdx.x * WPB + wave, gridDim.x * WPB, idx, end);
   while (idx < end) {
@@ -1218,6 +1222,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     int pmk[8];       // ... and of its sign word (zero right of the row: with W1 the masked gradient of such a pixel meets image pixels W-1)
 #pragma unroll
     for (int q = 0; q < 8; ++q) pmk[q] = (MASKED && x0 + 8 * q4 + q < W) ? (x0 + 8 * q4 + q) * 4 : FAR;
+    // L2 prefetch (pf_rows tile-rows ahead): one dword of each 64-byte half of the strip's 34 pixels of an input row
+    const int pfoff = (lane < 34 && gx0 + lane >= 0 && gx0 + lane < W) ? (gx0 + lane) * 128 : FAR;
     const int boff = (lane < 32 && x0 + (lane & 31) < W) ? (x0 + (lane & 31)) * 4 : FAR;      // the sign word lane P < 32 stores
 
     auto row_load = [&](int iy, f32x4 (&R)[2][4]) {      // input row iy: patch columns 2 t16 .. + 3, channels 16 g + 4 q4 .. + 3
@@ -1375,6 +1381,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
     xstage(R1, R1);
     xstage(R2, R2);
     uread(0, 0, uq[0]);
+    float pfv[4] = {0.f, 0.f, 0.f, 0.f};
     int oy_prev = H;      // nothing to emit in the first pass
 
     // One tile-row.  A0 .. A3 = the register rows holding input rows 2tr-1 .. 2tr+2; A0 is refilled with row 2tr+3 and A1 with
@@ -1396,6 +1403,11 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
           row_load(2 * tr + 3, A0);                              // A0 is dead: V(u = 0, g = 1) has just been formed
         }
         if (st == 2) {
+          if (pf_rows) {
+            pfacc += pfv[0] + pfv[1] + pfv[2] + pfv[3];      // the previous tile-row's (landed long ago; keeps them alive)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pfv[q] = bload1s(xrs, pfoff + (q & 1) * 64, (2 * (tr + pf_rows) + 3 + (q >> 1)) * pitch);
+          }
           transform_row(0, o0);
           if (W1) {
             store_row<4, 1, false>(xring + ((2 * tr + 2) & 3) * C4::SLOTB, xspill, lane, xpre[0]);
@@ -1474,6 +1486,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         for (int q = 0; q < 16; ++q) store_pending(q, pend, yso);
     }
   }
+  if (pf_rows && pfacc == 1.2345e-30f && !W1) y[lane] = pfacc;      // never: the prefetched words must not be optimised away
   if (W1) {
     const long gw = (long)blockIdx.x * WPB + wave;
 #pragma unroll
@@ -2100,10 +2113,13 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
                      (EPI == EPI_RELU_BITS_W1 ? (size_t)WPB * (4 * C4::SLOTB + C4::SPILLB) + 128 : 0);
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
   if (nw_out) *nw_out = grid * WPB;
-  auto k = ring ? conv_wino2_fwd<EPI, WPB> : conv_wino2r_fwd<EPI, WPB>;
-  if (int rc = allow_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips,
-                     x4, w1part);
+  if (int rc = ring ? allow_lds(conv_wino2_fwd<EPI, WPB>, lds) : allow_lds(conv_wino2r_fwd<EPI, WPB>, lds)) return rc;
+  // rows of the next tile-row are pulled into L2 a tile-row ahead (in the step: forward 1.195 -> 1.163 ms; DD_W2_PREFETCH=0 for A/B)
+  static const int pf_rows = getenv("DD_W2_PREFETCH") ? max(0, min(4, atoi(getenv("DD_W2_PREFETCH")))) : 1;
+  auto kring = conv_wino2_fwd<EPI, WPB>;
+  auto kreg = conv_wino2r_fwd<EPI, WPB>;
+  if (ring) hipLaunchKernelGGL(kring, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips, x4, w1part);
+  else hipLaunchKernelGGL(kreg, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips, x4, w1part, pf_rows);
   DD_LAUNCH_CHECK("conv_wino2_fwd");
   return 0;
 }

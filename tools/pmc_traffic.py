@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-KERNEL = "conv_wino2_fwd<5, 4"               # c2 forward (Winograd F(2x2,3x3), bias+ReLU+sign bits, 4 waves)
+KERNEL = "conv_wino2r_fwd<5, 4"               # c2 forward (Winograd F(2x2,3x3), bias+ReLU+sign bits, 4 waves)
 
 
 def per_launch(directory, counter, kernel=None):
@@ -31,7 +31,7 @@ def main():
     if len(sys.argv) > 4 and sys.argv[4] == "dgrad_w1":
         # c2 data gradient + c1 weight gradient in one kernel: reads g2 once, one sign word and one NHWC4 image pixel per pixel;
         # writes only the per-wave 32 x 32 partials of dW1
-        kernel, algorithmic = "conv_wino2_fwd<9, 4", px * (32 * 4 + 4 + 16) + 1024 * 1024 * 4
+        kernel, algorithmic = "conv_wino2r_fwd<9, 4", px * (32 * 4 + 4 + 16) + 1024 * 1024 * 4
     else:
         kernel, algorithmic = KERNEL, px * (32 * 4 * 2 + 4)    # read a1 once + write a2 once + one sign word per pixel, bs = 32
     fetch, n1 = per_launch(fetch_dir, "FETCH_SIZE", kernel)
