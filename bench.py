@@ -56,7 +56,13 @@ def parse_args():
                     "3 box head on the frozen encoder, 4 joint roadmap + box, 5 bf16 at 2x resolution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the config-1 / config-3 / config-5 step timings after the headline")
-    ap.add_argument("--no-adam-overlap", action="store_true", help="run the whole optimizer step after backward")
+    ap.add_argument("--adam-overlap", choices=("auto", "on", "off"), default="auto",
+                    help="Adam pass of the big tensors on a side stream beside the backward (on), after it (off); auto = on when there are "
+                    "gradients to all-reduce (N > 1: the pass then waits for each tensor's reduction under the rest of the backward).  On "
+                    "one GPU it was measured not to pay on any configuration (same box, on / off: config 2 8.0-8.2 / 8.0-8.2 ms, config 3 "
+                    "60.1-60.4 / 60.1-60.2, config 4 67.6-67.9 / 67.6-67.7, config 5 9.9-10.0 / 9.75-9.8): the steps are HBM-bound "
+                    "throughout, and beside Adam the c2 data gradient takes 2.25 ms instead of 1.46 (DESIGN.md 5)")
+    ap.add_argument("--no-adam-overlap", action="store_true", help="= --adam-overlap off")
     ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
     ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
     ap.add_argument("--latent", type=int, default=LATENT, help="latent width (64; with --hidden 256: 128)")
@@ -360,7 +366,6 @@ def other_configs(dev, steps=5, warmup=2):
         torch.manual_seed(SEED)
         ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, learning_rate=1e-3, output_img_freq=500)).to(dev)
         opt = HipAdam(ae.parameters(), lr=1e-3)
-        opt.overlap_with_backward()
         views = torch.rand(b, 6, 3, H, W, device=dev)
 
         def ae_step(i):
@@ -397,7 +402,6 @@ def other_configs(dev, steps=5, warmup=2):
     ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT))
     m = JointRoadMapBBox(Namespace(pretrained_ae=ae, learning_rate=1e-3, output_img_freq=500)).to(dev)
     opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()
 
     def joint_step(i):
         m.zero_grad(set_to_none=True)
@@ -414,7 +418,6 @@ def other_configs(dev, steps=5, warmup=2):
     m = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
     batch = (tuple(torch.rand(b5, 6, 3, h2, w2, device=dev)), None, tuple(torch.rand(b5, 800, 800, device=dev) < 0.3))
     opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()           # the first step unfreezes the extractor: LightningModule.unfreeze() re-arms the hooks
 
     def bf16_step(i):
         m.zero_grad(set_to_none=True)
@@ -430,7 +433,6 @@ def other_configs(dev, steps=5, warmup=2):
     ae = BasicAE(Namespace(hidden_dim=256, latent_dim=128))
     m = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500)).to(dev)
     opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()
     batch = synthetic_batch(dev, BATCH, 0)
 
     def wide_step(i):
@@ -654,7 +656,8 @@ def run_rank(a):
     # LightningModule.unfreeze() re-arms both (ddp.GradSync.refresh, optim.HipAdam.refresh).
     opt = HipAdam(model.parameters(), lr=1e-3)
     sync = GradSync(model, reserve_cus=reserve, force_collectives=rehearse)          # broadcasts rank 0's parameters and buffers
-    if not a.no_adam_overlap:
+    overlap = {"on": True, "off": False, "auto": world > 1 or rehearse}[a.adam_overlap] and not a.no_adam_overlap
+    if overlap:
         opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if (world > 1 or rehearse) else None)
     if a.config == 2:
         timer = KernelTimer()
@@ -712,7 +715,8 @@ def run_rank(a):
             "dtype": cfg["dtype"], "data": "synthetic", "n_ranks_seen": n_ranks_seen,
             **({"rehearsal": "N > 1 call pattern on a 1-rank RCCL communicator (DD_REHEARSE_RCCL=1)"} if rehearse else {}),
             "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
-                       "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
+                       "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
+                       "adam_overlap": bool(overlap)},
             # the step's algorithmic flops over its time, against the dense matrix peak of the dtype its convolutions run in
             ("step_algorithmic_frac_of_bf16_mfma_peak" if cfg["dtype"] == "bf16" else "step_algorithmic_frac_of_fp32_mfma_peak"):
                 round(cfg["flop_per_scene"] * per_gpu * world / (ms * 1e-3) / 1e12

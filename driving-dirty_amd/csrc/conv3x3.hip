@@ -1961,6 +1961,10 @@ __global__ __launch_bounds__(256) void conv_wino2_wgrad_reduce_a(const float* __
   ((f32x4*)tsum)[((long)c * 16 + p) * 256 + f] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// Few vector registers (rolled loops: 40): this kernel is launched on the side stream while the c2 data gradient holds 464 of every
+// SIMD's 512 -- with the 136 of the unrolled form its 17 waves waited in the queue for that kernel to END (1.59 ms from dispatch
+// to completion in the trace, ~60 us of it running, and the optimizer's last launch waits for it).  The output transform runs as
+// running sums with coefficients 0 / +-1 in the order of the closed forms ((t0 + t1) + t2, t1 - t2, (t1 + t2) + t3): the same bits.
 __global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
                                                                 float* __restrict__ dw, float* __restrict__ db, int nw) {
   const int l = threadIdx.x;
@@ -1978,30 +1982,35 @@ __global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __r
     if (l < 32) db[l] = t + other;
     return;
   }
-  float t[4][4];
+  float out[3][3];
 #pragma unroll
-  for (int p = 0; p < 16; ++p)      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
-  {
-    float v = 0.f;
-#pragma unroll
-    for (int c = 0; c < W2R_CHUNKS; ++c) v += tsum[(((long)c * 16 + p) * 16 + r) * 64 + l];
-    t[p >> 2][p & 3] = v * (((p >> 2) == 1 || (p >> 2) == 2) ? 0.5f : 1.f) * (((p & 3) == 1 || (p & 3) == 2) ? 0.5f : 1.f);
-  }
-  float z[3][4];      // z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
-#pragma unroll
+  for (int a = 0; a < 9; ++a) out[a / 3][a % 3] = 0.f;
+#pragma unroll 1
   for (int v = 0; v < 4; ++v) {
-    z[0][v] = (t[0][v] + t[1][v]) + t[2][v];
-    z[1][v] = t[1][v] - t[2][v];
-    z[2][v] = (t[1][v] + t[2][v]) + t[3][v];
-  }
-  const int o = dd_acc_row(r, l), j = l & 31;
-  float* out = dw + ((long)o * 32 + j) * 9;
+    float z[3] = {0.f, 0.f, 0.f};      // z[ky] = A^T[ky][u] t[u][v]
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+      const int p = u * 4 + v;
+      float t = 0.f;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    out[ky * 3 + 0] = (z[ky][0] + z[ky][1]) + z[ky][2];
-    out[ky * 3 + 1] = z[ky][1] - z[ky][2];
-    out[ky * 3 + 2] = (z[ky][1] + z[ky][2]) + z[ky][3];
+      for (int c = 0; c < W2R_CHUNKS; ++c) t += tsum[(((long)c * 16 + p) * 16 + r) * 64 + l];
+      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
+      t = t * ((u == 1 || u == 2) ? 0.5f : 1.f) * ((v == 1 || v == 2) ? 0.5f : 1.f);
+      z[0] += (u < 3 ? 1.f : 0.f) * t;
+      z[1] += (u == 1 ? 1.f : u == 2 ? -1.f : 0.f) * t;
+      z[2] += (u > 0 ? 1.f : 0.f) * t;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {      // dW[ky][kx] = z[ky][v] A[v][kx]
+      out[ky][0] += (v < 3 ? 1.f : 0.f) * z[ky];
+      out[ky][1] += (v == 1 ? 1.f : v == 2 ? -1.f : 0.f) * z[ky];
+      out[ky][2] += (v > 0 ? 1.f : 0.f) * z[ky];
+    }
   }
+  const int o = dd_acc_row(r, l), jj = l & 31;
+  float* dst = dw + ((long)o * 32 + jj) * 9;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) dst[a] = out[a / 3][a % 3];
 }
 
 // Second stage: fixed-order sums of the per-wave partials S_p (one block per (ky, register) row), then the output
