@@ -10,6 +10,9 @@ import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime t
 
 from .build import LIB
 
+if os.environ.get("DD_HOTPATH_LIB"):      # another BUILD of the same library (tools/: A/B of two builds on one box); must exist, same ABI
+    LIB = os.environ["DD_HOTPATH_LIB"]
+
 _i32, _i64, _f32, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
