@@ -523,10 +523,14 @@ def config2_roofline(timer, ops_mod):
     fwd_ms, dg_ms = timer.mean_ms("c2_fwd"), timer.mean_ms("c2_dgrad_w1")
     assert fwd_ms is not None, "the c2 forward kernel was never launched through the timed entry point"
     kernels = {}
+    # the kernels behind the two entry points (csrc/conv3x3.hip launch_wino2): register-row form for the forward, ring form for the fused
+    # data gradient; DD_WINO2_RING / DD_WINO2_REG_W1 switch them for A/B
+    k_fwd = "conv_wino2_fwd" if os.environ.get("DD_WINO2_RING") else "conv_wino2r_fwd"
+    k_w1 = "conv_wino2r_fwd" if (os.environ.get("DD_WINO2_REG_W1") and not os.environ.get("DD_WINO2_RING")) else "conv_wino2_fwd"
     algo = C2_FLOP_PER_SCENE * BATCH
     fwd_bytes = PIXELS_PER_SCENE * BATCH * 260.0       # reads a1 (128 B/pixel), writes a2 (128 B/pixel) + one sign word per pixel
     kernels["c2_forward"] = {
-        "kernel": "conv_wino2r_fwd<BIAS_RELU_BITS>" if wino2 else "conv_wino_fwd" if wino else "conv_strip_fwd<32,1>",
+        "kernel": k_fwd + "<BIAS_RELU_BITS>" if wino2 else "conv_wino_fwd" if wino else "conv_strip_fwd<32,1>",
         "launch_ms": round(fwd_ms, 4), "launches_timed": len(timer.pairs["c2_fwd"]),
         "issued_TFLOPs": round(algo * issue / (fwd_ms * 1e-3) / 1e12, 2), "algorithmic_equiv_TFLOPs": round(algo / (fwd_ms * 1e-3) / 1e12, 2),
         "mfma_frac": round(algo * issue / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
@@ -536,7 +540,7 @@ def config2_roofline(timer, ops_mod):
         # registers: 64 more MFMAs on every 256.  Reads g2 (128 B/pixel), one sign word and 16 B of image per pixel.
         issued = algo * issue * (320.0 / 256.0)
         kernels["c2_dgrad_w1"] = {
-            "kernel": "conv_wino2r_fwd<RELU_BITS_W1> (c2 data gradient + fused c1 weight gradient)",
+            "kernel": k_w1 + "<RELU_BITS_W1> (c2 data gradient + fused c1 weight gradient)",
             "launch_ms": round(dg_ms, 4), "launches_timed": len(timer.pairs["c2_dgrad_w1"]),
             "issued_TFLOPs": round(issued / (dg_ms * 1e-3) / 1e12, 2),
             "algorithmic_equiv_TFLOPs": round((algo + C1_WGRAD_FLOP_PER_SCENE * BATCH) / (dg_ms * 1e-3) / 1e12, 2),
@@ -545,7 +549,7 @@ def config2_roofline(timer, ops_mod):
     dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])          # the kernel with the largest in-step time
     traffic, source = measured_traffic("*_c2_dgrad_w1_traffic.json" if dom == "c2_dgrad_w1" else "*_c2_fwd_traffic.json")      # committed profile
     k = kernels[dom]
-    k["_pmc"] = ("wino2_dgrad_w1", "conv_wino2r_fwd<9, 4") if dom == "c2_dgrad_w1" else ("wino2_fwd", "conv_wino2r_fwd<5, 4")
+    k["_pmc"] = ("wino2_dgrad_w1", k_w1 + "<9, 4") if dom == "c2_dgrad_w1" else ("wino2_fwd", k_fwd + "<5, 4")
     # hbm_frac: the MEASURED HBM bytes per launch (rocprofv3 PMC, committed profile) over this run's launch time when a traffic
     # file exists, the algorithmic bytes otherwise
     hbm_frac = round(traffic / (k["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else k["hbm_frac_algorithmic"]
