@@ -82,6 +82,53 @@ void rung(int threads) {
   hipFree(out); hipFree(cyc);
 }
 
+// Two waves on every SIMD: waves 0-3 issue MFMAs only, waves 4-7 vector adds only (MODE 1), MFMAs too (MODE 2) or exit (MODE 0).
+// Does another wave's vector work take matrix time?
+template <int MODE, bool PK>
+__global__ __launch_bounds__(512) void kmix(float* out, long long* cyc, int iters) {
+  f32x4v acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4v{0, 0, 0, 0};
+  float a = threadIdx.x * 0.001f, b = 1.0f + threadIdx.x * 0.002f;
+  f32x2p t[4] = {{a, b}, {b, a}, {a, a}, {b, b}};
+  const int wave = threadIdx.x >> 6;
+  const bool mf = wave < 4 || MODE == 2;
+  if (!mf && MODE == 0) return;
+  long long t0 = __builtin_readcyclecounter();
+  if (mf) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int m = 0; m < 32; ++m) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 15]) : "v"(a), "v"(b));
+  } else {
+    for (int it = 0; it < iters * 8; ++it)
+#pragma unroll
+      for (int v = 0; v < 32; ++v) {
+        if (PK) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(t[v & 3]) : "v"(t[(v + 1) & 3]));
+        else asm volatile("v_add_f32 %0, %0, %1" : "+v"(t[v & 3].x) : "v"(t[(v + 1) & 3].y));
+      }
+  }
+  long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += acc[i][0];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + t[0].x + t[1].x + t[2].y + t[3].y;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  if (threadIdx.x == 256 && blockIdx.x == 0) cyc[1] = t1 - t0;
+}
+
+template <int MODE, bool PK>
+void runmix(const char* what) {
+  float* out; long long* cyc;
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 16);
+  const int iters = 1000;
+  kmix<MODE, PK><<<256, 512>>>(out, cyc, 10);
+  kmix<MODE, PK><<<256, 512>>>(out, cyc, iters);
+  hipDeviceSynchronize();
+  long long c[2]; hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);
+  printf("two waves per SIMD, wave A MFMAs only, wave B %s: %.1f cycles per MFMA of wave A", what, (double)c[0] / (iters * 32.0));
+  if (MODE == 1) printf("; wave B: %.1f cycles per vector instruction", (double)c[1] / (iters * 8 * 32.0));
+  printf("\n");
+  hipFree(out); hipFree(cyc);
+}
+
 template <int NV, int NDS, int NS, bool PK>
 void run(const char* name, int threads) {
   float* out; long long* cyc;
@@ -119,5 +166,9 @@ int main() {
     rung<1, 2, true>(th); rung<2, 2, true>(th); rung<4, 2, true>(th); rung<8, 2, true>(th); rung<16, 2, true>(th); rung<32, 2, true>(th);
     rung<1, 2, false>(th); rung<4, 2, false>(th); rung<32, 2, false>(th);
   }
+  runmix<0, false>("absent");
+  runmix<1, false>("v_add_f32 only");
+  runmix<1, true>("v_pk_add_f32 only");
+  runmix<2, false>("MFMAs too");
   return 0;
 }
