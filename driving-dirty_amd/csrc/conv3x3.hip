@@ -101,6 +101,25 @@ __device__ __forceinline__ void load_row(const float* __restrict__ img, int H, i
   }
 }
 
+// The same with ONE multiply, add and select per row instead of a 64-bit base + row * pitch and the 16-bit split of the address:
+// base = the image, the row in the scalar offset, num_records = the END of that row.  gfx950 adds the scalar offset in the range
+// check (tools/ubench/soffset_probe.hip), so a pixel right of the row is out of range and one left of it (a negative lane offset) too.
+template <int CIN, int S>
+__device__ __forceinline__ void load_row_img(const float* __restrict__ img, int H, int W, int iy, int gx0, int lane,
+                                             f32x4 (&r)[StripCfg<CIN, S>::NLOAD]) {
+  using C = StripCfg<CIN, S>;
+  const bool rowok = (iy >= 0) && (iy < H);
+  const int so = rowok ? iy * W * C::PXB : 0;
+  const __amdgpu_buffer_rsrc_t rs = rsrc(img, rowok ? so + W * C::PXB : 0);
+#pragma unroll
+  for (int i = 0; i < C::NLOAD; ++i) {
+    const int c = lane + 64 * i;
+    const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
+    const int off = (c < C::NCH) ? ((gx0 + q) * C::PXB + ch * 16) : -16;
+    r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, so, 2));
+  }
+}
+
 // Registers -> ring slot.  Every lane writes (no exec-masked branch that would drag the matching load and a
 // full vmcnt(0) wait into it): the lanes of the last, partial chunk group land in the wave's `spill` zone.
 template <int CIN, int S, bool SWZ>
@@ -954,17 +973,18 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
 
     for (int tr = r0; tr < r1; ++tr) {
       f32x4 pre[2][C::NLOAD];
-      load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
-      load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
+      load_row_img<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
+      load_row_img<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
       f32x4 xpre[2][C4::NLOAD];
       unsigned mw[2][8];
       if (MASKED) {   // sign words of this lane's 2 x 8 output pixels (tiles 4q..4q+3)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const int oy = 2 * tr + a;
-          const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)(b * H + min(oy, H - 1)) * W, (oy < H) ? W * 4 : 0);
+          const int mso = (oy < H) ? oy * W * 4 : 0;
+          const __amdgpu_buffer_rsrc_t ms = rsrc(bits_in + (long)b * H * W, (oy < H) ? mso + W * 4 : 0);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) mw[a][i] = __builtin_amdgcn_raw_buffer_load_b32(ms, (x0 + 8 * q4 + i) * 4, 0, 0);
+          for (int i = 0; i < 8; ++i) mw[a][i] = __builtin_amdgcn_raw_buffer_load_b32(ms, (x0 + 8 * q4 + i) * 4, mso, 0);
         }
       }
 
@@ -985,8 +1005,8 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_fwd(const float* __restri
           ystage(0, wq, vq[0]);
         }
         if (W1 && st == 7) {      // image rows for the next tile-row: they land after this tile-row's epilogue has read the old ones
-          load_row<4, 1>(x4b, H, W, 2 * tr + 3, gx0, lane, xpre[0]);
-          load_row<4, 1>(x4b, H, W, 2 * tr + 4, gx0, lane, xpre[1]);
+          load_row_img<4, 1>(x4b, H, W, 2 * tr + 3, gx0, lane, xpre[0]);
+          load_row_img<4, 1>(x4b, H, W, 2 * tr + 4, gx0, lane, xpre[1]);
         }
         if (st == 4) {      // rows 2tr+3, 2tr+4 replace rows 2tr-1, 2tr in the ring
           store_row<32, 1, true>(ring + ((2 * tr + 4) & 3) * C::SLOTB, spill, lane, pre[0]);
