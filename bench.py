@@ -523,10 +523,10 @@ def config2_roofline(timer, ops_mod):
     fwd_ms, dg_ms = timer.mean_ms("c2_fwd"), timer.mean_ms("c2_dgrad_w1")
     assert fwd_ms is not None, "the c2 forward kernel was never launched through the timed entry point"
     kernels = {}
-    # the kernels behind the two entry points (csrc/conv3x3.hip launch_wino2): register-row form for the forward, ring form for the fused
-    # data gradient; DD_WINO2_RING / DD_WINO2_REG_W1 switch them for A/B
+    # the kernels behind the two entry points (csrc/conv3x3.hip launch_wino2): register-row form for the forward and the fused
+    # data gradient; DD_WINO2_RING / DD_WINO2_RING_W1 switch to the ring form for A/B
     k_fwd = "conv_wino2_fwd" if os.environ.get("DD_WINO2_RING") else "conv_wino2r_fwd"
-    k_w1 = "conv_wino2r_fwd" if (os.environ.get("DD_WINO2_REG_W1") and not os.environ.get("DD_WINO2_RING")) else "conv_wino2_fwd"
+    k_w1 = "conv_wino2_fwd" if (os.environ.get("DD_WINO2_RING") or os.environ.get("DD_WINO2_RING_W1")) else "conv_wino2r_fwd"
     algo = C2_FLOP_PER_SCENE * BATCH
     fwd_bytes = PIXELS_PER_SCENE * BATCH * 260.0       # reads a1 (128 B/pixel), writes a2 (128 B/pixel) + one sign word per pixel
     kernels["c2_forward"] = {

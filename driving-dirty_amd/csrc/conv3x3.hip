@@ -1764,37 +1764,49 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
     const float* dyb = dy + (long)b * H * W * 32;
     const int gx0 = x0 - 1;
     const int aoff = ((x0 + 2 * h) * 32 + n) * 4;   // tile 2s+h = pixels x0 + 4s + 2h, +1: + 512 bytes per s, + 128 for the odd pixel
+    // Descriptors: base = the image, the row in the scalar offset, num_records = the END of that row -- the range check adds the
+    // scalar offset to the lane offset (tools/ubench/soffset_probe.hip), so a pixel right of the row is out of range and one
+    // left of it (a negative lane offset) too.  One multiply, one add and one select per row instead of a 64-bit base + row *
+    // pitch with its 16-bit split.
+    const int pitch = W * 128;
+    int roff[C::NLOAD];      // this lane's 16-byte chunks of a ring row (the idle lanes of the last group: out of range)
+#pragma unroll
+    for (int q = 0; q < C::NLOAD; ++q) {
+      const int c = lane + 64 * q;
+      roff[q] = (c < C::NCH) ? (gx0 + c / C::CHUNKS) * C::PXB + (c % C::CHUNKS) * 16 : -16;
+    }
+    auto row_loadq = [&](int iy, int q, f32x4& d) {      // chunk group q of input row iy
+      const bool ok = (iy >= 0) && (iy < H);
+      const int so = ok ? iy * pitch : 0;
+      d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(xb, ok ? so + pitch : 0), roff[q], so, 2));
+    };
 
 #pragma unroll
     for (int d = 0; d < 4; ++d) {      // input rows 2*r0 - 1 .. 2*r0 + 2; slot of row iy = (iy + 1) & 3
       f32x4 t[C::NLOAD];
       const int iy = 2 * r0 - 1 + d;
-      load_row<32, 1>(xb, H, W, iy, gx0, lane, t);
+#pragma unroll
+      for (int q = 0; q < C::NLOAD; ++q) row_loadq(iy, q, t[q]);
       store_row<32, 1, false>(ring + ((iy + 1) & 3) * C::SLOTB, spill, lane, t);
     }
     // dy rows 2tr, 2tr+1 of the strip: g[a][e][s]
-    auto load_dy = [&](int tr, f32x2p (&g)[2][8]) {      // g[e][s] = (row 2tr, row 2tr+1) of the tile's column e
+    auto load_dy1 = [&](int tr, int s8, f32x2p (&g)[2][8]) {      // g[e][s] = (row 2tr, row 2tr+1) of the tile's column e: tile s8's four
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int oy = 2 * tr + a;
         const bool ok = (tr < r1) && (oy < H);       // rows past the range belong to the next wave: read zeros
-        const __amdgpu_buffer_rsrc_t as = rsrc(dyb + (long)(ok ? oy : 0) * W * 32, ok ? W * 128 : 0);
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-          g[0][s8][a] = bload1(as, aoff + s8 * 512);
-          g[1][s8][a] = bload1(as, aoff + s8 * 512 + 128);
-        }
+        const int so = ok ? oy * pitch : 0;
+        const __amdgpu_buffer_rsrc_t as = rsrc(dyb, ok ? so + pitch : 0);
+        g[0][s8][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(as, aoff + s8 * 512, so, 2));
+        g[1][s8][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(as, aoff + s8 * 512 + 128, so, 2));
       }
     };
     f32x2p ga[2][8], gb[2][8];      // dy of the current / next tile-row, alternating (no register moves)
-    load_dy(r0, ga);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) load_dy1(r0, s8, ga);
 
     auto step = [&](int tr, const f32x2p (&gc)[2][8], f32x2p (&gn)[2][8]) {
       f32x4 pre[2][C::NLOAD];
-      load_row<32, 1>(xb, H, W, 2 * tr + 3, gx0, lane, pre[0]);
-      load_row<32, 1>(xb, H, W, 2 * tr + 4, gx0, lane, pre[1]);
-      load_dy(tr + 1, gn);
-      __builtin_amdgcn_sched_barrier(0);
 
       const char* rb[4];
 #pragma unroll
@@ -1845,17 +1857,36 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2_wgrad(const float* __rest
       rd(0, dq[0]);
       rd(1, dq[1]);
       tf(0, dq[0], aq[0], bq[0]);
+      // Per tile: a block of vector work (the next tile's transform), then the 16 MFMAs with everything that is not a vector
+      // instruction issued behind them -- the LDS reads of the tile after next, this tile-row's share of the global loads for the
+      // next one, the ring writes.  A memory instruction costs the wave 8-40 issue cycles inside the vector block and nothing
+      // behind an MFMA (64 cycles of matrix pipe each; tools/ubench/mfma_issue.hip), and every switch between vector and matrix
+      // instructions costs ~5 more.
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        if (s8 + 2 < 8) rd(s8 + 2, dq[s8 & 1]);                      // dq[s8&1] held tile s8: already transformed
-        if (s8 + 1 < 8) tf(s8 + 1, dq[(s8 + 1) & 1], aq[(s8 + 1) & 1], bq[(s8 + 1) & 1]);
-        if (s8 == 6) {      // every patch read of this tile-row is out (tile 7's was issued at s8 = 5): the new rows may land
-          store_row<32, 1, false>(ring + ((2 * tr + 4) & 3) * C::SLOTB, spill, lane, pre[0]);
-          store_row<32, 1, false>(ring + ((2 * tr + 5) & 3) * C::SLOTB, spill, lane, pre[1]);
-        }
         __builtin_amdgcn_sched_barrier(0);
+        if (s8 + 1 < 8) tf(s8 + 1, dq[(s8 + 1) & 1], aq[(s8 + 1) & 1], bq[(s8 + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s8 + 2 < 8) rd(s8 + 2, dq[s8 & 1]);                      // dq[s8&1] held tile s8: already transformed
+        load_dy1(tr + 1, s8, gn);
+#pragma unroll
+        for (int q = 2 * s8; q < 2 * s8 + 2; ++q)      // the ring rows of the next tile-row: out by tile 2, written to LDS in tiles 6 and 7
+          if (q < C::NLOAD) {
+            row_loadq(2 * tr + 3, q, pre[0][q]);
+            row_loadq(2 * tr + 4, q, pre[1][q]);
+          }
+        if (s8 == 6) store_row<32, 1, false>(ring + ((2 * tr + 4) & 3) * C::SLOTB, spill, lane, pre[0]);      // every patch read of this
+        if (s8 == 7) store_row<32, 1, false>(ring + ((2 * tr + 5) & 3) * C::SLOTB, spill, lane, pre[1]);      // tile-row is out (tile 7's: s8 = 5)
 #pragma unroll
         for (int p = 0; p < 16; ++p) acc[p] = DD_MFMA(aq[s8 & 1][p], bq[s8 & 1][p], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);      // SALU
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -1937,6 +1968,10 @@ __global__ __launch_bounds__(256) void conv_wino2_wgrad_reduce_a(const float* __
   ((f32x4*)tsum)[((long)c * 16 + p) * 256 + f] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// Few vector registers (rolled loops: 40): this kernel is launched on the side stream while the c2 data gradient holds 464 of every
+// SIMD's 512 -- with the 136 of the unrolled form its 17 waves waited in the queue for that kernel to END (1.59 ms from dispatch
+// to completion in the trace, ~60 us of it running, and the optimizer's last launch waits for it).  The output transform runs as
+// running sums with coefficients 0 / +-1 in the order of the closed forms ((t0 + t1) + t2, t1 - t2, (t1 + t2) + t3): the same bits.
 __global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
                                                                 float* __restrict__ dw, float* __restrict__ db, int nw) {
   const int l = threadIdx.x;
@@ -1954,30 +1989,35 @@ __global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __r
     if (l < 32) db[l] = t + other;
     return;
   }
-  float t[4][4];
+  float out[3][3];
 #pragma unroll
-  for (int p = 0; p < 16; ++p)      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
-  {
-    float v = 0.f;
-#pragma unroll
-    for (int c = 0; c < W2R_CHUNKS; ++c) v += tsum[(((long)c * 16 + p) * 16 + r) * 64 + l];
-    t[p >> 2][p & 3] = v * (((p >> 2) == 1 || (p >> 2) == 2) ? 0.5f : 1.f) * (((p & 3) == 1 || (p & 3) == 2) ? 0.5f : 1.f);
-  }
-  float z[3][4];      // z[ky][v] = A^T[ky][u] t[u][v];  then dW[ky][kx] = z[ky][v] A[v][kx]
-#pragma unroll
+  for (int a = 0; a < 9; ++a) out[a / 3][a % 3] = 0.f;
+#pragma unroll 1
   for (int v = 0; v < 4; ++v) {
-    z[0][v] = (t[0][v] + t[1][v]) + t[2][v];
-    z[1][v] = t[1][v] - t[2][v];
-    z[2][v] = (t[1][v] + t[2][v]) + t[3][v];
-  }
-  const int o = dd_acc_row(r, l), j = l & 31;
-  float* out = dw + ((long)o * 32 + j) * 9;
+    float z[3] = {0.f, 0.f, 0.f};      // z[ky] = A^T[ky][u] t[u][v]
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+      const int p = u * 4 + v;
+      float t = 0.f;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    out[ky * 3 + 0] = (z[ky][0] + z[ky][1]) + z[ky][2];
-    out[ky * 3 + 1] = z[ky][1] - z[ky][2];
-    out[ky * 3 + 2] = (z[ky][1] + z[ky][2]) + z[ky][3];
+      for (int c = 0; c < W2R_CHUNKS; ++c) t += tsum[(((long)c * 16 + p) * 16 + r) * 64 + l];
+      // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
+      t = t * ((u == 1 || u == 2) ? 0.5f : 1.f) * ((v == 1 || v == 2) ? 0.5f : 1.f);
+      z[0] += (u < 3 ? 1.f : 0.f) * t;
+      z[1] += (u == 1 ? 1.f : u == 2 ? -1.f : 0.f) * t;
+      z[2] += (u > 0 ? 1.f : 0.f) * t;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {      // dW[ky][kx] = z[ky][v] A[v][kx]
+      out[ky][0] += (v < 3 ? 1.f : 0.f) * z[ky];
+      out[ky][1] += (v == 1 ? 1.f : v == 2 ? -1.f : 0.f) * z[ky];
+      out[ky][2] += (v > 0 ? 1.f : 0.f) * z[ky];
+    }
   }
+  const int o = dd_acc_row(r, l), jj = l & 31;
+  float* dst = dw + ((long)o * 32 + jj) * 9;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) dst[a] = out[a / 3][a % 3];
 }
 
 // Second stage: fixed-order sums of the per-wave partials S_p (one block per (ky, register) row), then the output
@@ -2113,14 +2153,11 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
   using C4 = StripCfg<4, 1>;
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
-  // The fused data gradient of the training step runs beside the optimizer's streaming pass (side stream), and there the
-  // register-row form loses more than it gains: 2.0-2.3 ms in the step against 1.43 alone, where the ring form takes 1.78 against
-  // 1.54 -- its loads are issued a whole tile-row ahead (the register-row form: four stages), and a load waits several microseconds
-  // in the CU's memory queue behind the optimizer's.  Same box, step: 7.61-7.66 ms with the ring form here, 8.0-8.2 with the
-  // register-row form (with or without the overlap).  DD_WINO2_REG_W1=1 selects the register-row form for A/B.
-  static const bool ring_env = getenv("DD_WINO2_RING") != nullptr;      // A/B: the LDS-ring form everywhere
-  static const bool reg_w1 = getenv("DD_WINO2_REG_W1") != nullptr;
-  const bool ring = ring_env || (EPI == EPI_RELU_BITS_W1 && !reg_w1);
+  // Register-row kernels by default.  DD_WINO2_RING=1: the LDS-ring form everywhere, DD_WINO2_RING_W1=1: for the fused data
+  // gradient only (A/B; DESIGN.md 3.1c: beside the optimizer pass the choice depends on how that pass is launched -- csrc/dense.hip).
+  static const bool ring_env = getenv("DD_WINO2_RING") != nullptr;
+  static const bool ring_w1 = getenv("DD_WINO2_RING_W1") != nullptr;
+  const bool ring = ring_env || (EPI == EPI_RELU_BITS_W1 && ring_w1);
   DD_REQUIRE((long)d->height * d->width * 128 < (1L << 30), DD_ERR_UNSUPPORTED, "conv_wino2: image of %d x %d pixels: the kernel addresses an image with 30-bit offsets",
              d->height, d->width);
   const size_t lds = (size_t)WINO2_UFLOATS * 4 + (ring ? (size_t)WPB * (4 * C::SLOTB + C::SPILLB) : 0) +

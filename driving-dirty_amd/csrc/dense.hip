@@ -610,10 +610,13 @@ int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   DD_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, DD_ERR_BAD_ARG, "adam: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  // Persistent blocks, but only a few per CU: this pass usually runs BESIDE the backward (optim.HipAdam.overlap_with_backward),
-  // and 8 long-running blocks per CU would hold every wave slot -- the backward's small kernels (reductions, packs) then
-  // wait for an Adam block to finish its whole share (measured: 5 us kernels taking 300-700 us).
-  static const int per_cu = getenv("DD_ADAM_BLOCKS_PER_CU") ? max(1, atoi(getenv("DD_ADAM_BLOCKS_PER_CU"))) : 4;      // measured 1 / 2 / 3 / 4 / 6 / 8: 9.51 / 9.20 / 9.04 / 9.05 / 9.44 / 9.49 ms per step
+  // ONE persistent block per CU.  This pass usually runs BESIDE the conv backward (optim.HipAdam.overlap_with_backward), whose
+  // one-wave-per-SIMD kernels take 440-464 of a SIMD's 512 registers: one Adam wave (48) fits beside them, and -- the point --
+  // nothing of this launch is ever left QUEUED: blocks that wait for a CU are dispatched ahead of the next conv kernel when the
+  // current one ends, and a kernel of >= 456 registers then waits until they have all drained (tools/ubench/residency.hip; in the
+  // step: the c2 data gradient 2.2 ms from dispatch to end instead of 1.6).  Alone the pass is also fastest this way (0.536 ms for
+  // fc1's 481 MB = 6.3 TB/s; 4 blocks per CU: 0.586, 8: 0.595).
+  static const int per_cu = getenv("DD_ADAM_BLOCKS_PER_CU") ? max(1, atoi(getenv("DD_ADAM_BLOCKS_PER_CU"))) : 1;
   const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)DD_NUM_CU * per_cu);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
                      eps, (float)bc1, (float)sqrt(bc2), grad_scale);

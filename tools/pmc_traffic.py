@@ -31,7 +31,7 @@ def main():
     if len(sys.argv) > 4 and sys.argv[4] == "dgrad_w1":
         # c2 data gradient + c1 weight gradient in one kernel: reads g2 once, one sign word and one NHWC4 image pixel per pixel;
         # writes only the per-wave 32 x 32 partials of dW1
-        kernel, algorithmic = "conv_wino2_fwd<9, 4", px * (32 * 4 + 4 + 16) + 1024 * 1024 * 4
+        kernel, algorithmic = "conv_wino2r_fwd<9, 4", px * (32 * 4 + 4 + 16) + 1024 * 1024 * 4
     else:
         kernel, algorithmic = KERNEL, px * (32 * 4 * 2 + 4)    # read a1 once + write a2 once + one sign word per pixel, bs = 32
     fetch, n1 = per_launch(fetch_dir, "FETCH_SIZE", kernel)
