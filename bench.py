@@ -57,10 +57,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the config-1 / config-3 / config-5 step timings after the headline")
     ap.add_argument("--adam-overlap", choices=("auto", "on", "off"), default="auto",
-                    help="Adam pass of the big tensors on a side stream beside the backward (on) or after it (off); auto = on, except for "
-                    "the bf16 configuration on one GPU (measured 9.75-9.81 ms off against 9.91-10.03 on).  On the fp32 roadmap step the "
-                    "overlap is worth 0.7 ms (same box: 7.65 on, 8.36 off) -- with the kernels as shipped; see DESIGN.md 5 for how easily "
-                    "that is lost")
+                    help="Adam pass of the big tensors on a side stream beside the backward (on = auto) or after it (off).  With one Adam "
+                    "block per CU and the 33-instruction kernel (DESIGN.md 3.1c) the overlap pays on every configuration: same box, on / off: "
+                    "config 2 7.51-7.62 / 7.86-7.93 ms, config 5 (bf16) 9.21-9.27 / 9.53-9.59")
     ap.add_argument("--no-adam-overlap", action="store_true", help="= --adam-overlap off")
     ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
     ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
@@ -419,7 +418,8 @@ def other_configs(dev, steps=5, warmup=2):
     ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, input_height=h2, input_width=6 * w2, output_height=h2, output_width=w2))
     m = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
     batch = (tuple(torch.rand(b5, 6, 3, h2, w2, device=dev)), None, tuple(torch.rand(b5, 800, 800, device=dev) < 0.3))
-    opt = HipAdam(m.parameters(), lr=1e-3)      # bf16: the overlap was measured not to pay (9.75-9.81 ms without, 9.91-10.03 with)
+    opt = HipAdam(m.parameters(), lr=1e-3)
+    opt.overlap_with_backward()
 
     def bf16_step(i):
         m.zero_grad(set_to_none=True)
@@ -663,7 +663,7 @@ def run_rank(a):
     # LightningModule.unfreeze() re-arms both (ddp.GradSync.refresh, optim.HipAdam.refresh).
     opt = HipAdam(model.parameters(), lr=1e-3)
     sync = GradSync(model, reserve_cus=reserve, force_collectives=rehearse)          # broadcasts rank 0's parameters and buffers
-    overlap = {"on": True, "off": False, "auto": world > 1 or rehearse or a.config != 5}[a.adam_overlap] and not a.no_adam_overlap
+    overlap = {"on": True, "off": False, "auto": True}[a.adam_overlap] and not a.no_adam_overlap
     if overlap:
         opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if (world > 1 or rehearse) else None)
     if a.config == 2:
