@@ -129,6 +129,48 @@ void runmix(const char* what) {
   hipFree(out); hipFree(cyc);
 }
 
+// Every wave runs [NVB packed adds][32 MFMAs] per stage, like a stage of the c2 kernels: with two waves per SIMD, does one wave's
+// vector block fall under the other's MFMA block by itself?
+template <int NVB>
+__global__ __launch_bounds__(512) void kstage(float* out, long long* cyc, int iters) {
+  f32x4v acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4v{0, 0, 0, 0};
+  float a = threadIdx.x * 0.001f, b = 1.0f + threadIdx.x * 0.002f;
+  f32x2p t[4] = {{a, b}, {b, a}, {a, a}, {b, b}};
+  long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int v = 0; v < NVB; ++v) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(t[v & 3]) : "v"(t[(v + 1) & 3]));
+#pragma unroll
+    for (int m = 0; m < 32; ++m) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 15]) : "v"(a), "v"(b));
+  }
+  long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += acc[i][0];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + t[0].x + t[1].x + t[2].y + t[3].y;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  if (threadIdx.x == 256 && blockIdx.x == 0) cyc[1] = t1 - t0;
+}
+
+template <int NVB>
+void runstage() {
+  float* out; long long* cyc;
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 16);
+  const int iters = 2000;
+  for (int th = 256; th <= 512; th += 256) {
+    kstage<NVB><<<256, th>>>(out, cyc, 10);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    kstage<NVB><<<256, th>>>(out, cyc, iters);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long c[2]; hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);
+    printf("stage = %3d packed adds + 32 MFMAs, %d wave(s) per SIMD: %.0f cycles per stage of wave 0 (counter), %.3f ms wall = %.0f ns per stage and SIMD-wave\n", NVB,
+           th / 256, (double)c[0] / iters, ms, ms * 1e6 / iters / (th / 256));
+  }
+  hipFree(out); hipFree(cyc);
+}
+
 template <int NV, int NDS, int NS, bool PK>
 void run(const char* name, int threads) {
   float* out; long long* cyc;
@@ -166,6 +208,7 @@ int main() {
     rung<1, 2, true>(th); rung<2, 2, true>(th); rung<4, 2, true>(th); rung<8, 2, true>(th); rung<16, 2, true>(th); rung<32, 2, true>(th);
     rung<1, 2, false>(th); rung<4, 2, false>(th); rung<32, 2, false>(th);
   }
+  runstage<50>(); runstage<100>(); runstage<150>();
   runmix<0, false>("absent");
   runmix<1, false>("v_add_f32 only");
   runmix<1, true>("v_pk_add_f32 only");
