@@ -152,6 +152,51 @@ __global__ __launch_bounds__(512) void kstage(float* out, long long* cyc, int it
   if (threadIdx.x == 256 && blockIdx.x == 0) cyc[1] = t1 - t0;
 }
 
+// The same with the alternation FORCED: waves 0-3 run [adds] barrier [MFMAs] barrier, waves 4-7 [MFMAs] barrier [adds] barrier.
+template <int NVB>
+__global__ __launch_bounds__(512) void kphase(float* out, long long* cyc, int iters) {
+  f32x4v acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4v{0, 0, 0, 0};
+  float a = threadIdx.x * 0.001f, b = 1.0f + threadIdx.x * 0.002f;
+  f32x2p t[4] = {{a, b}, {b, a}, {a, a}, {b, b}};
+  const bool second = (threadIdx.x >> 8) != 0;
+  long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if ((ph == 0) != second) {
+#pragma unroll
+        for (int v = 0; v < NVB; ++v) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(t[v & 3]) : "v"(t[(v + 1) & 3]));
+      } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 15]) : "v"(a), "v"(b));
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += acc[i][0];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + t[0].x + t[1].x + t[2].y + t[3].y;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int NVB>
+void runphase() {
+  float* out; long long* cyc;
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 16);
+  const int iters = 2000;
+  kphase<NVB><<<256, 512>>>(out, cyc, 10);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  kphase<NVB><<<256, 512>>>(out, cyc, iters);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("stage = %3d packed adds + 32 MFMAs, 2 waves per SIMD in FORCED alternation (two barriers a stage): %.3f ms wall = %.0f ns per stage and SIMD-wave\n", NVB, ms,
+         ms * 1e6 / iters / 2);
+  hipFree(out); hipFree(cyc);
+}
+
 template <int NVB>
 void runstage() {
   float* out; long long* cyc;
@@ -209,6 +254,7 @@ int main() {
     rung<1, 2, false>(th); rung<4, 2, false>(th); rung<32, 2, false>(th);
   }
   runstage<50>(); runstage<100>(); runstage<150>();
+  runphase<50>(); runphase<100>(); runphase<150>();
   runmix<0, false>("absent");
   runmix<1, false>("v_add_f32 only");
   runmix<1, true>("v_pk_add_f32 only");
