@@ -2494,6 +2494,8 @@ int dd_conv_wino2_wgrad_partials(const float* x, const float* dy, void* workspac
   DD_REQUIRE(d->cin_real == 32 && d->stride == 1, DD_ERR_UNSUPPORTED, "conv_wino: only the 32 -> 32 stride-1 layer");
   DD_REQUIRE(workspace_bytes >= dd_conv_wino2_wgrad_workspace_bytes(d), DD_ERR_WORKSPACE, "conv_wino2_wgrad: workspace %ld < %ld bytes",
              (long)workspace_bytes, (long)dd_conv_wino2_wgrad_workspace_bytes(d));
+  DD_REQUIRE((long)d->height * d->width * 128 < (1L << 30), DD_ERR_UNSUPPORTED, "conv_wino2_wgrad: image of %d x %d pixels: the kernel addresses an image with 30-bit offsets",
+             d->height, d->width);
   constexpr int WPB = 4;
   const int nstrips = (d->width + 31) / 32;
   const int grid = wino2_wgrad_grid(d);      // one partial per WORKGROUP (its four waves are added in LDS)
