@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(WPB * 64) void conv_wino2r_fwd(const float* __restr
         for (int q = 0; q < 16; ++q) store_pending(q, pend, yso);
     }
   }
-  if (pf_rows && pfacc == 1.2345e-30f && !W1) y[lane] = pfacc;      // never: the prefetched words must not be optimised away
+  asm volatile("" : : "v"(pfacc));      // the prefetched words must not be optimised away
   if (W1) {
     const long gw = (long)blockIdx.x * WPB + wave;
 #pragma unroll
