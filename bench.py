@@ -67,6 +67,13 @@ def parse_args():
     ap.add_argument("--wino-1d", action="store_true", help="c2 forward / data gradient by F(2,3) along x instead of F(2x2,3x3)")
     ap.add_argument("--direct-conv", action="store_true", help="c2 forward / data gradient on the direct kernels instead of Winograd")
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
+    ap.add_argument("--shard-optimizer", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: reduce-scatter + Adam on the owned 1/N + all-gather under the next forward (on) instead of all-reduce + "
+                    "replicated Adam (off).  auto = on for the configs whose gradient message cannot hide under the backward as an "
+                    "all-reduce (4 and 5; DESIGN.md section 6), off for 2 and 3")
+    ap.add_argument("--simulate-shard", type=int, default=0, metavar="N",
+                    help="one GPU, timing only: the COMPUTE side of an N-GPU sharded step (Adam on rank 0's 1/N of every big tensor, no "
+                    "collectives; the parameters it leaves are meaningless) -- the per-GPU lower bound of the N-GPU step")
     return ap.parse_args()
 
 
@@ -93,6 +100,7 @@ def launch_ranks(n):
             alive.remove(p)
             if code != 0 and rc == 0:
                 rc = code
+                print(f"bench.py: rank {procs.index(p)} exited with status {code}; stopping the other {len(alive)} rank(s)", file=sys.stderr, flush=True)
                 for q in alive:              # a rank died: the collective would hang the others
                     q.terminate()
                 deadline = time.monotonic() + 10.0
@@ -155,10 +163,17 @@ class KernelTimer:
                 return out
             return timed
         is_c2 = lambda x, packed, bias, desc: desc.cin_real == 32 and desc.stride == 1      # noqa: E731
+        self._saved = {n: getattr(ops, n) for n in ("conv_fwd_bits", "conv_wino_fwd_bits", "conv_wino2_fwd_bits", "conv_wino2_dgrad_w1")}
         ops.conv_fwd_bits = wrap(ops.conv_fwd_bits, "c2_fwd", is_c2)
         ops.conv_wino_fwd_bits = wrap(ops.conv_wino_fwd_bits, "c2_fwd", is_c2)
         ops.conv_wino2_fwd_bits = wrap(ops.conv_wino2_fwd_bits, "c2_fwd", is_c2)
         ops.conv_wino2_dgrad_w1 = wrap(ops.conv_wino2_dgrad_w1, "c2_dgrad_w1", lambda *a: True)
+
+    def uninstall(self):
+        from driving_dirty_amd import ops
+        for n, f in getattr(self, "_saved", {}).items():
+            setattr(ops, n, f)
+        self._saved = {}
 
     def mean_ms(self, key):
         p = self.pairs[key]
@@ -182,8 +197,10 @@ class AbiTimer:
         by_symbol = {}
         for key, (symbol, pred) in self.watch.items():
             by_symbol.setdefault(symbol, []).append((key, pred))
+        self._saved = {}
         for symbol, cases in by_symbol.items():
             inner = getattr(lib, symbol)
+            self._saved[symbol] = inner
 
             def timed(*a, _inner=inner, _cases=cases):
                 if self.enabled:
@@ -197,6 +214,12 @@ class AbiTimer:
                             return rc
                 return _inner(*a)
             setattr(lib, symbol, timed)      # every caller looks the entry point up on this CDLL object
+
+    def uninstall(self):
+        from driving_dirty_amd import _lib
+        for symbol, inner in getattr(self, "_saved", {}).items():
+            setattr(_lib.lib(), symbol, inner)
+        self._saved = {}
 
     def mean_ms(self, key):
         p = self.pairs[key]
@@ -346,108 +369,66 @@ def time_steps(step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def other_configs(dev, steps=5, warmup=2):
+def other_configs(a, dev, steps=10, warmup=3):
     """Per-GPU step rates of the other BASELINE configurations, measured in this process after the headline timing (same
-    synthetic-data conventions; diagnostic numbers, not `value`)."""
+    synthetic-data conventions, the same TrainStep; diagnostic numbers, not `value`).  Configs 3 / 4 / 5 carry the `roofline` of their
+    dominant kernel, from HIP events around its C-ABI launches inside their timed steps (AbiTimer)."""
     import torch
     from driving_dirty_amd.autoencoder import BasicAE
-    from driving_dirty_amd.optim import HipAdam
     from driving_dirty_amd.roadmap import RoadMapBCE
-    from driving_dirty_amd.spatial import BBSpatialRoadMap
+    from driving_dirty_amd.train import TrainStep
     res = {}
 
-    def finish(name, dt, batch, extra=None):
-        res[name] = dict({"ms_per_step": round(dt * 1e3, 3), "scenes_per_s": round(batch / dt, 1), "batch": batch}, **(extra or {}))
+    def run(name, model, batch, nbatch, extra=None, watch=None, cfg=None):
+        ts = TrainStep(model, lr=1e-3, scheduler=False)
+        timer = AbiTimer(watch) if watch else None
+        if timer:
+            timer.install()
+
+        def step(i):
+            if timer:
+                timer.enabled = i >= warmup
+            ts(batch, i)
+        dt = time_steps(step, steps, warmup)
+        entry = dict({"ms_per_step": round(dt * 1e3, 3), "scenes_per_s": round(nbatch / dt, 1), "batch": nbatch, "steps": steps, "warmup": warmup},
+                     **(extra or {}))
+        if timer:
+            timer.enabled = False
+            entry["roofline"] = watched_roofline(cfg, timer, nbatch, dt * 1e3)
+            timer.uninstall()
+        res[name] = entry
+        ts.close()
 
     # config 1's GPU twin: BasicAE masked-view pre-training step (autoencoder.py:78-93), fwd+bwd+Adam
     for b in (4, BATCH):
         torch.manual_seed(SEED)
         ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, learning_rate=1e-3, output_img_freq=500)).to(dev)
-        opt = HipAdam(ae.parameters(), lr=1e-3)
-        opt.overlap_with_backward()
-        views = torch.rand(b, 6, 3, H, W, device=dev)
-
-        def ae_step(i):
-            ae.zero_grad(set_to_none=True)
-            ae.training_step(views, i)["loss"].backward()
-            opt.step()
-        finish(f"config1_ae_pretrain_bs{b}", time_steps(ae_step, steps, warmup), b, {"dtype": "f32"})
-        opt.close()
-        del ae, opt, views
+        run(f"config1_ae_pretrain_bs{b}", ae, torch.rand(b, 6, 3, H, W, device=dev), b, {"dtype": "f32"})
+        del ae
         torch.cuda.empty_cache()
-    # config 3: BBSpatialRoadMap, frozen AE encoder (spatial_w_rm.py), bs = 32, fwd+bwd+Adam on the heads
-    torch.manual_seed(SEED)
-    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT))
-    m = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=10 ** 9, learning_rate=1e-3, output_img_freq=500, mse_loss=False)).to(dev)
-    opt = HipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
-    opt.overlap_with_backward()
-    views = torch.rand(BATCH, 6, 3, H, W, device=dev)
-    road = torch.rand(BATCH, 800, 800, device=dev) < 0.3
-    tgt = tuple({"bb_map": (torch.rand(800, 800, device=dev) < 0.02).float()} for _ in range(BATCH))
-    batch = (tuple(views), tgt, tuple(road))
-
-    def bbox_step(i):
-        m.zero_grad(set_to_none=True)
-        m.training_step(batch, i)["loss"].backward()
-        opt.step()
-    dt = time_steps(bbox_step, steps, warmup)
-    gf = (69.14 + 138.28 + 11.64) * BATCH       # head fwd + head bwd + frozen encoder fwd, GFLOP per step (SURVEY.md 8d)
-    finish("config3_bbox_frozen_encoder_bs32", dt, BATCH, {"dtype": "f32", "algorithmic_TFLOPs": round(gf / dt / 1e3, 1),
-                                                           "frac_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_F32_MFMA_TF, 3)})
-    del m, ae, opt
-    torch.cuda.empty_cache()
-    # config 4, per GPU: joint roadmap + bounding-box step (one shared encoder pass, both heads, summed losses), bs = 32
-    from driving_dirty_amd.joint import JointRoadMapBBox
-    torch.manual_seed(SEED)
-    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT))
-    m = JointRoadMapBBox(Namespace(pretrained_ae=ae, learning_rate=1e-3, output_img_freq=500)).to(dev)
-    opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()
-
-    def joint_step(i):
-        m.zero_grad(set_to_none=True)
-        m.training_step(batch, i)["loss"].backward()
-        opt.step()
-    finish("config4_joint_roadmap_bbox_bs32_per_gpu", time_steps(joint_step, steps, warmup), BATCH, {"dtype": "f32"})
-    opt.close()
-    del m, ae, opt, batch, views, road, tgt
-    torch.cuda.empty_cache()
-    # config 5, per GPU: bf16 mixed precision at 2x resolution (6x3x512x612), bs = 16, roadmap step fwd+bwd+Adam
-    torch.manual_seed(SEED)
-    h2, w2, b5 = 2 * H, 2 * W, 16
-    ae = BasicAE(Namespace(hidden_dim=HIDDEN, latent_dim=LATENT, input_height=h2, input_width=6 * w2, output_height=h2, output_width=w2))
-    m = RoadMapBCE(Namespace(pretrained_ae=ae, precision="bf16", unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=10 ** 9)).to(dev)
-    batch = (tuple(torch.rand(b5, 6, 3, h2, w2, device=dev)), None, tuple(torch.rand(b5, 800, 800, device=dev) < 0.3))
-    opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()
-
-    def bf16_step(i):
-        m.zero_grad(set_to_none=True)
-        m.training_step(batch, i)["loss"].backward()
-        opt.step()
-    finish("config5_bf16_2x_resolution_bs16", time_steps(bf16_step, steps, warmup), b5, {"dtype": "bf16 (fp32 master weights, accumulate, tail)"})
-    opt.close()
-    del m, ae, opt, batch
-    torch.cuda.empty_cache()
+    names = {3: "config3_bbox_frozen_encoder_bs32", 4: "config4_joint_roadmap_bbox_bs32_per_gpu", 5: "config5_bf16_2x_resolution_bs16"}
+    for c in (3, 4, 5):
+        cfg = setup_config(Namespace(config=c, rows_per_task=0), dev, 0)
+        extra = {"dtype": "bf16 (fp32 master weights, accumulate, tail)" if c == 5 else "f32"}
+        algo = cfg["flop_per_scene"] * cfg["per_gpu_batch"]
+        peak = PEAK_BF16_MFMA_TF if c == 5 else PEAK_F32_MFMA_TF
+        run(names[c], cfg["model"], cfg["batch"], cfg["per_gpu_batch"], extra, cfg["watch"], c)
+        ms = res[names[c]]["ms_per_step"]
+        res[names[c]].update(algorithmic_TFLOPs=round(algo / (ms * 1e-3) / 1e12, 1),
+                             **{("frac_bf16_mfma_peak" if c == 5 else "frac_fp32_mfma_peak"): round(algo / (ms * 1e-3) / 1e12 / peak, 4)})
+        del cfg
+        torch.cuda.empty_cache()
     # config 2 at the reference's DEFAULT width (autoencoder.py:33-34,164-166: hidden 256 / latent 128; SURVEY.md 8d "also report 256/128"):
     # fc1 962 MB, head 328 MB, the encoder tail on the separate Linear / BatchNorm kernels
     torch.manual_seed(SEED)
     ae = BasicAE(Namespace(hidden_dim=256, latent_dim=128))
     m = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500)).to(dev)
-    opt = HipAdam(m.parameters(), lr=1e-3)
-    opt.overlap_with_backward()
-    batch = synthetic_batch(dev, BATCH, 0)
-
-    def wide_step(i):
-        m.zero_grad(set_to_none=True)
-        m.training_step(batch, i)["loss"].backward()
-        opt.step()
-    finish("config2_hidden256_latent128_bs32", time_steps(wide_step, steps, warmup), BATCH, {"dtype": "f32"})
-    opt.close()
+    run("config2_hidden256_latent128_bs32", m, synthetic_batch(dev, BATCH, 0), BATCH, {"dtype": "f32"})
     return res
 
 
 UPCONV1_FLOP_PER_SCENE = 2.0 * 256 * 256 * 49 * 96 * 64      # RoadMapBoxesMergingCNN.up_conv_1 (components.py:135), one pass
+UPCONV2_FLOP_PER_SCENE = 2.0 * 298 * 298 * 49 * 64 * 32      # up_conv_2 (components.py:136): input 298 x 298
 
 
 def box_batch(dev, batch, rank):
@@ -493,7 +474,10 @@ def setup_config(a, dev, rank):
             metric = "6-view scenes/sec fwd+bwd, joint roadmap+bbox bs=32 per GPU"
         watch = {"up_conv_1_fwd": ("dd_dconv_fwd", lambda *x: _desc(x[5]).cin == 96 and _desc(x[5]).cout == 64),
                  "up_conv_1_dgrad": ("dd_dconv_fwd", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96),
-                 "up_conv_1_wgrad": ("dd_dconv_wgrad", lambda *x: x[8] == 96 and x[13] == 64)}
+                 "up_conv_1_wgrad": ("dd_dconv_wgrad", lambda *x: x[8] == 96 and x[13] == 64),
+                 "up_conv_2_fwd": ("dd_dconv_fwd", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 32 and _desc(x[5]).kh == 7),
+                 "up_conv_2_dgrad": ("dd_dconv_fwd", lambda *x: _desc(x[5]).cin == 32 and _desc(x[5]).cout == 64 and _desc(x[5]).kh == 7),
+                 "up_conv_2_wgrad": ("dd_dconv_wgrad", lambda *x: x[8] == 64 and x[13] == 32 and x[14] == 7)}
         return dict(model=model, batch=box_batch(dev, BATCH, rank), per_gpu_batch=BATCH, dtype="f32", metric=metric, workload=what,
                     flop_per_scene=flop, watch=watch)
     # config 5: bf16 mixed precision at 2x resolution (6x3x512x612), bs = 16 per GPU (128 on 8 GPUs), roadmap step
@@ -575,8 +559,31 @@ def refresh_traffic(roof, pmc):
         roof["traffic_live"] = how
 
 
-def watched_roofline(cfg, timer, per_gpu_batch):
-    """Configs 3 / 4 / 5: the watched C-ABI launches -> the dominant kernel's roofline."""
+def config5_step_bytes(per_gpu_batch, shard_world=1):
+    """Algorithmic HBM bytes of one config-5 step (bf16 activations, fp32 parameters): every activation
+    written once and read once per consumer, the two big weights read twice and their gradients written once, Adam's seven
+    passes over the parameters it owns.  P = full-resolution pixels of the batch (512 x 3672 per scene), q = P / 4."""
+    P = 512 * 3672 * per_gpu_batch
+    per_pixel = (20      # stitch: 12 B of fp32 views in, 8 B of bf16 NHWC4 out
+                 + 76    # c1 forward: 8 in, 64 out, 4 of sign bits
+                 + 132   # c2 forward: 64 in, 64 out, 4 of sign bits
+                 + 81    # c3 forward (stride 2): 64 in at P, 64 + 4 out at q
+                 + 25    # pool forward: 64 in, 32 (fp32 pooled) + 4 (routing codes) out, at q
+                 + 25    # pool backward
+                 + 84    # c3 data gradient: 64 in at q, sign bits 4 and 64 out at P
+                 + 80    # c3 weight gradient: 64 at P + 64 at q
+                 + 132   # c2 data gradient
+                 + 128   # c2 weight gradient
+                 + 72)   # c1 weight gradient: 8 + 64
+    fc1 = (32 * 256 * 1836 // 4) * HIDDEN * 4.0
+    head = LATENT * 640000 * 4.0
+    return P * float(per_pixel) + 3.0 * (fc1 + head) + 7.0 * (fc1 + head) / shard_world
+
+
+def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
+    """Configs 3 / 4 / 5: the watched C-ABI launches -> the dominant kernel's roofline.  Config 5 (bf16) prices every kernel against
+    BOTH roofs -- the time its algorithmic flops need at the dense bf16 matrix peak and its algorithmic bytes at the HBM peak -- and
+    reports the one that binds (the larger): min(MFMA, HBM) as SURVEY.md 8d asks."""
     kernels = {}
     for key in timer.pairs:
         ms = timer.mean_ms(key)
@@ -584,10 +591,14 @@ def watched_roofline(cfg, timer, per_gpu_batch):
             continue
         entry = {"launch_ms": round(ms, 4), "launches_timed": len(timer.pairs[key])}
         if cfg in (3, 4):
-            flop = UPCONV1_FLOP_PER_SCENE * per_gpu_batch
+            layer, what = key.rsplit("_", 1)
+            flop = {"up_conv_1": UPCONV1_FLOP_PER_SCENE, "up_conv_2": UPCONV2_FLOP_PER_SCENE}[layer] * per_gpu_batch
             entry.update(kernel={"up_conv_1_fwd": "dconv_tfwd_kernel (up_conv_1 forward, input-aligned)",
                                  "up_conv_1_dgrad": "dconv_gfwd_kernel (up_conv_1 data gradient)",
-                                 "up_conv_1_wgrad": "dconv_wgrad_kernel (up_conv_1 weight gradient)"}[key],
+                                 "up_conv_1_wgrad": "dconv_wgrad_kernel (up_conv_1 weight gradient)",
+                                 "up_conv_2_fwd": "dconv_tfwd_kernel (up_conv_2 forward)",
+                                 "up_conv_2_dgrad": "dconv_fwd_kernel (up_conv_2 data gradient, gather form)",
+                                 "up_conv_2_wgrad": "dconv_wgrad_kernel (up_conv_2 weight gradient)"}[key],
                          bound="mfma", achieved=round(flop / (ms * 1e-3) / 1e12, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                          frac=round(flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4))
         else:
@@ -596,31 +607,179 @@ def watched_roofline(cfg, timer, per_gpu_batch):
                       "c2_fwd_bf16": px * (64 + 64 + 4.0),                    # bf16 NHWC in + out, one sign word per pixel
                       "c2_dgrad_bf16": px * (64 + 64 + 4.0),
                       "c2_wgrad_bf16": px * (64 + 64.0)}[key]
-            entry.update(kernel={"adam_fc1": "adam_kernel (fc1.fc1.weight, 481 M elements, side stream)", "c2_fwd_bf16": "conv_bf16_fwd (c2)",
-                                 "c2_dgrad_bf16": "conv_bf16_dgrad (c2)", "c2_wgrad_bf16": "conv_bf16_wgrad (c2)"}[key],
-                         bound="hbm", achieved=round(nbytes / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                         frac=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+            flop = 0.0 if key == "adam_fc1" else 2.0 * px * 32 * 288
+            t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), flop / (PEAK_BF16_MFMA_TF * 1e12)
+            hbm_frac = round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            mfma_frac = round(flop / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF, 4)
+            name = {"adam_fc1": "adam_kernel (fc1.fc1.weight, 481 M elements, side stream)", "c2_fwd_bf16": "conv_bf16_fwd (c2)",
+                    "c2_dgrad_bf16": "conv_bf16_dgrad (c2)", "c2_wgrad_bf16": "conv_bf16_wgrad (c2)"}[key]
+            if t_hbm >= t_mfma:
+                entry.update(kernel=name, bound="hbm", achieved=round(nbytes / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
+            else:
+                entry.update(kernel=name, bound="mfma", achieved=round(flop / (ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s", frac=mfma_frac)
+            entry.update(hbm_frac=hbm_frac, mfma_frac=mfma_frac, roof_ms={"hbm": round(t_hbm * 1e3, 4), "mfma": round(t_mfma * 1e3, 4)})
         kernels[key] = entry
     if not kernels:
         return None
     dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])
     k = kernels[dom]
-    return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
+    roof = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
             "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"], "traffic": None, "kernels": kernels}
+    if cfg == 5 and step_ms:
+        nbytes = config5_step_bytes(per_gpu_batch)
+        roof["step"] = {"algorithmic_bytes": nbytes, "TBps": round(nbytes / (step_ms * 1e-3) / 1e12, 3),
+                        "hbm_frac": round(nbytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "of_which_adam_bytes": 7.0 * ((32 * 256 * 1836 // 4) * HIDDEN + LATENT * 640000) * 4.0}
+    return roof
+
+
+class RankStderr:
+    """Prefix every line this rank writes to stderr (tracebacks included) with its rank, so the output of N processes that
+    share one terminal or log can be told apart."""
+
+    def __init__(self, rank, raw):
+        self.tag, self.raw, self.bol = f"[rank {rank}] ", raw, True
+
+    def write(self, text):
+        out = []
+        for ch in text.splitlines(keepends=True):
+            out.append((self.tag if self.bol else "") + ch)
+            self.bol = ch.endswith("\n")
+        self.raw.write("".join(out))
+        return len(text)
+
+    def flush(self):
+        self.raw.flush()
+
+    def __getattr__(self, name):
+        return getattr(self.raw, name)
+
+
+class Watchdog:
+    """A rank that makes no progress for ``limit`` seconds (a peer that never joined the rendezvous, a collective whose partner died,
+    a kernel that never ends) prints where it stands and EXITS with status 3 -- `os._exit`: never an exec, the process has touched
+    the GPU -- so that the launcher (or torch.distributed.run) tears the job down instead of sitting out the driver's limit in
+    silence.  ``beat(phase)`` is called at every phase change and every step."""
+
+    def __init__(self, rank, limit):
+        import threading
+        self.rank, self.limit = rank, float(limit)
+        self.phase, self.last = "start", time.monotonic()
+        self.done = False
+        if self.limit > 0:
+            threading.Thread(target=self._run, name="dd-watchdog", daemon=True).start()
+
+    def beat(self, phase):
+        self.phase, self.last = phase, time.monotonic()
+
+    def stop(self):
+        self.done = True
+
+    def _run(self):
+        import faulthandler
+        while not self.done:
+            time.sleep(min(1.0, self.limit / 4))
+            idle = time.monotonic() - self.last
+            if not self.done and idle > self.limit:
+                sys.stderr.write(f"bench.py watchdog: rank {self.rank} made no progress for {idle:.0f} s in phase '{self.phase}' "
+                                 f"(limit {self.limit:.0f} s, DD_WATCHDOG_S); exiting with status 3\n")
+                try:
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    sys.stderr.flush()
+                finally:
+                    os._exit(3)
+
+
+def init_distributed(world, rank, dev, backend, dog):
+    """Rendezvous with a BOUNDED wait, then one collective that every rank must reach (the preflight count)."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")             # RCCL's own warnings carry host:pid:rank
+    limit = datetime.timedelta(seconds=float(os.environ.get("DD_DIST_TIMEOUT_S", "120")))
+    dog.beat("rendezvous")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+    dog.beat("preflight collective")
+    ones = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    seen = int(round(float(ones.item())))
+    info = {"backend": backend, "n_ranks_seen": seen, "world_size": world, "dist_timeout_s": limit.total_seconds()}
+    if dev is not None:
+        info.update(visible_devices=torch.cuda.device_count(), device=torch.cuda.get_device_name(dev),
+                    HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES"), ROCR_VISIBLE_DEVICES=os.environ.get("ROCR_VISIBLE_DEVICES"))
+        if backend == "nccl":
+            try:
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:      # noqa: BLE001  (diagnostics only)
+                info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    if rank == 0:
+        sys.stderr.write("bench.py preflight: " + json.dumps(info) + "\n")
+        sys.stderr.flush()
+    if seen != world:
+        raise SystemExit(f"preflight: {seen} ranks answered, WORLD_SIZE is {world}")
+    return info
+
+
+def fault_injection(rank, i):
+    """DD_BENCH_FAULT="<rank>:<step>[:hang]": that rank dies (or hangs) at that step -- the failure-path tests' lever."""
+    spec = os.environ.get("DD_BENCH_FAULT")
+    if not spec:
+        return
+    parts = spec.split(":")
+    if int(parts[0]) == rank and int(parts[1]) == i:
+        if len(parts) > 2 and parts[2] == "hang":
+            sys.stderr.write(f"bench.py: injected hang on rank {rank} at step {i}\n")
+            time.sleep(10 ** 6)
+        sys.stderr.write(f"bench.py: injected fault on rank {rank} at step {i}\n")
+        sys.stderr.flush()
+        os._exit(17)
+
+
+def control_flow_rehearsal(a, world, rank, dog):
+    """DD_BENCH_CONTROL_ONLY=1: the rank's CONTROL flow -- bounded rendezvous, preflight, barriers, one collective per step,
+    the timing reductions, the watchdog -- over gloo with no model and no kernel, for the failure-path tests on a machine without a
+    GPU.  Prints a rehearsal record, never a benchmark line."""
+    import torch
+    import torch.distributed as dist
+    info = init_distributed(world, rank, None, "gloo", dog)
+    t = torch.zeros(1 << 16)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup + a.steps):
+        dog.beat(f"step {i}")
+        fault_injection(rank, i)
+        t.fill_(float(rank + i))
+        dist.all_reduce(t)
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"control_flow_rehearsal": True, "n_ranks_seen": info["n_ranks_seen"], "steps": a.steps, "warmup": a.warmup}), flush=True)
+    dog.stop()
+    dist.destroy_process_group()
 
 
 def run_rank(a):
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("DD_RESERVED_CUS", "16"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        sys.stderr = RankStderr(rank, sys.stderr)
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE {world}: start either `python bench.py --gpus N` (self-launching) or "
                          f"torch.distributed.run with --nproc-per-node equal to --gpus")
+    # the first import of torch on a fresh box pages the image in (1-2 min): the watchdog's clock starts after it
+    import torch
+    import torch.distributed as dist
+    dog = Watchdog(rank, float(os.environ.get("DD_WATCHDOG_S", "150")) if world > 1 or os.environ.get("DD_WATCHDOG_S") else 0)
+    if os.environ.get("DD_BENCH_CONTROL_ONLY") == "1":
+        return control_flow_rehearsal(a, world, rank, dog)
+    if world > 1:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("DD_RESERVED_CUS", "16"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # one process per GPU; DD_DIST_BACKEND=gloo + several ranks on ONE card is only a rehearsal of the N > 1
@@ -632,22 +791,17 @@ def run_rank(a):
     if rehearse:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("DD_RESERVED_CUS", "16"))
         os.environ.setdefault("MASTER_PORT", "29533")
-    if world > 1 or rehearse:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    comm = world > 1 or rehearse
+    preflight = init_distributed(world, rank, dev, backend, dog) if comm else None
 
     from driving_dirty_amd import _lib
     from driving_dirty_amd import ops as _ops
-    from driving_dirty_amd.ddp import GradSync
-    from driving_dirty_amd.optim import HipAdam
+    from driving_dirty_amd.train import TrainStep
     _lib.lib()                                            # fail loudly if the HIP library is missing
-    # RCCL's all-reduce workgroups run for milliseconds beside the conv backward and need LDS the conv workgroups do not
+    # RCCL's collective workgroups run for milliseconds beside the conv backward and need LDS the conv workgroups do not
     # leave free: GradSync gives them their own compute units (and RCCL is capped at as many channels) from the first big
     # gradient to the end of the step, so the conv grids stay one resident round.  DD_RESERVED_CUS overrides.
-    reserve = int(os.environ.get("DD_RESERVED_CUS", "16")) if (world > 1 or rehearse) else 0
+    reserve = int(os.environ.get("DD_RESERVED_CUS", "16")) if comm else 0
     if a.cu_budget:
         _lib.check(_lib.lib().dd_set_cu_budget(a.cu_budget), "dd_set_cu_budget")
 
@@ -656,16 +810,17 @@ def run_rank(a):
         _ops.WINOGRAD = False
     if a.wino_1d:
         _ops.WINOGRAD_2D = False
+    dog.beat("model")
     cfg = setup_config(a, dev, rank)
     model, batch, per_gpu = cfg["model"], cfg["batch"], cfg["per_gpu_batch"]
+    overlap = {"on": True, "off": False, "auto": True}[a.adam_overlap] and not a.no_adam_overlap
+    # sharded optimizer: where the gradient message cannot hide under the backward as ONE all-reduce
+    shard = (comm or a.simulate_shard > 1) and {"on": True, "off": False, "auto": a.config in (4, 5) or a.simulate_shard > 1}[a.shard_optimizer]
     # The optimizer and the gradient synchronisation are built over the model AS CONSTRUCTED -- feature extractor still frozen
     # (roadmap_bce_v2.py:45-47, spatial_w_rm.py:45-48): the first training_step unfreezes it where the config says so, and
-    # LightningModule.unfreeze() re-arms both (ddp.GradSync.refresh, optim.HipAdam.refresh).
-    opt = HipAdam(model.parameters(), lr=1e-3)
-    sync = GradSync(model, reserve_cus=reserve, force_collectives=rehearse)          # broadcasts rank 0's parameters and buffers
-    overlap = {"on": True, "off": False, "auto": True}[a.adam_overlap] and not a.no_adam_overlap
-    if overlap:
-        opt.overlap_with_backward(grad_scale=sync.grad_scale, grad_sync=sync if (world > 1 or rehearse) else None)
+    # LightningModule.unfreeze() re-arms both (driving_dirty_amd.train.TrainStep = HipAdam + GradSync, the step of this benchmark).
+    ts = TrainStep(model, lr=1e-3, adam_overlap=overlap, shard_optimizer=shard, reserve_cus=reserve, force_collectives=rehearse,
+                   simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False)
     if a.config == 2:
         timer = KernelTimer()
     else:
@@ -673,17 +828,15 @@ def run_rank(a):
     timer.install()
 
     def step(i):
-        model.zero_grad(set_to_none=True)
-        out = model.training_step(batch, i)
-        out["loss"].backward()
-        sync.finish()
-        opt.step(grad_scale=sync.grad_scale)
-        return out["loss"]
+        dog.beat(f"step {i}")
+        fault_injection(rank, i)
+        return ts(batch, i)["loss"]
 
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1 or rehearse:
+    if comm:
+        dog.beat("barrier before the timed region")
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
@@ -691,13 +844,16 @@ def run_rank(a):
     for i in range(a.steps):
         loss = step(a.warmup + i)
     torch.cuda.synchronize()
-    if world > 1 or rehearse:
+    if comm:
+        dog.beat("barrier after the timed region")
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    ts.sync_params()
     n_ranks_seen = 1
-    if world > 1 or rehearse:
+    if comm:
+        dog.beat("timing reductions")
         cdev = dev if backend == "nccl" else "cpu"
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -706,6 +862,7 @@ def run_rank(a):
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # every rank that took part in the timed region counts itself
         n_ranks_seen = int(round(float(ones.item())))
     loss_val = float(loss.detach())
+    dog.stop()                                            # what follows (rank 0's diagnostics, the CPU baseline) takes minutes by design
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -714,34 +871,39 @@ def run_rank(a):
         if a.config == 2:
             roof, pmc = config2_roofline(timer, _ops)
         else:
-            roof = watched_roofline(a.config, timer, per_gpu)
+            roof = watched_roofline(a.config, timer, per_gpu, ms)
         line = {
             "metric": cfg["metric"],
             "value": round(value, 2), "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic", "n_ranks_seen": n_ranks_seen,
             **({"rehearsal": "N > 1 call pattern on a 1-rank RCCL communicator (DD_REHEARSE_RCCL=1)"} if rehearse else {}),
+            **({"simulated": f"COMPUTE side of a {a.simulate_shard}-GPU sharded step on one GPU: Adam on rank 0's 1/{a.simulate_shard} of every big "
+                             "tensor, no collectives; a per-GPU lower bound, not a training step (parameters meaningless)"} if a.simulate_shard > 1 else {}),
             "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
-                       "adam_overlap": bool(overlap)},
+                       "adam_overlap": bool(overlap), "optimizer": "sharded (reduce-scatter, Adam on 1/N, all-gather)" if shard else "replicated"},
             # the step's algorithmic flops over its time, against the dense matrix peak of the dtype its convolutions run in
             ("step_algorithmic_frac_of_bf16_mfma_peak" if cfg["dtype"] == "bf16" else "step_algorithmic_frac_of_fp32_mfma_peak"):
                 round(cfg["flop_per_scene"] * per_gpu * world / (ms * 1e-3) / 1e12
                       / ((PEAK_BF16_MFMA_TF if cfg["dtype"] == "bf16" else PEAK_F32_MFMA_TF) * world), 4),
             "roofline": roof,
         }
-        if world == 1 and a.config == 2 and not a.no_others:
-            opt.close()
-            del model, opt, sync, batch, cfg
+        if preflight is not None:
+            line["preflight"] = preflight
+        if world == 1 and a.config == 2 and not a.no_others and not a.simulate_shard:
+            ts.close()
+            timer.uninstall()
+            del model, ts, batch, cfg
             torch.cuda.empty_cache()
-            line["others"] = other_configs(dev)
-        if world == 1 and a.config == 2 and pmc is not None and not a.no_others:
+            line["others"] = other_configs(a, dev)
+        if world == 1 and a.config == 2 and pmc is not None and not a.no_others and not a.simulate_shard:
             torch.cuda.empty_cache()      # this process's models are gone by now (deleted before `others`): the children get the GPU to themselves
             refresh_traffic(roof, pmc)
-        if not a.no_cpu_baseline and world == 1 and a.config == 2:
+        if not a.no_cpu_baseline and world == 1 and a.config == 2 and not a.simulate_shard:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1 or rehearse:
+    if comm:
         dist.barrier()
         dist.destroy_process_group()
 

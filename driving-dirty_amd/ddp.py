@@ -31,35 +31,88 @@ others are hooked the moment they become trainable -- ``LightningModule.unfreeze
 GradSync (``lightning.on_unfreeze``), and ``finish()`` catches whatever was switched on by hand (``p.requires_grad_(True)``)
 since: such a gradient is reduced there, synchronously, and hooked from then on.  Every rank takes the same decisions (the
 epoch counter is the same everywhere), so the collectives still pair up.
+
+Sharded optimizer (``shard_optimizer=True``; round 4).  Configs 4 and 5 of BASELINE.json exist only on 8 GPUs, and for config 5
+(2.09 GB of gradients, 14.6 GB of Adam traffic per step and GPU) the replicated optimizer is the largest single consumer of HBM
+bytes in the step.  In shard mode a big gradient is REDUCE-SCATTERED instead of all-reduced: the flat tensor is cut into the same
+in-order pieces, every piece into ``world`` equal slices, and rank r receives the sum of slice r of every piece (a persistent
+buffer of numel / world elements per tensor).  The optimizer then updates only the slices this rank owns -- Adam state exists only
+for them: 1/world of the moments' memory and of the pass's HBM traffic -- and every updated slice is ALL-GATHERED in place into the
+parameter (input = the owned slice of the output: no staging copy), asynchronously: the gather runs on RCCL's stream underneath the
+NEXT step's forward, and the first kernel that touches the parameter waits for it (``PARAM_WAITS``, consulted where the shims take a
+tensor's device pointer).  Same bytes on the links per step (RS + AG = AR), but each phase has its own compute to hide under, and
+the arithmetic is elementwise: the replicas hold bit-for-bit the parameters of the all-reduce path whenever the backend's
+reduce-scatter adds in the order of its all-reduce (gloo: always; tests/test_ddp_gloo.py, world sizes 2 and 4).  In shard mode
+``p.grad`` of a sharded tensor keeps THIS rank's local gradient; the reduced gradient exists only as ``shards(p)``.
+``simulate_world=N`` (one process, no communicator) cuts the shards of rank 0 of an N-rank job out of the local gradient and skips
+the gather: the COMPUTE side of an N-GPU sharded step on one GPU -- a timing aid (`bench.py --simulate-shard N`), the parameters
+it leaves are meaningless.
 """
 import torch
 import torch.distributed as dist
 
 from . import lightning
 
+# data_ptr of a parameter -> callable that makes the CURRENT stream wait for the all-gather still writing into it (shard mode).
+# ops._p / gconv._p pop and call the entry the first time a kernel operand with that address is handed to the C ABI.
+PARAM_WAITS = {}
+
+
+def param_ready(t):
+    """Wait (on the current stream) for an in-flight all-gather into ``t``; no-op otherwise."""
+    if PARAM_WAITS:
+        wait = PARAM_WAITS.pop(t.data_ptr(), None)
+        if wait is not None:
+            wait()
+
+
+class Shard:
+    """One piece's slice owned by this rank: ``param`` = flat view of p.data[lo:hi] (updated in place by the optimizer),
+    ``grad`` = the summed gradient of exactly those elements, valid once ``work`` (None: already there) has been waited for."""
+    __slots__ = ("work", "index", "lo", "hi", "piece_lo", "piece_hi", "param", "grad")
+
+    def __init__(self, work, index, lo, hi, piece_lo, piece_hi, param, grad):
+        self.work, self.index, self.lo, self.hi, self.piece_lo, self.piece_hi, self.param, self.grad = \
+            work, index, lo, hi, piece_lo, piece_hi, param, grad
+
 
 class GradSync:
-    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25, reserve_cus=0, force_collectives=False):
+    def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25, reserve_cus=0, force_collectives=False,
+                 shard_optimizer=False, simulate_world=0):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         # force_collectives: issue every collective even in a 1-rank group -- a rehearsal of the N > 1 call pattern (async
-        # all-reduce of gradient pieces from autograd hooks, the optimizer's per-piece waits, the CU hand-over) on the real
-        # backend when only one GPU is at hand; results are unchanged (a 1-rank all-reduce is the identity)
+        # all-reduce / reduce-scatter of gradient pieces from autograd hooks, the optimizer's per-piece waits, the all-gathers,
+        # the CU hand-over) on the real backend when only one GPU is at hand; results are unchanged (1-rank collectives are copies)
         self.active = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
+        self.simulate_world = int(simulate_world) if (simulate_world and not self.active) else 0
+        self.shard = bool(shard_optimizer) and (self.active or self.simulate_world > 0)
+        self.shard_world = self.simulate_world if self.simulate_world else self.world
         self.big_numel = big_numel
         self.chunk_numel = max(4, chunk_numel - chunk_numel % 4)      # pieces start on 16-byte boundaries
+        if self.shard:      # every piece splits into shard_world slices of whole 16-byte groups
+            q = 4 * self.shard_world
+            self.chunk_numel = max(q, chunk_numel - chunk_numel % q)
         # RCCL's workgroups need compute units the resident conv grids do not leave: while collectives are in flight (from
         # the first big gradient to finish()) the conv kernels are launched on 256 - reserve_cus units; the forward, which
-        # runs beside no collective, keeps the whole GPU.
+        # runs beside no collective (shard mode: beside the tail of the all-gathers), keeps the whole GPU.
         self.reserve_cus = int(reserve_cus) if self.active else 0
         self._reserved = False
         self.params = [p for p in module.parameters()]
+        # the module that owns each parameter directly: a consumer that CALLS that module (plain torch layers) waits for an
+        # in-flight all-gather through a forward pre-hook; the hot path's shims, which take weights by pointer, through PARAM_WAITS
+        self._owner = {p: m for m in module.modules() for p in m.parameters(recurse=False)}
+        self._pre_hooked = set()
         if self.active:      # every replica starts from rank 0's weights and BatchNorm statistics (DDP's contract)
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=self.group)
         self._handles = []
         self._by_param = {}
+        self._shards = {}          # p -> [Shard]: kept until the next backward replaces them (the optimizer reads them after finish())
+        self._gshard = {}          # p -> persistent numel / shard_world buffer the reduce-scatters write into
+        self._gathers = {}         # p -> [work]: all-gathers of updated slices still in flight
         self._small = []
         self._hooks = []
         self._hooked = set()
@@ -68,7 +121,7 @@ class GradSync:
 
     def refresh(self):
         """Hook every parameter that requires a gradient and has no hook yet (called again after an ``unfreeze()``)."""
-        if not self.active:
+        if not (self.active or self.shard):
             return
         for p in self.params:
             if p.requires_grad and p not in self._hooked:
@@ -79,54 +132,139 @@ class GradSync:
     def grad_scale(self):
         return 1.0 / self.world
 
+    # ---- the collectives (one place each: a backend without one of them can be served by overriding these) ----------------
+    def _all_reduce(self, t, async_op=True):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _reduce_scatter(self, out, inp):
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _all_gather(self, out, inp):
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+
+    def shardable(self, p):
+        """Whether ``p`` travels as reduce-scatter + all-gather: shard mode, a big contiguous tensor that splits evenly."""
+        return (self.shard and p.numel() >= self.big_numel and p.numel() % (4 * self.shard_world) == 0 and p.data.is_contiguous()
+                and (p.grad is None or p.grad.is_contiguous()))
+
+    def _pieces_of(self, n):
+        return [(off, min(off + self.chunk_numel, n)) for off in range(0, n, self.chunk_numel)]
+
+    def _reduce_big(self, p):
+        """Start the reduction of one big gradient: reduce-scatter per piece (shard mode) or all-reduce per piece."""
+        flat = p.grad.view(-1) if p.grad.is_contiguous() else None
+        if flat is not None and self.shardable(p):
+            w, r = self.shard_world, self.rank
+            gs = self._gshard.get(p)
+            if not self.simulate_world and (gs is None or gs.numel() != flat.numel() // w or gs.device != flat.device):
+                gs = self._gshard[p] = torch.empty(flat.numel() // w, device=flat.device, dtype=flat.dtype)
+            pflat = p.data.view(-1)
+            shards = []
+            for k, (a, b) in enumerate(self._pieces_of(flat.numel())):
+                n = (b - a) // w
+                lo = a + r * n
+                if self.simulate_world:          # rank 0's slice of the LOCAL gradient: no communicator to sum over
+                    work, out = None, flat[lo:lo + n]
+                else:
+                    out = gs[a // w:a // w + n]
+                    work = self._reduce_scatter(out, flat[a:b])
+                    self._handles.append(work)
+                shards.append(Shard(work, k, lo, lo + n, a, b, pflat[lo:lo + n], out))
+            self._shards[p] = shards
+            self._by_param.pop(p, None)
+            owner = self._owner.get(p)
+            if owner is not None and p not in self._pre_hooked:
+                self._hooks.append(owner.register_forward_pre_hook(lambda _m, _a, q=p: self.wait_param_gather(q)))
+                self._pre_hooked.add(p)
+            return
+        self._shards.pop(p, None)
+        if flat is not None:
+            pieces = []
+            for a, b in self._pieces_of(flat.numel()):
+                work = self._all_reduce(flat[a:b])
+                self._handles.append(work)
+                pieces.append((work, a, b - a))
+            self._by_param[p] = pieces
+        else:
+            work = self._all_reduce(p.grad)
+            self._handles.append(work)
+            self._by_param[p] = [(work, 0, p.grad.numel())]
+
     def _on_grad(self, p):
         if p.grad is None:
             return
-        if p.grad.numel() >= self.big_numel and self.reserve_cus and not self._reserved:
+        big = p.grad.numel() >= self.big_numel
+        if big and self.reserve_cus and not self._reserved:
             self._set_budget(256 - self.reserve_cus)
             self._reserved = True
-        if p.grad.numel() >= self.big_numel and p.grad.is_contiguous():
-            flat = p.grad.view(-1)
-            pieces = []
-            for off in range(0, flat.numel(), self.chunk_numel):
-                n = min(self.chunk_numel, flat.numel() - off)
-                work = dist.all_reduce(flat[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._handles.append(work)
-                pieces.append((work, off, n))
-            self._by_param[p] = pieces
-        elif p.grad.numel() >= self.big_numel:
-            work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._handles.append(work)
-            self._by_param[p] = [(work, 0, p.grad.numel())]
-        else:
+        if big and (self.active or self.shardable(p)):
+            self._reduce_big(p)
+        elif self.active:
             self._small.append(p)
 
     def pieces(self, p):
-        """[(work, offset, numel), ...] of the in-flight all-reduce of ``p`` in issue order (None: p went the small-tensor way)."""
+        """[(work, offset, numel), ...] of the in-flight all-reduce of ``p`` in issue order (None: p went the small-tensor way,
+        or travels as shards)."""
         return self._by_param.get(p)
 
+    def shards(self, p):
+        """[Shard, ...] of ``p`` from the latest backward (shard mode, big tensors), None otherwise.  Still valid after
+        ``finish()``: the optimizer may run after it."""
+        return self._shards.get(p) if self.shard else None
+
+    def gather_shard(self, p, shard):
+        """All-gather the updated slice ``shard.param`` into its piece of ``p``, in place and asynchronously, issued behind the
+        CURRENT stream's work (the optimizer pass that wrote the slice).  Whoever reads ``p`` next waits through PARAM_WAITS."""
+        if self.simulate_world or not self.active:
+            return
+        flat = p.data.view(-1)
+        work = self._all_gather(flat[shard.piece_lo:shard.piece_hi], shard.param)
+        self._gathers.setdefault(p, []).append(work)
+        PARAM_WAITS[p.data_ptr()] = lambda q=p: self.wait_param_gather(q)
+
+    def wait_param_gather(self, p):
+        PARAM_WAITS.pop(p.data_ptr(), None)
+        for work in self._gathers.pop(p, ()):
+            work.wait()
+
+    def wait_gathers(self):
+        """Make the current stream wait for every all-gather in flight: before validation, ``state_dict()``, a checkpoint, or
+        anything else that reads parameters outside the hot path's kernels."""
+        for p in list(self._gathers):
+            self.wait_param_gather(p)
+
     def wait_param(self, p):
-        """Make the CURRENT stream wait for the whole all-reduce of ``p`` (no-op when p went the small-tensor way)."""
+        """Make the CURRENT stream wait for the whole reduction of ``p`` (no-op when p went the small-tensor way)."""
         for work, _, _ in self._by_param.get(p) or ():
             work.wait()
+        for sh in self._shards.get(p) or ():
+            if sh.work is not None:
+                sh.work.wait()
 
     def finish(self):
         """Reduce the small gradients in one message and wait for everything in flight."""
         if self.active:
             # parameters switched to requires_grad by hand since the last refresh(): their hooks did not exist during this
             # backward, so their gradients are still local -- reduce them here (with the small tensors, or by themselves when
-            # big) and hook them for the steps to come
+            # big: as shards in shard mode, so that the optimizer sees one layout per tensor for good) and hook them
             late = [p for p in self.params if p.requires_grad and p not in self._hooked and p.grad is not None]
             for p in late:
                 if p.grad.numel() >= self.big_numel:
-                    self._handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._reduce_big(p)
                 else:
                     self._small.append(p)
             if late:
                 self.refresh()
+        elif self.shard:
+            late = [p for p in self.params if p.requires_grad and p not in self._hooked and p.grad is not None]
+            for p in late:
+                if self.shardable(p):
+                    self._reduce_big(p)
+            if late:
+                self.refresh()
         if self.active and self._small:
             flat = torch.cat([p.grad.reshape(-1) for p in self._small])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(flat, async_op=False)
             off = 0
             for p in self._small:
                 n = p.grad.numel()
@@ -145,8 +283,12 @@ class GradSync:
         _lib.check(_lib.lib().dd_set_cu_budget(cus), "dd_set_cu_budget")
 
     def remove(self):
+        self.wait_gathers()
         for h in self._hooks:
             h.remove()
         self._hooks = []
         self._hooked = set()
+        self._pre_hooked = set()
+        self._shards, self._gshard = {}, {}
         self.active = False
+        self.shard = False

@@ -17,6 +17,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
+from . import ddp as _ddp
 from ._lib import GConvDesc, check
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK, EPI_BIAS_SIGMOID = 0, 1, 2, 3, 4
@@ -27,7 +28,16 @@ def _stream():
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device pointer of a kernel operand.  A parameter whose all-gather (sharded optimizer, ddp.GradSync) is still in flight
+    is waited for -- on the current stream -- the first time it is handed to a kernel."""
+    if t is None:
+        return None
+    ptr = t.data_ptr()
+    if _ddp.PARAM_WAITS:
+        wait = _ddp.PARAM_WAITS.pop(ptr, None)
+        if wait is not None:
+            wait()
+    return C.c_void_p(ptr)
 
 
 def _chk(t, name):

@@ -11,6 +11,7 @@ import os
 import torch
 
 from . import _lib
+from . import ddp as _ddp
 from ._lib import ConvDesc, check
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK = 0, 1, 2, 3
@@ -22,7 +23,16 @@ def _stream():
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device pointer of a kernel operand.  A parameter whose all-gather (sharded optimizer, ddp.GradSync) is still in flight
+    is waited for -- on the current stream -- the first time it is handed to a kernel."""
+    if t is None:
+        return None
+    ptr = t.data_ptr()
+    if _ddp.PARAM_WAITS:
+        wait = _ddp.PARAM_WAITS.pop(ptr, None)
+        if wait is not None:
+            wait()
+    return C.c_void_p(ptr)
 
 
 def _dev(t, name, shape=None):

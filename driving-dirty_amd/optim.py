@@ -3,6 +3,12 @@ executed by ``dd_adam_step``, one fused read-modify-write pass per parameter ten
 
 ``grad_scale`` folds the 1/world_size of data-parallel gradient averaging into the same pass, so the
 all-reduced SUM never needs a separate divide kernel.
+
+Shard mode (``attach(grad_sync)`` / ``overlap_with_backward(grad_sync=...)`` with ``GradSync(shard_optimizer=True)``): a tensor
+that travels as reduce-scatter + all-gather is updated only in the slices this rank owns (``grad_sync.shards(p)``), its moments
+exist only for those slices (``state[p]["shards"][piece] = (exp_avg, exp_avg_sq)``), and each updated slice is handed straight
+back to ``grad_sync.gather_shard`` -- piece k's all-gather is on the links while piece k+1's update runs.  Elementwise, so the
+owned elements get bit for bit the update of the whole-tensor pass.
 """
 import os
 
@@ -33,6 +39,35 @@ class HipAdam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
 
+    def _launch(self, p, g, m, v, group, step, grad_scale):
+        """The one place the elementwise kernel is called (flat fp32 device tensors of equal length)."""
+        b1, b2 = group["betas"]
+        ops.adam_step_flat(p, g, m, v, group["lr"], b1, b2, group["eps"], step, grad_scale)
+
+    def attach(self, grad_sync):
+        """Use ``grad_sync`` (ddp.GradSync) for per-piece waits and, in shard mode, for the shards and their all-gathers."""
+        self._sync = grad_sync
+
+    def _update_shards(self, p, group, grad_scale, shards):
+        """The update of the slices of ``p`` this rank owns: wait (on the current stream) for piece k's reduce-scatter, update the
+        slice, start its all-gather behind the update, go on."""
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["shards"] = {}
+        if "shards" not in st:
+            raise RuntimeError("HipAdam: a tensor that was updated whole is now sharded (GradSync(shard_optimizer=True) must be "
+                               "attached before the first step)")
+        st["step"] += 1
+        for sh in shards:
+            if sh.work is not None:
+                sh.work.wait()
+            mv = st["shards"].get(sh.index)
+            if mv is None or mv[0].numel() != sh.param.numel():
+                mv = st["shards"][sh.index] = (torch.zeros_like(sh.param), torch.zeros_like(sh.param))
+            self._launch(sh.param, sh.grad, mv[0], mv[1], group, st["step"], grad_scale)
+            self._sync.gather_shard(p, sh)
+
     def _update_pieces(self, p, group, grad_scale, pieces):
         """The update of a tensor whose all-reduce travels in pieces: wait (on the current stream) for piece k, update that
         slice, go on -- the pass over piece k runs while piece k+1 is still on the links."""
@@ -47,16 +82,16 @@ class HipAdam(torch.optim.Optimizer):
         pf, gf, mf, vf = p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1)
         for work, off, n in pieces:
             work.wait()
-            ops.adam_step_flat(pf[off:off + n], gf[off:off + n], mf[off:off + n], vf[off:off + n], group["lr"], b1, b2,
-                               group["eps"], st["step"], grad_scale)
+            self._launch(pf[off:off + n], gf[off:off + n], mf[off:off + n], vf[off:off + n], group, st["step"], grad_scale)
 
     def _update(self, p, group, grad_scale):
         st = self._state_of(p)
+        if "shards" in st:
+            raise RuntimeError("HipAdam: a sharded tensor arrived without shards (GradSync.finish() of this step not reached, or the "
+                               "GradSync was removed while its optimizer lives on)")
         st["step"] += 1
-        b1, b2 = group["betas"]
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-        ops.adam_step_flat(p.data.view(-1), g.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
-                           group["lr"], b1, b2, group["eps"], st["step"], grad_scale)
+        self._launch(p.data.view(-1), g.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), group, st["step"], grad_scale)
 
     def overlap_with_backward(self, big_numel=1 << 20, grad_scale=1.0, grad_sync=None):
         """Run the Adam pass of every parameter of >= ``big_numel`` elements on a side stream the moment autograd has
@@ -70,7 +105,8 @@ class HipAdam(torch.optim.Optimizer):
         parameters and joins the side stream."""
         self._side = torch.cuda.Stream()
         self._scale = grad_scale
-        self._sync = grad_sync
+        if grad_sync is not None:
+            self._sync = grad_sync
         self._pending = []
         self._big_numel = big_numel
         self._hooked = set()
@@ -116,8 +152,11 @@ class HipAdam(torch.optim.Optimizer):
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
             for p, group in self._pending:
+                shards = self._sync.shards(p) if self._sync is not None else None
                 pieces = self._sync.pieces(p) if self._sync is not None else None
-                if pieces:                        # the side stream (not the host) waits for the all-reduce, piece by piece
+                if shards:                        # sharded optimizer: this rank's slices only, each all-gathered behind its update
+                    self._update_shards(p, group, self._scale, shards)
+                elif pieces:                      # the side stream (not the host) waits for the all-reduce, piece by piece
                     self._update_pieces(p, group, self._scale, pieces)
                 else:
                     self._update(p, group, self._scale)
@@ -132,6 +171,10 @@ class HipAdam(torch.optim.Optimizer):
             small = {}                            # step count -> [(p, g, m, v)]: one launch for all the small tensors
             for p in group["params"]:
                 if p.grad is None or p in self._early:
+                    continue
+                shards = self._sync.shards(p) if self._sync is not None else None
+                if shards:
+                    self._update_shards(p, group, grad_scale, shards)
                     continue
                 if p.numel() > self.SMALL_NUMEL or not p.grad.is_contiguous() or not p.data.is_contiguous():
                     self._update(p, group, grad_scale)

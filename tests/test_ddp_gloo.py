@@ -8,6 +8,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port  # noqa: E402
 
 
 def _net():
@@ -41,7 +43,7 @@ def _worker(rank, world, port, out):
 
 def test_gradsync_matches_full_batch(tmp_path):
     out = str(tmp_path / "g.pt")
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
     net = _net()
@@ -65,7 +67,7 @@ def test_gradsync_single_process_is_noop():
 def test_gradsync_broadcasts_rank0_weights(tmp_path):
     """Ranks seeded differently must leave GradSync's constructor with rank 0's parameters AND buffers."""
     out = str(tmp_path / "b.pt")
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_bcast_worker, args=(2, port, out), nprocs=2, join=True)
     sd0, sd1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert sorted(sd0) == sorted(sd1)
@@ -171,7 +173,7 @@ def test_gradsync_on_a_frozen_model_and_unfreeze_later(tmp_path, how):
     equal a single process fed the summed gradients."""
     sys.path.insert(0, ROOT)
     out = str(tmp_path / "f.pt")
-    port = 36500 + os.getpid() % 2000 + (7 if how == "by_hand" else 0)
+    port = free_port()
     mp.spawn(_frozen_worker, args=(2, port, out, how), nprocs=2, join=True)
     sd0, sd1 = torch.load(out + ".0"), torch.load(out + ".1")
     threads = torch.get_num_threads()
@@ -271,7 +273,7 @@ def test_hipadam_overlapped_under_data_parallel_matches_single_process(tmp_path)
     sys.path.insert(0, ROOT)
     from driving_dirty_amd.optim import HipAdam
     out = str(tmp_path / "a.pt")
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_adam_worker, args=(2, port, out), nprocs=2, join=True)
     got0, got1 = torch.load(out + ".0"), torch.load(out + ".1")
     dev = torch.device("cuda:0")
@@ -316,7 +318,7 @@ def test_bench_step_over_a_one_rank_rccl_communicator():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(DD_REHEARSE_RCCL="1", MASTER_PORT=str(35500 + os.getpid() % 2000))
+    env.update(DD_REHEARSE_RCCL="1", MASTER_PORT=str(free_port()))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-others", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -324,3 +326,56 @@ def test_bench_step_over_a_one_rank_rccl_communicator():
     assert line["n_ranks_seen"] == 1 and "rehearsal" in line and line["value"] > 0
     loss = line["config"]["final_loss"]
     assert loss == loss and abs(loss) < 1e3                                  # finite
+
+
+# ---- bench.py --gpus N: the failure paths of its first real multi-rank run, rehearsed on the control flow alone (no GPU here) ------
+def _bench_control(tmp_env, *args, timeout=120):
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(DD_BENCH_CONTROL_ONLY="1", **tmp_env)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+def test_bench_control_flow_rehearsal_two_ranks():
+    """Bounded rendezvous, preflight count, barriers, a collective per step, MAX-over-ranks timing: two gloo ranks, no kernels."""
+    import json
+    r, _ = _bench_control({}, "--gpus", "2", "--steps", "4", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec == {"control_flow_rehearsal": True, "n_ranks_seen": 2, "steps": 4, "warmup": 1}
+    pre = [ln for ln in r.stderr.splitlines() if "bench.py preflight:" in ln]
+    assert len(pre) == 1 and pre[0].startswith("[rank 0] ") and '"n_ranks_seen": 2' in pre[0]      # rank-tagged stderr, one preflight line
+
+
+def test_bench_rank_killed_mid_step_fails_fast_and_names_the_rank():
+    """Rank 1 dies inside step 2 (VERDICT r3 #2): `bench.py --gpus 2` returns non-zero within 30 s and says which rank failed."""
+    r, dt = _bench_control({"DD_BENCH_FAULT": "1:2"}, "--gpus", "2", "--steps", "6", "--warmup", "1")
+    assert r.returncode != 0 and dt < 30.0, (r.returncode, dt, r.stderr[-1500:])
+    assert "rank 1 exited with status 17" in r.stderr and "[rank 1] bench.py: injected fault on rank 1 at step 2" in r.stderr
+    assert "control_flow_rehearsal" not in r.stdout                       # no record from a failed job
+
+
+def test_bench_rank_hung_mid_step_is_ended_by_the_watchdog():
+    """Rank 1 stops making progress inside step 2 (a collective whose partner never arrives looks the same): the per-rank watchdog
+    prints the phase and a traceback and EXITS (status 3), the launcher tears the job down: non-zero within 30 s."""
+    r, dt = _bench_control({"DD_BENCH_FAULT": "1:2:hang", "DD_WATCHDOG_S": "4", "DD_DIST_TIMEOUT_S": "60"}, "--gpus", "2", "--steps", "6", "--warmup", "1")
+    assert r.returncode != 0 and dt < 30.0, (r.returncode, dt, r.stderr[-1500:])
+    assert "bench.py watchdog: rank" in r.stderr and "made no progress" in r.stderr and "in phase 'step 2'" in r.stderr
+    assert "exited with status 3" in r.stderr
+
+
+def test_bench_rendezvous_with_a_missing_rank_times_out():
+    """WORLD_SIZE says 2 but only one process shows up: the bounded rendezvous (or the watchdog) ends it -- no silent wait for the
+    driver's limit."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DD_BENCH_CONTROL_ONLY="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(free_port()), DD_DIST_TIMEOUT_S="5", DD_WATCHDOG_S="8")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.monotonic() - t0 < 40.0, (r.returncode, r.stderr[-1500:])

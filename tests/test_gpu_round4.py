@@ -1,0 +1,184 @@
+"""GPU tests, fourth set: the sharded optimizer on the real Adam kernel (two and four ranks on one card over gloo), the
+``TrainStep`` helper against ``configure_optimizers()``'s torch Adam, the N > 1 rehearsals of ``bench.py`` for configs 3 / 4 / 5 and
+of the reduce-scatter / all-gather call pattern on a one-rank RCCL communicator."""
+import json
+import os
+import subprocess
+import sys
+from argparse import Namespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from driving_dirty_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _tiny_model(dev, frozen_epochs=0):
+    from driving_dirty_amd import synth
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.roadmap import RoadMapBCE
+    ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132))
+    model = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=frozen_epochs, learning_rate=1e-2, output_img_freq=500))
+    synth.fill_module(model, seed=77)
+    model = model.to(dev)
+    model.ae.encoder.fc1.drop_p = model.ae.encoder.fc2.drop_p = 0.0
+    return model
+
+
+def _tiny_batch(dev, step, rank):
+    from driving_dirty_amd import synth
+    views = synth.camera_batch(3, 16, 22, seed=100 + 10 * step + rank).to(dev)
+    road = synth.road_maps(3, seed=100 + 10 * step + rank).to(dev)
+    return (tuple(views), None, tuple(road))
+
+
+# ------------------------------------------------------------------------------------------------ sharded optimizer, real kernel
+def _shard_worker(rank, world, port, out, shard, overlap):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from driving_dirty_amd import ddp
+    from driving_dirty_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    model = _tiny_model(dev, frozen_epochs=1)                 # the extractor stays frozen through epoch 0 (roadmap_bce_v2.py:127-129)
+    # head fc1.weight: 640000 x 8 = 5.12 M elements; chunk 1 << 20 -> 5 pieces; encoder fc1.fc1.weight 16 x 1056 = 16,896 -> big too
+    ts = TrainStep(model, lr=1e-2, adam_overlap=overlap, shard_optimizer=shard, big_numel=4096, chunk_numel=1 << 20, scheduler=False)
+    assert ts.sync.shard == shard
+    for step in range(4):
+        if step == 1:
+            model.current_epoch = 1                           # training_step unfreezes the extractor: GradSync / HipAdam re-arm
+        ts(_tiny_batch(dev, step, rank), step)
+        if shard:
+            sh = ts.sync.shards(model.fc1.weight)
+            assert sh is not None and len(sh) == 5
+            if step >= 1:
+                assert ts.sync.shards(model.ae.encoder.fc1.fc1.weight) is not None
+    if shard:
+        assert ddp.PARAM_WAITS or world == 1                  # the last step's all-gathers are still registered ...
+    ts.sync_params()
+    assert not ddp.PARAM_WAITS                                # ... and gone once waited for
+    if shard:
+        st = ts.optimizer.state[model.fc1.weight]
+        assert "exp_avg" not in st and sum(m.numel() for m, _ in st["shards"].values()) * world == model.fc1.weight.numel()
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in model.state_dict().items()}, f"{out}.{int(shard)}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, True), (2, False), (4, True)])
+def test_sharded_hipadam_is_bit_identical_to_the_all_reduce_path(tmp_path, dev, world, overlap):
+    """ddp.GradSync(shard_optimizer=True) + optim.HipAdam on the real kernel, `world` ranks on one card over gloo, a frozen extractor
+    unfrozen after step 0, Adam beside the backward or after it: every replica holds bit for bit the parameters the all-reduce path
+    leaves (reduce-scatter over gloo adds in its all-reduce's order; the update is elementwise)."""
+    out = str(tmp_path / "s.pt")
+    for shard in (False, True):
+        mp.spawn(_shard_worker, args=(world, free_port(), out, shard, overlap), nprocs=world, join=True)
+    ref = torch.load(f"{out}.0.0")
+    start = {k: v.cpu() for k, v in _tiny_model(dev, 1).state_dict().items()}
+    assert float((ref["ae.encoder.c2.weight"] - start["ae.encoder.c2.weight"]).abs().max()) > 0      # the unfrozen extractor trained
+    assert float((ref["fc1.weight"] - start["fc1.weight"]).abs().max()) > 0
+    for shard in (0, 1):
+        for rank in range(world):
+            sd = torch.load(f"{out}.{shard}.{rank}")
+            for k in ref:
+                assert torch.equal(sd[k], ref[k]), f"shard={shard} rank={rank}: {k} differs from the all-reduce path on rank 0"
+
+
+# ------------------------------------------------------------------------------------------------ TrainStep == the reference's loop
+def test_trainstep_matches_configure_optimizers_loop(dev):
+    """Two steps through train.TrainStep (HipAdam beside the backward, ReduceLROnPlateau attached) leave the parameters that two steps
+    of the reference's loop -- zero_grad / training_step / backward / step with configure_optimizers()'s torch.optim.Adam
+    (roadmap_bce_v2.py:154-157) -- leave, within the Adam kernel's own 1e-6."""
+    from driving_dirty_amd.train import TrainStep
+    a, b = _tiny_model(dev), _tiny_model(dev)
+    (opt,), (sched,) = a.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau)
+    ts = TrainStep(b)                                         # lr from hparams.learning_rate, scheduler because the module returns one
+    assert ts.scheduler is not None and ts.lr == 1e-2
+    losses = []
+    for step in range(2):
+        batch = _tiny_batch(dev, step, 0)
+        opt.zero_grad()
+        la = a.training_step(batch, step)["loss"]
+        la.backward()
+        opt.step()
+        lb = ts(batch, step)["loss"]
+        losses.append((float(la), float(lb)))
+    ts.sync_params()
+    assert abs(losses[0][0] - losses[0][1]) <= 1e-6 * abs(losses[0][0])
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        d = float((p.detach() - q.detach()).abs().max() / p.detach().abs().max().clamp_min(1e-30))
+        assert d <= 1e-6, (k, d)
+    # the plateau scheduler: 11 epochs without improvement cut the rate by 10 (patience 10), on both optimizers alike
+    for _ in range(12):
+        sched.step(1.0)
+        ts.validation_epoch_end(1.0)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-3) and ts.lr == pytest.approx(1e-3)
+    ts.close()
+
+
+def test_trainstep_has_no_scheduler_for_the_autoencoder(dev):
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.train import TrainStep
+    ae = BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132, output_height=16, output_width=22,
+                           learning_rate=1e-3, output_img_freq=500)).to(dev)
+    ts = TrainStep(ae)
+    assert ts.scheduler is None                               # autoencoder.py:119-120 returns the bare optimizer
+    ts.close()
+
+
+# ------------------------------------------------------------------------------------------------ bench.py rehearsals
+def _bench(env_extra, *args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--no-others", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+def test_bench_sharded_step_over_a_one_rank_rccl_communicator(dev):
+    """The sharded step's call pattern on the real backend: RCCL reduce-scatter per gradient piece from the autograd hooks, Adam on
+    the owned slices on the side stream, in-place all-gather behind each, the wait where the next forward first touches the
+    parameter (1-rank collectives are copies: the loss must equal the replicated step's)."""
+    line, err = _bench({"DD_REHEARSE_RCCL": "1", "MASTER_PORT": str(free_port())}, "--steps", "3", "--warmup", "2",
+                       "--shard-optimizer", "on")
+    assert line["n_ranks_seen"] == 1 and "rehearsal" in line and line["config"]["optimizer"].startswith("sharded")
+    assert line["preflight"]["backend"] == "nccl" and "rccl_version" in line["preflight"] and "bench.py preflight:" in err
+    plain, _ = _bench({"DD_REHEARSE_RCCL": "1", "MASTER_PORT": str(free_port())}, "--steps", "3", "--warmup", "2",
+                      "--shard-optimizer", "off")
+    assert plain["config"]["optimizer"] == "replicated"
+    assert abs(line["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-6 * abs(plain["config"]["final_loss"])
+
+
+@pytest.mark.parametrize("config", [3, 4, 5])
+def test_bench_two_ranks_over_gloo_on_one_card(dev, config):
+    """`bench.py --gpus 2 --config C` starting its own ranks, both on this card, gradients over gloo (DD_DIST_BACKEND=gloo): the N > 1
+    control flow of every BASELINE configuration that exists only on several GPUs -- config 4 and 5 on the sharded optimizer (auto)."""
+    line, err = _bench({"DD_DIST_BACKEND": "gloo", "DD_RESERVED_CUS": "0"}, "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1")
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["baseline_config"] == config
+    assert line["config"]["optimizer"].startswith("sharded" if config in (4, 5) else "replicated")
+    assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]
+    assert line["roofline"] is not None and line["roofline"]["frac"] > 0
+    assert "[rank 0] bench.py preflight:" in err
+
+
+def test_simulated_shard_step_runs(dev):
+    """`--simulate-shard 8`: the compute side of an 8-GPU sharded step on this one GPU (a timing aid; labelled as such)."""
+    line, _ = _bench({}, "--steps", "3", "--warmup", "2", "--simulate-shard", "8")
+    assert "simulated" in line and line["config"]["optimizer"].startswith("sharded") and line["value"] > 0
