@@ -92,11 +92,13 @@ def test_sharded_hipadam_is_bit_identical_to_the_all_reduce_path(tmp_path, dev, 
     start = {k: v.cpu() for k, v in _tiny_model(dev, 1).state_dict().items()}
     assert float((ref["ae.encoder.c2.weight"] - start["ae.encoder.c2.weight"]).abs().max()) > 0      # the unfrozen extractor trained
     assert float((ref["fc1.weight"] - start["fc1.weight"]).abs().max()) > 0
-    for shard in (0, 1):
-        for rank in range(world):
-            sd = torch.load(f"{out}.{shard}.{rank}")
-            for k in ref:
-                assert torch.equal(sd[k], ref[k]), f"shard={shard} rank={rank}: {k} differs from the all-reduce path on rank 0"
+    buffers = {k for k in ref if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}      # BatchNorm statistics stay per-rank
+    for rank in range(world):
+        plain, sharded = torch.load(f"{out}.0.{rank}"), torch.load(f"{out}.1.{rank}")
+        for k in ref:
+            assert torch.equal(sharded[k], plain[k]), f"rank {rank}: {k} differs between the sharded and the all-reduce run"
+            if k not in buffers:
+                assert torch.equal(plain[k], ref[k]), f"rank {rank}: parameter {k} differs from rank 0's"
 
 
 # ------------------------------------------------------------------------------------------------ TrainStep == the reference's loop
@@ -110,20 +112,29 @@ def test_trainstep_matches_configure_optimizers_loop(dev):
     assert isinstance(opt, torch.optim.Adam) and isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau)
     ts = TrainStep(b)                                         # lr from hparams.learning_rate, scheduler because the module returns one
     assert ts.scheduler is not None and ts.lr == 1e-2
-    losses = []
-    for step in range(2):
+    # step 0: both models hold the same parameters, the same kernels give the same gradients, only the optimizer differs: 1e-6.
+    # Before step 1 the torch-Adam model takes over the TrainStep model's parameters (they differ by that rounding, 2e-7 of an update,
+    # and Adam's m / sqrt(v) turns the resulting relative change of a near-zero gradient element into the same relative change of a
+    # full-size update: measured 9e-4 of peak on c2.weight); each optimizer keeps its OWN moments and step count from step 0, so step 1
+    # still compares the two optimizers' second steps -- on identical gradients.
+    for step, tol in ((0, 1e-6), (1, 1e-6)):
+        if step == 1:
+            with torch.no_grad():
+                for p, q in zip(a.parameters(), b.parameters()):
+                    p.copy_(q)
+            for (_, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+                u.copy_(v)
         batch = _tiny_batch(dev, step, 0)
         opt.zero_grad()
         la = a.training_step(batch, step)["loss"]
         la.backward()
         opt.step()
         lb = ts(batch, step)["loss"]
-        losses.append((float(la), float(lb)))
-    ts.sync_params()
-    assert abs(losses[0][0] - losses[0][1]) <= 1e-6 * abs(losses[0][0])
-    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-        d = float((p.detach() - q.detach()).abs().max() / p.detach().abs().max().clamp_min(1e-30))
-        assert d <= 1e-6, (k, d)
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la)), (step, float(la), float(lb))
+        ts.sync_params()
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            d = float((p.detach() - q.detach()).abs().max() / p.detach().abs().max().clamp_min(1e-30))
+            assert d <= tol, (step, k, d)
     # the plateau scheduler: 11 epochs without improvement cut the rate by 10 (patience 10), on both optimizers alike
     for _ in range(12):
         sched.step(1.0)
