@@ -559,6 +559,9 @@ def test_adam_overlapped_with_backward_is_identical(dev):
             n = p.numel()
             return [(self.Work(), o, min(1000, n - o)) for o in range(0, n, 1000)] if n >= 1000 else None
 
+        def shards(self, p):      # all-reduce mode: nothing travels as shards
+            return None
+
         def wait_param(self, p):
             pass
 
