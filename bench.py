@@ -424,7 +424,40 @@ def other_configs(a, dev, steps=10, warmup=3):
     ae = BasicAE(Namespace(hidden_dim=256, latent_dim=128))
     m = RoadMapBCE(Namespace(pretrained_ae=ae, unfreeze_epoch_no=0, learning_rate=1e-3, output_img_freq=500)).to(dev)
     run("config2_hidden256_latent128_bs32", m, synthetic_batch(dev, BATCH, 0), BATCH, {"dtype": "f32"})
+    del m, ae
+    torch.cuda.empty_cache()
+    res["config2_u8_h2d"] = u8_h2d_step(dev, steps, warmup)
     return res
+
+
+def u8_h2d_step(dev, steps, warmup):
+    """PCIe-INCLUSIVE rate of the headline step (never `value`): every batch starts in pinned HOST memory as decoded uint8 camera
+    frames (the collate's tuple of 32 x [6,256,306,3]) + bool road masks, crosses PCIe on a copy stream one batch ahead of the step
+    (driving_dirty_amd.prefetch.DevicePrefetcher) and is read by the model as it is (ToTensor's /255 fused into the 6-view gather)."""
+    import torch
+    from driving_dirty_amd.prefetch import DevicePrefetcher
+    from driving_dirty_amd.train import TrainStep
+    model = build_model(dev)
+    ts = TrainStep(model, lr=1e-3, scheduler=False)
+    g = torch.Generator().manual_seed(SEED)
+    host = []
+    for _ in range(2):
+        frames = torch.randint(0, 256, (BATCH, 6, H, W, 3), dtype=torch.uint8, generator=g)
+        road = torch.rand(BATCH, 800, 800, generator=g) < 0.3
+        host.append((tuple(f.clone().pin_memory() for f in frames), tuple({} for _ in range(BATCH)), tuple(r.clone().pin_memory() for r in road)))
+    nbytes = BATCH * (6 * H * W * 3 + 800 * 800)
+    t0 = None
+    for i, batch in enumerate(DevicePrefetcher((host[i & 1] for i in range(warmup + steps)), dev)):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        ts(batch, i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ts.close()
+    return {"ms_per_step": round(dt * 1e3, 3), "scenes_per_s": round(BATCH / dt, 1), "batch": BATCH, "steps": steps, "warmup": warmup, "dtype": "f32",
+            "input": "uint8 frames [6,256,306,3] per sample + bool road masks from pinned host memory, prefetched one batch ahead on a copy stream",
+            "pcie_bytes_per_step": nbytes, "pcie_GBs_needed": round(nbytes / dt / 1e9, 2)}
 
 
 UPCONV1_FLOP_PER_SCENE = 2.0 * 256 * 256 * 49 * 96 * 64      # RoadMapBoxesMergingCNN.up_conv_1 (components.py:135), one pass

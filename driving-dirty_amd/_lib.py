@@ -49,6 +49,7 @@ SIGNATURES = {
     "dd_stitch6_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_boxes_to_binary_map": (_i32, [_p, _i32, _p, _p, _i32, _p]),
     "dd_stitch6_u8": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "dd_stitch6_u8_ptrs": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_nchw_to_nhwc": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_subsample_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_subsample_nhwc4_u8_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "dd_deconv2x2_c1_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "dd_view_to_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_view_to_nhwc4_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_view_to_nhwc4_u8_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_add": (_i32, [_p, _p, _p, _i64, _p]),
     "dd_bce_probs": (_i32, [_p, _p, _p, _p, _i64, _f32, _p, _p]),
     "dd_linear_workspace_bytes": (_i64, [_i32, _i32, _i32]),
@@ -142,6 +144,7 @@ SIGNATURES = {
     "dd_conv_wino_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "dd_stitch6_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_stitch6_bf16_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "dd_stitch6_bf16_u8_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "dd_conv_bf16_packed_elems": (_i64, [_p]),
     "dd_conv_bf16_pack": (_i32, [_p, _p, _i32, _p, _p]),
     "dd_conv_bf16_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _p]),

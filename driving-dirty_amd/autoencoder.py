@@ -42,6 +42,8 @@ class BasicAE(LightningModule):
         view and the blanking happen in one HIP kernel.
         """
         target_img_index = int(np.random.randint(0, 5))
+        if x.dtype == torch.uint8:      # decoded frames [B,6,H,W,3]: ToTensor per view first (data_helper.py:63-68)
+            x = x.permute(0, 1, 4, 2, 3).float().div(255)
         _, wide, y = ops.stitch6(x.contiguous(), mask_slot=target_img_index, want_nhwc4=False, want_nchw=True,
                                  want_target=True)
         assert wide.size(-1) == 6 * x.size(-1)
@@ -55,7 +57,7 @@ class BasicAE(LightningModule):
         """autoencoder.py:78-93: mask one view, encode, decode, ``mse_loss(y, y_hat)``."""
         keeps = keeps or {}
         target_img_index = int(np.random.randint(0, 5))
-        wide4, _, y = ops.stitch6(batch.contiguous(), mask_slot=target_img_index, want_target=True)
+        wide4, y = ops.wide_image(batch, "fp32", mask_slot=target_img_index, want_target=True)      # fp32 views or uint8 frames
         z = self.encoder.forward_nhwc4(wide4, keeps.get("enc", (None, None)))
         y_hat = self(z, keeps.get("dec", (None, None)))
         if self.logger is not None and batch_idx % self.hparams.output_img_freq == 0:

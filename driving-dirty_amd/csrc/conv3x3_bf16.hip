@@ -678,6 +678,27 @@ __global__ __launch_bounds__(256) void stitch6_bf16_ptrs_kernel(const BfSamplePt
   }
 }
 
+// the same from uint8 HWC frames (per-sample [6,H,W,3], a JPEG decoder's output): ToTensor's /255 (a true division, as
+// torchvision does it) and the bf16 rounding of the quotient fused with the gather -- the values dd_stitch6_bf16 makes of
+// frames.float() / 255
+struct BfSamplePtrsU8 {
+  const unsigned char* p[64];
+};
+__global__ __launch_bounds__(256) void stitch6_bf16_u8_ptrs_kernel(const BfSamplePtrsU8 samples, u32x2* __restrict__ wide4, int B, int H, int W) {
+  const long npx = (long)B * H * 6 * W;
+  for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < npx; px += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(px % (6 * W));
+    const int yy = (int)((px / (6 * W)) % H);
+    const int b = (int)(px / ((long)6 * W * H));
+    const int slot = xw / W, xx = xw - slot * W;
+    const unsigned char* src = samples.p[b] + (((long)kViewOrderBf[slot] * H + yy) * W + xx) * 3;
+    u32x2 o;
+    o.x = pack_bf16((float)src[0] / 255.0f, (float)src[1] / 255.0f);
+    o.y = pack_bf16((float)src[2] / 255.0f, 0.f);
+    wide4[px] = o;
+  }
+}
+
 // max_pool1d(4) over the NCHW-flattened feature (components.py:46-47) from an NHWC bf16 tensor, H*W % 4 == 0:
 // thread = (4 consecutive flat pixels, 4 channels)
 __global__ __launch_bounds__(256) void pool4_bf16_fwd(const u32x2* __restrict__ feat, float* __restrict__ pooled, int B, long HW, int C) {
@@ -964,6 +985,22 @@ int dd_stitch6_bf16_ptrs(const float* const* sample_ptrs, uint16_t* wide_nhwc4, 
     hipLaunchKernelGGL(stitch6_bf16_ptrs_kernel, dim3((unsigned)min((npx + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
                        (hipStream_t)stream, tab, (u32x2*)wide_nhwc4 + (long)b0 * height * 6 * width, nb, height, width);
     DD_LAUNCH_CHECK("stitch6_bf16_ptrs");
+  }
+  return 0;
+}
+
+int dd_stitch6_bf16_u8_ptrs(const unsigned char* const* sample_ptrs, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
+                            void* stream) {
+  DD_REQUIRE(sample_ptrs && wide_nhwc4 && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "stitch6_bf16_u8_ptrs: bad argument");
+  for (int b0 = 0; b0 < batch; b0 += 64) {
+    const int nb = min(64, batch - b0);
+    BfSamplePtrsU8 tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < nb ? sample_ptrs[b0 + i] : nullptr;
+    for (int i = 0; i < nb; ++i) DD_REQUIRE(tab.p[i] != nullptr, DD_ERR_BAD_ARG, "stitch6_bf16_u8_ptrs: null sample pointer");
+    const long npx = (long)nb * height * 6 * width;
+    hipLaunchKernelGGL(stitch6_bf16_u8_ptrs_kernel, dim3((unsigned)min((npx + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
+                       (hipStream_t)stream, tab, (u32x2*)wide_nhwc4 + (long)b0 * height * 6 * width, nb, height, width);
+    DD_LAUNCH_CHECK("stitch6_bf16_u8_ptrs");
   }
   return 0;
 }

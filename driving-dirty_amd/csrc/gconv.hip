@@ -438,6 +438,28 @@ __global__ __launch_bounds__(256) void view_to_nhwc4_ptrs_kernel(const ViewSampl
   }
 }
 
+// the same from uint8 HWC frames (per-sample [6,H,W,3]): ToTensor's /255 (true division) fused with the re-layout
+struct ViewSamplePtrsU8 {
+  const unsigned char* p[64];
+};
+
+__global__ __launch_bounds__(256) void view_to_nhwc4_u8_ptrs_kernel(const ViewSamplePtrsU8 samples, f32x4* __restrict__ out, int B,
+                                                                    int H, int W, int view, int tf) {
+  const int Ho = (tf == 1 || tf == 2) ? W : H, Wo = (tf == 1 || tf == 2) ? H : W;
+  const long total = (long)B * Ho * Wo;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(p % Wo), i = (int)((p / Wo) % Ho);
+    const int b = (int)(p / ((long)Wo * Ho));
+    int ys, xs;
+    if (tf == 0) { ys = i; xs = j; }
+    else if (tf == 1) { ys = j; xs = W - 1 - i; }
+    else if (tf == 2) { ys = H - 1 - j; xs = i; }
+    else { ys = H - 1 - i; xs = W - 1 - j; }
+    const unsigned char* src = samples.p[b] + (((long)view * H + ys) * W + xs) * 3;
+    out[p] = f32x4{(float)src[0] / 255.0f, (float)src[1] / 255.0f, (float)src[2] / 255.0f, 0.f};
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
                                                   f32x4* __restrict__ out, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
@@ -1002,6 +1024,23 @@ int dd_view_to_nhwc4_ptrs(const float* const* sample_ptrs, float* out, int32_t b
     hipLaunchKernelGGL(view_to_nhwc4_ptrs_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
                        (hipStream_t)stream, tab, (f32x4*)out + (long)b0 * height * width, nb, height, width, view, transform);
     DD_LAUNCH_CHECK("view_to_nhwc4_ptrs");
+  }
+  return 0;
+}
+
+int dd_view_to_nhwc4_u8_ptrs(const unsigned char* const* sample_ptrs, float* out, int32_t batch, int32_t height, int32_t width,
+                             int32_t view, int32_t transform, void* stream) {
+  DD_REQUIRE(sample_ptrs && out && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "view_to_nhwc4_u8_ptrs: bad argument");
+  DD_REQUIRE(view >= 0 && view < 6 && transform >= 0 && transform <= 3, DD_ERR_BAD_ARG, "view_to_nhwc4_u8_ptrs: view %d transform %d", view, transform);
+  for (int b0 = 0; b0 < batch; b0 += 64) {
+    const int nb = min(64, batch - b0);
+    ViewSamplePtrsU8 tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < nb ? sample_ptrs[b0 + i] : nullptr;
+    for (int i = 0; i < nb; ++i) DD_REQUIRE(tab.p[i] != nullptr, DD_ERR_BAD_ARG, "view_to_nhwc4_u8_ptrs: null sample pointer");
+    const long total = (long)nb * height * width;
+    hipLaunchKernelGGL(view_to_nhwc4_u8_ptrs_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0,
+                       (hipStream_t)stream, tab, (f32x4*)out + (long)b0 * height * width, nb, height, width, view, transform);
+    DD_LAUNCH_CHECK("view_to_nhwc4_u8_ptrs");
   }
   return 0;
 }

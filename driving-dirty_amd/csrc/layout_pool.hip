@@ -69,8 +69,38 @@ __global__ __launch_bounds__(256) void stitch6_u8_kernel(const unsigned char* __
     const int b = (int)(p / ((long)6 * W * H));
     const int slot = xw / W, xx = xw - slot * W;
     const unsigned char* src = frames + ((((long)b * 6 + kViewOrder[slot]) * H + yy) * W + xx) * 3;
-    constexpr float s = 1.0f / 255.0f;
-    wide4[p] = f32x4{src[0] * s, src[1] * s, src[2] * s, 0.f};
+    // a true division, correctly rounded: bit for bit ToTensor's img.float().div(255) (x * (1/255.f) differs in the last place for
+    // some of the 256 values)
+    wide4[p] = f32x4{(float)src[0] / 255.0f, (float)src[1] / 255.0f, (float)src[2] / 255.0f, 0.f};
+  }
+}
+
+// The same from a table of per-sample base pointers (each [6,H,W,3] uint8: the collate's tuple of decoded frames), with the
+// masked-view task of BasicAE.six_to_one_task (autoencoder.py:59-73) optional: view slot `mask_slot` of the wide image is
+// blanked and written, as fp32 NCHW, to `target`.
+struct SamplePtrsU8 {
+  const unsigned char* p[64];
+};
+
+__global__ __launch_bounds__(256) void stitch6_u8_ptrs_kernel(const SamplePtrsU8 samples, f32x4* __restrict__ wide4,
+                                                              float* __restrict__ target, int B, int H, int W, int mask_slot) {
+  const long npx = (long)B * H * 6 * W;
+  const long plane = (long)H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(p % (6 * W));
+    const int yy = (int)((p / (6 * W)) % H);
+    const int b = (int)(p / ((long)6 * W * H));
+    const int slot = xw / W, xx = xw - slot * W;
+    const unsigned char* src = samples.p[b] + (((long)kViewOrder[slot] * H + yy) * W + xx) * 3;
+    float c0 = (float)src[0] / 255.0f, c1 = (float)src[1] / 255.0f, c2 = (float)src[2] / 255.0f;
+    if (slot == mask_slot) {
+      if (target) {
+        float* t = target + ((long)b * 3) * plane + (long)yy * W + xx;
+        t[0] = c0; t[plane] = c1; t[2 * plane] = c2;
+      }
+      c0 = c1 = c2 = 0.f;
+    }
+    wide4[p] = f32x4{c0, c1, c2, 0.f};
   }
 }
 
@@ -356,6 +386,24 @@ int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch,
   hipLaunchKernelGGL(stitch6_u8_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, frames, (f32x4*)wide_nhwc4,
                      batch, height, width);
   DD_LAUNCH_CHECK("stitch6_u8");
+  return 0;
+}
+
+int dd_stitch6_u8_ptrs(const unsigned char* const* sample_ptrs, float* wide_nhwc4, float* target, int32_t batch, int32_t height,
+                       int32_t width, int32_t mask_slot, void* stream) {
+  DD_REQUIRE(sample_ptrs && wide_nhwc4 && batch > 0 && height > 0 && width > 0, DD_ERR_BAD_ARG, "stitch6_u8_ptrs: bad argument");
+  DD_REQUIRE(mask_slot >= -1 && mask_slot < 6, DD_ERR_BAD_ARG, "stitch6_u8_ptrs: mask_slot %d", mask_slot);
+  for (int b0 = 0; b0 < batch; b0 += 64) {
+    const int nb = min(64, batch - b0);
+    SamplePtrsU8 tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < nb ? sample_ptrs[b0 + i] : nullptr;
+    for (int i = 0; i < nb; ++i) DD_REQUIRE(tab.p[i] != nullptr, DD_ERR_BAD_ARG, "stitch6_u8_ptrs: null sample pointer");
+    const long npx = (long)nb * height * 6 * width;
+    hipLaunchKernelGGL(stitch6_u8_ptrs_kernel, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, tab,
+                       (f32x4*)wide_nhwc4 + (long)b0 * height * 6 * width, target ? target + (long)b0 * 3 * height * width : nullptr, nb,
+                       height, width, mask_slot);
+    DD_LAUNCH_CHECK("stitch6_u8_ptrs");
+  }
   return 0;
 }
 

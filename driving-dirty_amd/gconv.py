@@ -303,7 +303,15 @@ def channel_sum(view, out, accumulate=False):
 
 def view_to_nhwc4(views, view, transform):
     """views [B,6,3,H,W] -- or the collate's tuple / list of B per-sample [6,3,H,W] tensors, read through a pointer table
-    (no torch.stack) -- -> one view as NHWC4 with SpatialMappingCNN's rot90/flip applied (see dd_view_to_nhwc4)."""
+    (no torch.stack) -- -> one view as NHWC4 with SpatialMappingCNN's rot90/flip applied (see dd_view_to_nhwc4).  uint8 frames
+    ([B,6,H,W,3] or a tuple of [6,H,W,3]) are read as they are, ToTensor's /255 fused (dd_view_to_nhwc4_u8_ptrs)."""
+    from . import ops
+    if ops.is_u8_frames(views):
+        table, b, h, w, dev, _keep = ops.u8_table(views, "view_to_nhwc4")
+        oh, ow = (w, h) if transform in (1, 2) else (h, w)
+        out = torch.empty((b, oh, ow, 4), device=dev, dtype=torch.float32)
+        check(_lib.lib().dd_view_to_nhwc4_u8_ptrs(table, _p(out), b, h, w, view, transform, _stream()), "dd_view_to_nhwc4_u8_ptrs")
+        return out
     if isinstance(views, (tuple, list)):
         b = len(views)
         _, _, h, w = views[0].shape

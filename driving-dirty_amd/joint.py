@@ -30,12 +30,8 @@ class JointRoadMapBBox(LightningModule):
     def forward(self, x, rm):
         """x [B,6,3,256,306], rm [B,1,800,800] -> (roadmap logits [B,800,800], box probabilities [B,800,800]).  Both may also be
         the collate's tuples (per-sample views, bool road masks), read through pointer tables."""
-        if isinstance(x, (tuple, list)):
-            x = tuple(t.contiguous() for t in x)
-            wide4 = ops.stitch6_samples(list(x))
-        else:
-            x = x.contiguous()
-            wide4 = ops.stitch6(x)[0]
+        x = tuple(t.contiguous() for t in x) if isinstance(x, (tuple, list)) else x.contiguous()
+        wide4 = ops.wide_image(x)                                     # fp32 views or uint8 frames, tensor or the collate's tuple
         feat, z = self.ae.encoder.forward_both(wide4)
         logits = ops.linear(z, self.fc1.weight, self.fc1.bias).reshape(-1, 800, 800)
         boxes = self.box_merge(feat, self.space_map_cnn(x), rm).squeeze(1)

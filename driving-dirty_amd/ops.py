@@ -119,6 +119,66 @@ def stitch6_u8(frames):
     return out
 
 
+def is_u8_frames(sample):
+    """uint8 camera frames as a decoder emits them: a [B,6,H,W,3] tensor or the collate's tuple / list of B [6,H,W,3] tensors."""
+    if isinstance(sample, torch.Tensor):
+        return sample.dtype == torch.uint8 and sample.dim() == 5
+    return isinstance(sample, (tuple, list)) and len(sample) > 0 and all(
+        isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and t.dim() == 4 for t in sample)
+
+
+def u8_table(sample, who):
+    """-> (ctypes pointer table, B, H, W, device, keepalive) for uint8 frames, validated on the host (a faulting kernel can reset
+    the GPU).  A [B,6,H,W,3] tensor is a table of its B slices: one code path for both forms."""
+    import ctypes
+    items = [sample[i] for i in range(sample.shape[0])] if isinstance(sample, torch.Tensor) else list(sample)
+    if not items:
+        raise _lib.HotpathError(f"{who}: empty batch")
+    n, h, w, c = items[0].shape
+    if n != 6 or c != 3:
+        raise _lib.HotpathError(f"{who}: expected uint8 frames of [6,H,W,3] per sample, got {tuple(items[0].shape)}")
+    keep = []
+    for t in items:
+        if not (t.is_cuda and t.dtype == torch.uint8 and tuple(t.shape) == (6, h, w, 3)):
+            raise _lib.HotpathError(f"{who}: expected uint8 [6,{h},{w},3] frames on the GPU, got {tuple(t.shape)} {t.dtype} on {t.device}")
+        keep.append(t if t.is_contiguous() else t.contiguous())
+    table = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+    return table, len(keep), h, w, keep[0].device, keep
+
+
+def stitch6_u8_samples(sample, mask_slot=-1, want_target=False):
+    """uint8 frames ([B,6,H,W,3] or a tuple of [6,H,W,3]) -> wide NHWC4 fp32 in [0,1] (ToTensor's /255, data_helper.py:63-68, fused
+    with the 6-view gather), optionally with BasicAE's masked-view task (-> (wide4, target [B,3,H,W]))."""
+    table, b, h, w, dev, _keep = u8_table(sample, "stitch6_u8_samples")
+    wide4 = torch.empty((b, h, 6 * w, 4), device=dev, dtype=torch.float32)
+    tgt = torch.empty((b, 3, h, w), device=dev, dtype=torch.float32) if want_target else None
+    check(_lib.lib().dd_stitch6_u8_ptrs(table, _p(wide4), _p(tgt), b, h, w, int(mask_slot), _stream()), "dd_stitch6_u8_ptrs")
+    return (wide4, tgt) if want_target else wide4
+
+
+def wide_image(sample, precision="fp32", mask_slot=-1, want_target=False):
+    """Whatever the data pipeline hands over -> the wide NHWC4 image the conv stack reads (view order [0,1,2,5,4,3],
+    roadmap_bce_v2.py:53-64), fp32 or bf16, in ONE pass:
+      * fp32 [B,6,3,H,W] (autoencoder.py:53-57) or the collate's tuple of B fp32 [6,3,H,W] tensors (helper.py:22-23);
+      * uint8 [B,6,H,W,3] or a tuple of B uint8 [6,H,W,3] decoded frames: ToTensor's /255 (data_helper.py:63-68) fused in.
+    ``mask_slot`` / ``want_target``: the masked-view task of BasicAE.six_to_one_task (fp32 image only) -> (wide4, target)."""
+    per_sample = isinstance(sample, (tuple, list))
+    if precision == "bf16":
+        from . import ops_bf16
+        if mask_slot >= 0 or want_target:
+            raise _lib.HotpathError("wide_image: the masked-view task is built for the fp32 image")
+        if is_u8_frames(sample):
+            return ops_bf16.stitch6_bf16_u8(sample)
+        return ops_bf16.stitch6_bf16_samples([t.contiguous() for t in sample]) if per_sample else ops_bf16.stitch6_bf16(sample.contiguous())
+    if is_u8_frames(sample):
+        return stitch6_u8_samples(sample, mask_slot, want_target)
+    if per_sample and mask_slot < 0 and not want_target:
+        return stitch6_samples([t.contiguous() for t in sample])      # gather straight from the samples: no stack copy
+    x = torch.stack(tuple(sample), dim=0) if per_sample else sample
+    wide4, _, tgt = stitch6(x.contiguous(), mask_slot=mask_slot, want_target=want_target)
+    return (wide4, tgt) if want_target else wide4
+
+
 def threat_score(a, b, round_b=False):
     """compute_ts_road_map (helper.py:74-77) in one pass on the device."""
     _dev(a, "a")

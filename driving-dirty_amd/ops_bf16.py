@@ -46,6 +46,15 @@ def stitch6_bf16_samples(samples):
     return out
 
 
+def stitch6_bf16_u8(sample):
+    """uint8 frames ([B,6,H,W,3] or a tuple of [6,H,W,3]) -> wide NHWC4 bf16: /255 (true division) and the bf16 rounding fused with
+    the gather -- the values ``stitch6_bf16(frames.permute(..).float() / 255)`` gives."""
+    table, b, h, w, dev, _keep = ops.u8_table(sample, "stitch6_bf16_u8")
+    out = torch.empty((b, h, 6 * w, 4), device=dev, dtype=torch.bfloat16)
+    check(_lib.lib().dd_stitch6_bf16_u8_ptrs(table, _p(out), b, h, w, _stream()), "dd_stitch6_bf16_u8_ptrs")
+    return out
+
+
 def to_bf16(t):
     ops._dev(t, "t")
     if t.numel() % 4:

@@ -40,19 +40,14 @@ class RoadMapBCE(LightningModule):
     def wide_stitch_six_images(self, sample):
         """tuple of B [6,3,H,W] -> [B,3,H,6W] (NCHW), views re-ordered.  roadmap_bce_v2.py:53-64."""
         x = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
+        if x.dtype == torch.uint8:      # decoded frames [B,6,H,W,3]: ToTensor per view (data_helper.py:63-68), for the logger's picture
+            x = x.permute(0, 1, 4, 2, 3).float().div(255)
         return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
 
     def _encode(self, sample, keeps=(None, None)):
-        if self.ae.encoder.precision == "bf16":         # hparams.precision = "bf16" (BASELINE config 5)
-            from . import ops_bf16
-            if isinstance(sample, (tuple, list)):       # the collate's tuple: gather straight from the samples
-                wide4 = ops_bf16.stitch6_bf16_samples([t.contiguous() for t in sample])
-            else:
-                wide4 = ops_bf16.stitch6_bf16(sample.contiguous())
-        elif isinstance(sample, (tuple, list)):         # the collate's tuple: gather straight from the samples
-            wide4 = ops.stitch6_samples([t.contiguous() for t in sample])
-        else:
-            wide4 = ops.stitch6(sample.contiguous())[0]  # gather + NHWC in one pass, no NCHW intermediate
+        """The 6-view gather (+ NHWC, + ToTensor's /255 for uint8 frames, + the bf16 rounding) in one pass over whatever the data
+        pipeline handed over -- ops.wide_image -- then the encoder."""
+        wide4 = ops.wide_image(sample, self.ae.encoder.precision)
         return self.ae.encoder.forward_nhwc4(wide4, keeps)
 
     def _logits(self, x, keeps=(None, None)):

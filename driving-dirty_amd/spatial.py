@@ -40,6 +40,7 @@ class SpatialMappingCNN(nn.Module):
         for n in _ORDER:
             m = getattr(self, n)
             params += [m.weight, m.bias]
+        # uint8 frames ([b,6,256,306,3] or a tuple of [6,256,306,3]) are read as they are: ToTensor's /255 happens in the re-layout
         views = tuple(t.contiguous() for t in x) if per_sample else x.contiguous()
         return SpatialMapFn.apply(views, *params).permute(0, 3, 1, 2)
 
@@ -104,7 +105,9 @@ def per_sample_inputs(sample, road_image):
     if not (isinstance(sample, (tuple, list)) and isinstance(road_image, (tuple, list)) and 0 < len(sample) == len(road_image)):
         return False
     shape = tuple(sample[0].shape)
-    return (all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == shape and t.dim() == 4 for t in sample)
+    dtype = sample[0].dtype                                   # fp32 [6,3,H,W] views or uint8 [6,H,W,3] decoded frames
+    return (dtype in (torch.float32, torch.uint8) and
+            all(t.is_cuda and t.is_contiguous() and t.dtype == dtype and tuple(t.shape) == shape and t.dim() == 4 for t in sample)
             and all(t.is_cuda and t.is_contiguous() and t.dtype in (torch.bool, torch.uint8) and t.dim() == 2 for t in road_image))
 
 
@@ -146,15 +149,8 @@ class BBSpatialRoadMap(LightningModule):
     def forward(self, x, rm):
         """x [b,6,3,256,306], rm [b,1,800,800] -> [b,800,800].  spatial_w_rm.py:67-83.  Both may also be the collate's tuples
         (b x [6,3,256,306] views, b x bool [800,800] masks): the kernels then gather from the per-sample tensors."""
-        per_sample = isinstance(x, (tuple, list))
         space_rep = self.space_map_cnn(x)
-        if self.ae.encoder.precision == "bf16":
-            from . import ops_bf16
-            wide4 = ops_bf16.stitch6_bf16_samples([t.contiguous() for t in x]) if per_sample else ops_bf16.stitch6_bf16(x.contiguous())
-        elif per_sample:
-            wide4 = ops.stitch6_samples([t.contiguous() for t in x])
-        else:
-            wide4 = ops.stitch6(x.contiguous())[0]
+        wide4 = ops.wide_image(x, self.ae.encoder.precision)      # fp32 views or uint8 frames, tensor or the collate's tuple
         ssr = self.ae.encoder.forward_nhwc4(wide4)
         yhat = self.box_merge(ssr, space_rep, rm)
         return yhat.squeeze(1)
@@ -173,7 +169,8 @@ class BBSpatialRoadMap(LightningModule):
             pred_bb_img = self(tuple(sample), tuple(road_image))
         else:
             sample = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-            target_bb_img = self.bb_coord_to_map(target, sample.device).to(sample.device).type_as(sample)
+            target_bb_img = self.bb_coord_to_map(target, sample.device).to(sample.device)
+            target_bb_img = target_bb_img.float() if sample.dtype == torch.uint8 else target_bb_img.type_as(sample)
             rm = torch.stack(tuple(road_image), dim=0).float().unsqueeze(1)
             pred_bb_img = self(sample, rm)
         batch_size = target_bb_img.size(0)

@@ -102,6 +102,12 @@ int dd_boxes_to_binary_map(const void* boxes, int32_t boxes_dtype, const int32_t
  * NHWC4 fp32 image, with torchvision ToTensor's /255 (reference autoencoder.py:133, data_helper.py:63-68) fused. */
 int dd_stitch6_u8(const unsigned char* frames, float* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
                   void* stream);
+/* The same from a HOST array of `batch` per-sample DEVICE base pointers (each [6,H,W,3] uint8 contiguous: the collate's tuple of
+ * decoded frames, helper.py:22-23 over data_helper.py:63-68 without ToTensor), with BasicAE.six_to_one_task's masked-view task
+ * (autoencoder.py:59-73) optional as in dd_stitch6: `mask_slot` in [0,5] blanks that slot of the wide image and writes the view, as
+ * fp32 NCHW [B,3,H,W], to `target` (may be NULL); -1 = no mask.  The division by 255 is a true fp32 division (ToTensor's). */
+int dd_stitch6_u8_ptrs(const unsigned char* const* sample_ptrs, float* wide_nhwc4, float* target, int32_t batch, int32_t height,
+                       int32_t width, int32_t mask_slot, void* stream);
 
 /* NCHW [B,C,H,W] <-> NHWC [B,H,W,Cs] (Cs >= C; extra channels written as zero / ignored). */
 int dd_nchw_to_nhwc(const float* src, float* dst, int32_t batch, int32_t c, int32_t h, int32_t w,
@@ -371,6 +377,8 @@ int dd_view_to_nhwc4(const float* views, float* out, int32_t batch, int32_t heig
 /* The same from a HOST array of `batch` per-sample DEVICE base pointers (each [6,3,H,W] contiguous), as dd_stitch6_ptrs:
  * BBSpatialRoadMap._run_step receives the collate's tuple (helper.py:22-23) and torch.stack()s it (spatial_w_rm.py:100-103);
  * this skips that 180 MB copy. */
+int dd_view_to_nhwc4_u8_ptrs(const unsigned char* const* sample_ptrs, float* out, int32_t batch, int32_t height, int32_t width,
+                             int32_t view, int32_t transform, void* stream);      /* per-sample [6,H,W,3] uint8 frames, /255 fused */
 int dd_view_to_nhwc4_ptrs(const float* const* sample_ptrs, float* out, int32_t batch, int32_t height, int32_t width,
                           int32_t view, int32_t transform, void* stream);
 /* rm_conv_1 (spatial_bb/components.py:80, Conv2d(1, 32, 7, stride=3, dilation=3, padding=1)) reads only the road-map pixels
@@ -498,6 +506,8 @@ int dd_conv_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* d
 int dd_stitch6_bf16(const float* views, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width, void* stream);
 /* The same from a HOST array of `batch` per-sample DEVICE base pointers (each [6,3,H,W] fp32 contiguous), as dd_stitch6_ptrs:
  * no torch.stack of the collate's tuple (roadmap_bce_v2.py:55) in front of the bf16 path either. */
+int dd_stitch6_bf16_u8_ptrs(const unsigned char* const* sample_ptrs, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
+                            void* stream);      /* per-sample [6,H,W,3] uint8 frames: /255 (true division), then the bf16 rounding */
 int dd_stitch6_bf16_ptrs(const float* const* sample_ptrs, uint16_t* wide_nhwc4, int32_t batch, int32_t height, int32_t width,
                          void* stream);
 int64_t dd_conv_bf16_packed_elems(const dd_conv_desc* d);                 /* uint16 elements of an operand image */
