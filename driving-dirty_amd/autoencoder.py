@@ -42,8 +42,9 @@ class BasicAE(LightningModule):
         view and the blanking happen in one HIP kernel.
         """
         target_img_index = int(np.random.randint(0, 5))
-        if x.dtype == torch.uint8:      # decoded frames [B,6,H,W,3]: ToTensor per view first (data_helper.py:63-68)
-            x = x.permute(0, 1, 4, 2, 3).float().div(255)
+        if ops.is_u8_frames(x):         # decoded frames [B,6,H,W,3]: ToTensor's /255 (a true division) inside the gather kernel
+            wide4, y = ops.wide_image(x, "fp32", mask_slot=target_img_index, want_target=True)
+            return ops.nhwc_to_nchw(wide4, 3), y
         _, wide, y = ops.stitch6(x.contiguous(), mask_slot=target_img_index, want_nhwc4=False, want_nchw=True,
                                  want_target=True)
         assert wide.size(-1) == 6 * x.size(-1)

@@ -39,9 +39,9 @@ class RoadMapBCE(LightningModule):
 
     def wide_stitch_six_images(self, sample):
         """tuple of B [6,3,H,W] -> [B,3,H,6W] (NCHW), views re-ordered.  roadmap_bce_v2.py:53-64."""
+        if ops.is_u8_frames(sample):    # decoded frames: ToTensor's /255 (a true division) inside the gather kernel
+            return ops.nhwc_to_nchw(ops.wide_image(sample), 3)
         x = torch.stack(tuple(sample), dim=0) if isinstance(sample, (tuple, list)) else sample
-        if x.dtype == torch.uint8:      # decoded frames [B,6,H,W,3]: ToTensor per view (data_helper.py:63-68), for the logger's picture
-            x = x.permute(0, 1, 4, 2, 3).float().div(255)
         return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
 
     def _encode(self, sample, keeps=(None, None)):

@@ -203,8 +203,9 @@ def _frames(b, h, w, seed):
 
 def _as_views(frames):
     """What the reference's dataset makes of decoded frames: ToTensor per camera (HWC uint8 -> CHW float / 255), stacked
-    (data_helper.py:63-68)."""
-    return frames.permute(0, 1, 4, 2, 3).float().div(255).contiguous()
+    (data_helper.py:63-68) -- ON THE CPU, as in a DataLoader worker: there torch divides; on a GPU tensor `x / 255` is computed as
+    x * (1 / 255), one ulp off for some of the 256 values."""
+    return frames.cpu().permute(0, 1, 4, 2, 3).float().div(255).contiguous().to(frames.device)
 
 
 def _grads(model):

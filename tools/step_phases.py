@@ -53,8 +53,10 @@ def main():
     import driving_dirty_amd.roadmap as rm
     comp.ops.linear = linear
     rm.ops.linear = linear
+    ts(batch, 0)                                              # the first training_step unfreezes the extractor where the config says so
     for n, p in big.items():
-        p.register_post_accumulate_grad_hook(lambda q, n=n: mark("grad_ready:" + n))
+        if p.requires_grad:
+            p.register_post_accumulate_grad_hook(lambda q, n=n: mark("grad_ready:" + n))
     rows = []
     for i in range(a.warmup + a.steps):
         marks.clear()
