@@ -140,6 +140,13 @@ class Encoder(nn.Module):
         pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, True, self.rows_per_task)
         return self._tail(pooled, keeps)
 
+    def conv_feature_and_pooled(self, x4):
+        """The conv stack once, both exits: (conv feature [B,32,H/2,W/2] as an NCHW-shaped view, pooled vector for ``_tail``).  A
+        caller that runs other work on the feature BEFORE ``_tail(pooled)`` gets the tail differentiated first in the backward
+        (autograd runs the newest nodes first): see joint.JointRoadMapBBox.forward."""
+        feat, pooled = ops.encoder_conv_stack(x4, self.c1, self.c2, self.c3, 2, self.rows_per_task)
+        return feat.permute(0, 3, 1, 2), pooled
+
     def forward_both(self, x4, keeps=(None, None)):
         """One pass of the conv stack feeding BOTH exits the reference's ``c3_only`` switch chooses between
         (components.py:44-45): returns (conv feature [B,32,H/2,W/2], latent z).  Used by the joint roadmap + box model."""

@@ -201,6 +201,11 @@ class GradSync:
             self._reduce_big(p)
         elif self.active:
             self._small.append(p)
+            # every reduction started so far has finished and no all-gather is on the links: the conv grids get their compute
+            # units back for the rest of the backward (config 4: the big gradients are done tens of milliseconds before it ends)
+            if self._reserved and not self._gathers and all(h.is_completed() for h in self._handles):
+                self._set_budget(256)
+                self._reserved = False
 
     def pieces(self, p):
         """[(work, offset, numel), ...] of the in-flight all-reduce of ``p`` in issue order (None: p went the small-tensor way,
@@ -218,6 +223,9 @@ class GradSync:
         if self.simulate_world or not self.active:
             return
         flat = p.data.view(-1)
+        if self.reserve_cus and not self._reserved:      # the gathers run under the NEXT forward: RCCL keeps its compute units until the last one is waited for
+            self._set_budget(256 - self.reserve_cus)
+            self._reserved = True
         work = self._all_gather(flat[shard.piece_lo:shard.piece_hi], shard.param)
         self._gathers.setdefault(p, []).append(work)
         PARAM_WAITS[p.data_ptr()] = lambda q=p: self.wait_param_gather(q)
@@ -226,6 +234,9 @@ class GradSync:
         PARAM_WAITS.pop(p.data_ptr(), None)
         for work in self._gathers.pop(p, ()):
             work.wait()
+        if self._reserved and not self._gathers and not self._handles:
+            self._set_budget(256)                        # the last all-gather has been waited for: the whole GPU for the kernels behind it
+            self._reserved = False
 
     def wait_gathers(self):
         """Make the current stream wait for every all-gather in flight: before validation, ``state_dict()``, a checkpoint, or
@@ -273,7 +284,7 @@ class GradSync:
         for h in self._handles:
             h.wait()
         self._handles, self._small, self._by_param = [], [], {}
-        if self._reserved:
+        if self._reserved and not self._gathers:         # shard mode: the all-gathers keep RCCL's compute units (wait_param_gather returns them)
             self._set_budget(256)
             self._reserved = False
 

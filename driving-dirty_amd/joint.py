@@ -32,9 +32,14 @@ class JointRoadMapBBox(LightningModule):
         the collate's tuples (per-sample views, bool road masks), read through pointer tables."""
         x = tuple(t.contiguous() for t in x) if isinstance(x, (tuple, list)) else x.contiguous()
         wide4 = ops.wide_image(x)                                     # fp32 views or uint8 frames, tensor or the collate's tuple
-        feat, z = self.ae.encoder.forward_both(wide4)
-        logits = ops.linear(z, self.fc1.weight, self.fc1.bias).reshape(-1, 800, 800)
+        feat, pooled = self.ae.encoder.conv_feature_and_pooled(wide4)
+        # the box branch FIRST, the encoder's dense tail and the road-map head after it: autograd runs the newest nodes first, so
+        # the two tensors that are 99.6 % of the data-parallel message (encoder fc1.fc1.weight 481 MB, head fc1.weight 164 MB) get
+        # their gradients at the START of the backward and their reduction has the whole box-head backward (~40 ms) to hide under
+        # instead of its last 5 (tools/step_phases.py); same arithmetic, same results
         boxes = self.box_merge(feat, self.space_map_cnn(x), rm).squeeze(1)
+        z = self.ae.encoder._tail(pooled, (None, None))
+        logits = ops.linear(z, self.fc1.weight, self.fc1.bias).reshape(-1, 800, 800)
         return logits, boxes
 
     def training_step(self, batch, batch_idx):
