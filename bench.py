@@ -69,8 +69,8 @@ def parse_args():
     ap.add_argument("--rows-per-task", type=int, default=0, help="conv kernel tuning knob (results unchanged)")
     ap.add_argument("--shard-optimizer", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: reduce-scatter + Adam on the owned 1/N + all-gather under the next forward (on) instead of all-reduce + "
-                    "replicated Adam (off).  auto = on for the configs whose gradient message cannot hide under the backward as an "
-                    "all-reduce (4 and 5; DESIGN.md section 6), off for 2 and 3")
+                    "replicated Adam (off).  auto = on for the configs with a big gradient message (2, 4, 5: 0.65 / 0.65 / 2.09 GB -- the budget "
+                    "of DESIGN.md section 6 favours it at every N and link speed), off for 3 (2 MB of head gradients)")
     ap.add_argument("--simulate-shard", type=int, default=0, metavar="N",
                     help="one GPU, timing only: the COMPUTE side of an N-GPU sharded step (Adam on rank 0's 1/N of every big tensor, no "
                     "collectives; the parameters it leaves are meaningless) -- the per-GPU lower bound of the N-GPU step")
@@ -847,8 +847,8 @@ def run_rank(a):
     cfg = setup_config(a, dev, rank)
     model, batch, per_gpu = cfg["model"], cfg["batch"], cfg["per_gpu_batch"]
     overlap = {"on": True, "off": False, "auto": True}[a.adam_overlap] and not a.no_adam_overlap
-    # sharded optimizer: where the gradient message cannot hide under the backward as ONE all-reduce
-    shard = (comm or a.simulate_shard > 1) and {"on": True, "off": False, "auto": a.config in (4, 5) or a.simulate_shard > 1}[a.shard_optimizer]
+    # sharded optimizer wherever the gradient message is big (tools/ddp_budget.py)
+    shard = (comm or a.simulate_shard > 1) and {"on": True, "off": False, "auto": a.config in (2, 4, 5) or a.simulate_shard > 1}[a.shard_optimizer]
     # The optimizer and the gradient synchronisation are built over the model AS CONSTRUCTED -- feature extractor still frozen
     # (roadmap_bce_v2.py:45-47, spatial_w_rm.py:45-48): the first training_step unfreezes it where the config says so, and
     # LightningModule.unfreeze() re-arms both (driving_dirty_amd.train.TrainStep = HipAdam + GradSync, the step of this benchmark).

@@ -180,10 +180,10 @@ def test_bench_sharded_step_over_a_one_rank_rccl_communicator(dev):
 @pytest.mark.parametrize("config", [3, 4, 5])
 def test_bench_two_ranks_over_gloo_on_one_card(dev, config):
     """`bench.py --gpus 2 --config C` starting its own ranks, both on this card, gradients over gloo (DD_DIST_BACKEND=gloo): the N > 1
-    control flow of every BASELINE configuration that exists only on several GPUs -- config 4 and 5 on the sharded optimizer (auto)."""
+    control flow of every BASELINE configuration that exists only on several GPUs -- configs 4 and 5 on the sharded optimizer (auto)."""
     line, err = _bench({"DD_DIST_BACKEND": "gloo", "DD_RESERVED_CUS": "0"}, "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1")
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["baseline_config"] == config
-    assert line["config"]["optimizer"].startswith("sharded" if config in (4, 5) else "replicated")
+    assert line["config"]["optimizer"].startswith("sharded" if config in (2, 4, 5) else "replicated")
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0
     assert "[rank 0] bench.py preflight:" in err
