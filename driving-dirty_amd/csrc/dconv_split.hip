@@ -1,0 +1,375 @@
+// EXPERIMENT (round 4; off by default): the forward of the dilated stride-1 ConvTranspose2d layers of the box heads
+// (spatial_bb/components.py:135-136) with fp32-equivalent products on the BF16 matrix pipe.
+//
+// The exact-fp32 kernels of dconv_t.hip keep the fp32 matrix pipe 87-90 % busy: on that pipe (157 TF) they are done.  The bf16
+// pipe runs 16x faster per multiply, and an fp32 number splits EXACTLY into three bf16 pieces (8 + 8 + 8 = 24 significant bits, by
+// truncation: x = hi + mid + lo with no rounding anywhere), so
+//     a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + [am*bl + al*bm + al*bl]
+// and the three terms in brackets are below 2^-23 of |a*b| -- the size of fp32's own rounding of the product.  The six others are
+// issued on v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact in fp32, accumulation is fp32), smallest first:
+// 6 x 32 cycles per 32 x 32 x 16 block against 8 x 64 for v_mfma_f32_32x32x2_f32 = 6/16 of the matrix time.
+//
+// Operands are split ONCE, outside the kernel, into the images the kernel's LDS wants, so that every stage fill is a plain
+// lane-linear copy done by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass):
+//   * dd_dconv_split_input: x (NHWC fp32, a channel slice) -> xs[b][y][q][px][112 B]: per pixel and 16-channel chunk q the three
+//     planes hi / mid / lo (16 bf16 = 32 B each) and 16 B of padding -- 112 B = 7 sixteen-byte slots, an odd number, so the sixteen
+//     lanes of a ds_read_b128 group (pixels p, p+1, ..: 7p mod 16 is a bijection) cover all 64 banks: conflict-free as stored;
+//   * dd_dconv_split_pack: W -> wp[q][ky][nt][kx][plane][lane][8 bf16]: the B fragments of one (chunk, tap row, column tile) are
+//     one contiguous 21 KB block in lane order.
+// The kernel is dconv_tfwd_kernel's input-aligned form (one accumulator tile per (m-tile, tap column), partial rows added at their
+// shifts in LDS: no border zero is multiplied) with the stage cut at (16-channel chunk, tap row): per stage a wave issues 3 + 21
+// ds_read_b128 and 42 MFMAs; the next stage's 49-56 KB arrive by DMA meanwhile (two LDS buffers, one s_barrier per stage).
+//
+// Same operands, same products up to 2^-23 each, same fp32 accumulation as the exact kernels in a different order: held to the
+// exact kernels' own tests (2e-5 of peak against fp64).  The headline numbers and `dtype: f32` never use this path.
+#include <stdlib.h>
+
+#include "dd_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+#define SP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int SP_THREADS = 512;
+constexpr int SP_PXB = 112;                 // bytes of one pixel of one 16-channel chunk in xs and in LDS
+
+__device__ __forceinline__ void sp_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- x = hi + mid + lo, exactly: three truncations (the upper 16 bits of an fp32 ARE a bf16)
+__device__ __forceinline__ void sp_split(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+  const float r = x - __builtin_bit_cast(float, hi);
+  mid = __builtin_bit_cast(unsigned, r) & 0xFFFF0000u;
+  const float s = r - __builtin_bit_cast(float, mid);
+  lo = __builtin_bit_cast(unsigned, s) & 0xFFFF0000u;
+}
+
+// one thread per (image row, chunk, pixel, 8-channel half): 32 B in, 3 x 16 B out (+ the 16 B pad from half 0)
+__global__ __launch_bounds__(256) void split_input_kernel(const float* __restrict__ x, char* __restrict__ xs, long rows, int W, int cstore,
+                                                          int coff, int NC) {
+  const long total = rows * NC * W * 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int half = (int)(idx & 1);
+    const long t = idx >> 1;
+    const int px = (int)(t % W);
+    const long u = t / W;
+    const int q = (int)(u % NC);
+    const long r = u / NC;
+    const float* src = x + (r * W + px) * cstore + coff + 16 * q + 8 * half;
+    const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sp_split(v[j], h[j], m[j], l[j]);
+    char* dst = xs + ((r * NC + q) * W + px) * SP_PXB + half * 16;
+    u32x4s oh, om, ol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      oh[j] = (h[2 * j] >> 16) | h[2 * j + 1];
+      om[j] = (m[2 * j] >> 16) | m[2 * j + 1];
+      ol[j] = (l[2 * j] >> 16) | l[2 * j + 1];
+    }
+    *(u32x4s*)dst = oh;
+    *(u32x4s*)(dst + 32) = om;
+    *(u32x4s*)(dst + 64) = ol;
+    if (half == 0) *(u32x4s*)(dst + 96) = u32x4s{0u, 0u, 0u, 0u};
+  }
+}
+
+// wp[(((((q*K + ky)*NT + nt)*K + kx)*3 + plane)*64 + lane)*8 + j] = plane of W(n = 32 nt + (lane & 31), c = 16 q + 8 (lane >> 5) + j, tap)
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int nchunks, int NT, int K,
+                                                         long w_off, long sn, long sc, int flip, int n_real, int c_real) {
+  const long total = (long)nchunks * K * NT * K * 512;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+  long g = idx >> 9;
+  const int kx = (int)(g % K);
+  g /= K;
+  const int nt = (int)(g % NT);
+  g /= NT;
+  const int ky = (int)(g % K), q = (int)(g / K);
+  const int tap = ky * K + kx, T = K * K;
+  const int c = 16 * q + 8 * (lane >> 5) + j, n = nt * 32 + (lane & 31);
+  float v = 0.f;
+  if (n < n_real && c < c_real) v = w[w_off + n * sn + c * sc + (flip ? T - 1 - tap : tap)];
+  unsigned hi, mid, lo;
+  sp_split(v, hi, mid, lo);
+  const long base = ((((long)(q * K + ky) * NT + nt) * K + kx) * 3) * 512 + lane * 8 + j;
+  p[base] = (unsigned short)(hi >> 16);
+  p[base + 512] = (unsigned short)(mid >> 16);
+  p[base + 1024] = (unsigned short)(lo >> 16);
+}
+
+struct SpTask {
+  int b, nt, oy, ry, ky0, ky1;
+};
+
+template <int K, int D, int NSLOT, int MODE, int IWP>
+__global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __restrict__ xs, const char* __restrict__ wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 const dd_gconv_desc d, int epi) {
+  constexpr bool ONE_MT = MODE == 0;
+  constexpr int TW = 32, NE = 16, P = 40, HALO = D * (K - 1);
+  constexpr int AROW = IWP * SP_PXB;                       // bytes of the A image of a stage (one input row, one chunk)
+  constexpr int BST = K * 3 * 1024;                        // bytes of its B image (K tap columns x 3 planes x 64 lanes x 16 B)
+  constexpr int STAGE = AROW + BST;
+  constexpr int NA = AROW / 1024, NB = K * 3, NI = NA + NB;      // 1 KB wave-instructions of a stage fill
+  static_assert(AROW % 1024 == 0, "the A image is filled in whole 1 KB wave-instructions");
+  constexpr int IMG = (IWP + HALO) * P * 4;
+  constexpr int LDSB = 2 * STAGE > IMG ? 2 * STAGE : IMG;
+  __shared__ __attribute__((aligned(1024))) char lds[LDSB];
+  using acc_t = f32x16;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NC = d.cin >> 4, NTC = (d.cout + 31) >> 5;
+  const int rows_max = (d.out_h + D - 1) / D;
+  const int n_mt = (d.in_w + TW - 1) / TW;
+  const int row_bytes = d.in_w * SP_PXB;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+
+  // this wave's tiles: linear index L = m-tile * K + kx (MODE 0: m-tile = wave, kx = slot)
+  int s_kx[NSLOT], s_mt[NSLOT];
+  bool s_ok[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int L = ONE_MT ? wave * K + i : wave * NSLOT + i;
+    s_ok[i] = L < n_mt * K;
+    const int mt = s_ok[i] ? L / K : 0;
+    s_kx[i] = s_ok[i] ? L - mt * K : 0;
+    s_mt[i] = mt;
+  }
+  const int a_lane = (lane & 31) * SP_PXB + (lane >> 5) * 16;      // this lane's A fragment inside an m-tile's 32 pixels
+  const int ioff_lane = 4 * (lane >> 5) * P + (lane & 31);         // its accumulator element 0 in the output row image
+
+  // ---- tasks: as dconv_tfwd_kernel (XCD = blockIdx % 8 owns the x-th eighth of the (image, residue, phase row, column tile) list)
+  const int per_x = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int per_img = D * rows_max * NTC;
+  const long len = (long)d.batch * per_img;
+  const long seg1 = len * (xcd + 1) / 8;
+  auto decode = [&](long t, SpTask& k) -> bool {
+    k.b = (int)(t / per_img);
+    int rem = (int)(t - (long)k.b * per_img);
+    k.nt = rem % NTC;
+    rem /= NTC;
+    const int r = rem / rows_max, jy = rem - r * rows_max;
+    k.oy = r + D * jy;
+    k.ry = k.oy - d.pad_h;
+    k.ky0 = k.ry >= 0 ? 0 : (-k.ry + D - 1) / D;
+    k.ky1 = min(K - 1, (d.in_h - 1 - k.ry) >= 0 ? (d.in_h - 1 - k.ry) / D : -1);
+    return k.oy < d.out_h;
+  };
+  auto next_task = [&](long t, SpTask& k) -> long {
+    while (t < seg1 && !decode(t, k)) t += per_x;
+    return t < seg1 ? t : seg1;
+  };
+
+  // ---- stage fill by LDS-DMA: wave-instruction j of the stage copies 1 KB; lanes past the end of the row read zeros (the buffer
+  // descriptor ends with the row), which is what the pixels of a ragged last m-tile must hold
+  auto fill = [&](int buf, const SpTask& k, int q, int ky) {
+    const long arow = ((long)(k.b * d.in_h + k.ry + D * ky) * NC + q) * row_bytes;
+    const __amdgpu_buffer_rsrc_t ra = dd_rsrc(xs + arow, row_bytes);
+    const __amdgpu_buffer_rsrc_t rb = dd_rsrc(wp + ((long)(q * K + ky) * NTC + k.nt) * BST, BST);
+    char* base = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < (NI + 7) / 8; ++i) {
+      const int j = wave + 8 * i;
+      if (j < NA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, lane * 16, j * 1024, 0, 0);
+      else if (j < NI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(base + AROW + (j - NA) * 1024), 16, lane * 16,
+                                                 (j - NA) * 1024, 0, 0);
+    }
+  };
+
+  SpTask cur;
+  long t = next_task(len * xcd / 8 + (blockIdx.x >> 3), cur);
+  while (t < seg1) {
+    const int ky0 = cur.ky0, ky1 = cur.ky1;
+    acc_t acc[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[i][e] = 0.f;
+
+    if (ky1 >= ky0) {
+      int par = 0;
+      fill(0, cur, 0, ky0);
+      sp_barrier();
+      const int nky = ky1 - ky0 + 1, nstage = NC * nky;
+      int q = 0, ky = ky0;
+      for (int s = 0; s < nstage; ++s) {
+        int qn = q, kyn = ky + 1;
+        if (kyn > ky1) { kyn = ky0; qn = q + 1; }
+        if (s + 1 < nstage) fill(par ^ 1, cur, qn, kyn);
+        const char* sb = lds + par * STAGE;
+        const char* bp = sb + AROW + lane * 16;
+        if constexpr (ONE_MT) {
+          const char* ap = sb + wave * (32 * SP_PXB) + a_lane;
+          const bf16x8 Ah = *(const bf16x8*)ap, Am = *(const bf16x8*)(ap + 32), Al = *(const bf16x8*)(ap + 64);
+#pragma unroll
+          for (int i = 0; i < NSLOT; ++i) {
+            const bf16x8 Bh = *(const bf16x8*)(bp + i * 3072), Bm = *(const bf16x8*)(bp + i * 3072 + 1024), Bl = *(const bf16x8*)(bp + i * 3072 + 2048);
+            acc[i] = SP_MFMA(Al, Bh, acc[i]);
+            acc[i] = SP_MFMA(Ah, Bl, acc[i]);
+            acc[i] = SP_MFMA(Am, Bm, acc[i]);
+            acc[i] = SP_MFMA(Am, Bh, acc[i]);
+            acc[i] = SP_MFMA(Ah, Bm, acc[i]);
+            acc[i] = SP_MFMA(Ah, Bh, acc[i]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NSLOT; ++i) {
+            if (s_ok[i]) {
+              const char* ap = sb + s_mt[i] * (32 * SP_PXB) + a_lane;
+              const char* bq = bp + s_kx[i] * 3072;
+              const bf16x8 Ah = *(const bf16x8*)ap, Am = *(const bf16x8*)(ap + 32), Al = *(const bf16x8*)(ap + 64);
+              const bf16x8 Bh = *(const bf16x8*)bq, Bm = *(const bf16x8*)(bq + 1024), Bl = *(const bf16x8*)(bq + 2048);
+              acc[i] = SP_MFMA(Al, Bh, acc[i]);
+              acc[i] = SP_MFMA(Ah, Bl, acc[i]);
+              acc[i] = SP_MFMA(Am, Bm, acc[i]);
+              acc[i] = SP_MFMA(Am, Bh, acc[i]);
+              acc[i] = SP_MFMA(Ah, Bm, acc[i]);
+              acc[i] = SP_MFMA(Ah, Bh, acc[i]);
+            }
+          }
+        }
+        sp_barrier();                                         // this wave's DMA has landed, every wave is done with buffer `par`
+        par ^= 1;
+        q = qn;
+        ky = kyn;
+      }
+    }
+
+    // ---- epilogue (as dconv_tfwd_kernel): the K partial rows are added into one output row image at their shifts.  Tap column
+    // K-1 (shift 0) goes first and is STORED, the others are added in K-1 barrier-separated passes: a fixed order.
+    float* img = (float*)lds;
+    constexpr int LPP = 8;
+    constexpr int WIT = ((IWP + HALO) * LPP + SP_THREADS - 1) / SP_THREADS;
+    const int c4 = 4 * (tid % LPP), cch = 32 * cur.nt + c4;
+    f32x4 bvec = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && cch < d.cout) bvec = *(const f32x4*)&bias[cch];
+    {
+      if (tid < HALO * (P / 4)) *(f32x4*)&img[n_mt * TW * P + tid * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      static_assert(HALO * (P / 4) <= SP_THREADS, "one zeroing store per thread");
+#pragma unroll
+      for (int pass = K - 1; pass >= 0; --pass) {
+        const int shift = D * (K - 1 - pass);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+          if (ONE_MT ? (i == pass && s_ok[i]) : (s_ok[i] && s_kx[i] == pass)) {
+            float* p0 = img + ioff_lane + s_mt[i] * (TW * P);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+              float* pe = p0 + ((e & 3) + 8 * (e >> 2) + shift) * P;
+              if (pass == K - 1) *pe = acc[i][e]; else *pe += acc[i][e];
+            }
+          }
+        }
+        sp_barrier();
+      }
+    }
+    {
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff + cch;
+      f32x4 v[WIT];
+#pragma unroll
+      for (int j = 0; j < WIT; ++j) {
+        const int px = (tid + SP_THREADS * j) / LPP;
+        v[j] = px < d.out_w ? *(const f32x4*)&img[px * P + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < WIT; ++j) {
+        const int px = (tid + SP_THREADS * j) / LPP;
+        f32x4 o = v[j] + bvec;
+        if (epi == DD_EPI_BIAS_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        const int off = (px < d.out_w && cch < d.cout) ? (base + px * d.out_cstore) * 4 : -16;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), ys, off, 0, 0);
+      }
+    }
+    sp_barrier();
+    t = next_task(t + per_x, cur);
+  }
+}
+
+bool sp_layer_ok(const dd_gconv_desc* d) {
+  if (!dd_dconv_desc_ok(d)) return false;
+  if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7) return false;
+  if (d->pad_h != 42 || d->pad_w != 42) return false;                                          // the full transposed form only
+  if (d->out_h < d->in_h + 42 || d->out_w < d->in_w + 42) return false;
+  if (d->cin % 16 || d->cout <= 16 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
+  if (d->in_w > 320 || d->out_w > ((d->in_w + 31) / 32) * 32 + 42) return false;
+  if ((long)d->in_w * SP_PXB * (d->cin / 16) * d->in_h * d->batch >= (1L << 40)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dd_dconv_split_supported(const dd_gconv_desc* d) { return d && sp_layer_ok(d) ? 1 : 0; }
+
+int64_t dd_dconv_split_input_bytes(const dd_gconv_desc* d) {
+  if (!d || !sp_layer_ok(d)) return dd_fail(DD_ERR_UNSUPPORTED, "dconv_split_input_bytes: unsupported layer"), -1;
+  return (int64_t)d->batch * d->in_h * (d->cin / 16) * d->in_w * SP_PXB;
+}
+
+int64_t dd_dconv_split_packed_bytes(const dd_gconv_desc* d) {
+  if (!d || !sp_layer_ok(d)) return dd_fail(DD_ERR_UNSUPPORTED, "dconv_split_packed_bytes: unsupported layer"), -1;
+  return (int64_t)(d->cin / 16) * 7 * ((d->cout + 31) / 32) * 7 * 3 * 1024;
+}
+
+int dd_dconv_split_input(const float* x, void* xs, const dd_gconv_desc* d, void* stream) {
+  DD_REQUIRE(d && sp_layer_ok(d), DD_ERR_UNSUPPORTED, "dconv_split_input: unsupported layer");
+  DD_REQUIRE(x && xs, DD_ERR_BAD_ARG, "dconv_split_input: NULL pointer");
+  DD_REQUIRE(d->in_coff % 4 == 0 && d->in_cstore % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)xs & 15) == 0, DD_ERR_BAD_ARG,
+             "dconv_split_input: 16-byte alignment");
+  const long rows = (long)d->batch * d->in_h;
+  const long total = rows * (d->cin / 16) * d->in_w * 2;
+  hipLaunchKernelGGL(split_input_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 16)), dim3(256), 0, (hipStream_t)stream, x,
+                     (char*)xs, rows, d->in_w, d->in_cstore, d->in_coff, d->cin / 16);
+  DD_LAUNCH_CHECK("dconv_split_input");
+  return 0;
+}
+
+int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc, int32_t flip,
+                        int32_t n_real, int32_t c_real, void* stream) {
+  DD_REQUIRE(d && sp_layer_ok(d), DD_ERR_UNSUPPORTED, "dconv_split_pack: unsupported layer");
+  DD_REQUIRE(w && packed, DD_ERR_BAD_ARG, "dconv_split_pack: NULL pointer");
+  DD_REQUIRE(n_real > 0 && n_real <= d->cout && c_real > 0 && c_real <= d->cin, DD_ERR_BAD_ARG, "dconv_split_pack: n_real/c_real");
+  const int NT = (d->cout + 31) / 32;
+  const long total = (long)(d->cin / 16) * 7 * NT * 7 * 512;
+  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed,
+                     d->cin / 16, NT, 7, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real);
+  DD_LAUNCH_CHECK("dconv_split_pack");
+  return 0;
+}
+
+int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, float* y, const dd_gconv_desc* d, int32_t epilogue,
+                       void* stream) {
+  DD_REQUIRE(d && sp_layer_ok(d), DD_ERR_UNSUPPORTED, "dconv_fwd_split: unsupported layer");
+  DD_REQUIRE(xs && packed && y, DD_ERR_BAD_ARG, "dconv_fwd_split: NULL pointer");
+  DD_REQUIRE(epilogue == DD_EPI_NONE || epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU, DD_ERR_BAD_ARG, "dconv_fwd_split: epilogue %d",
+             epilogue);
+  DD_REQUIRE(!(epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) || (bias && ((uintptr_t)bias & 15) == 0), DD_ERR_BAD_ARG,
+             "dconv_fwd_split: bias epilogue needs a 16-byte aligned bias");
+  const int grid = dd_cu_budget_internal() & ~7;
+  DD_REQUIRE(grid >= 8, DD_ERR_UNSUPPORTED, "dconv_fwd_split: CU budget below 8");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->in_w <= 256)
+    hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 7, 0, 256>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, bias, y, *d,
+                       epilogue);
+  else
+    hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 9, 1, 320>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, bias, y, *d,
+                       epilogue);
+  DD_LAUNCH_CHECK("dconv_fwd_split");
+  return 0;
+}
+
+}  // extern "C"

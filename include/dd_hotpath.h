@@ -333,6 +333,24 @@ int dd_dconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t
 int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y,
                  const dd_gconv_desc* d, int32_t epilogue, void* stream);
 
+/* EXPERIMENT, off by default (csrc/dconv_split.hip): the forward of the k7 d7 dilated ConvTranspose2d layers with Cout > 16
+ * (up_conv_1 / up_conv_2, spatial_bb/components.py:135-136) with fp32-equivalent products on the bf16 matrix pipe: every fp32
+ * operand is split exactly into three bf16 pieces (hi + mid + lo, truncation: 24 significant bits) and the six cross products
+ * >= 2^-23 of the full product are issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same descriptor, packing
+ * parameters and epilogues (NONE / BIAS / BIAS_RELU) as dd_dconv_pack + dd_dconv_fwd; the operands are split once, outside:
+ *   dd_dconv_split_input   x (NHWC fp32, channels [in_coff, +cin)) -> xs, dd_dconv_split_input_bytes(d) bytes
+ *   dd_dconv_split_pack    weights -> packed, dd_dconv_split_packed_bytes(d) bytes
+ *   dd_dconv_fwd_split     y = epilogue(conv_transpose(x, w))
+ * dd_dconv_split_supported(d): 1 for the layers it is built for (full transposed form, cin % 16 == 0, in_w <= 320). */
+int32_t dd_dconv_split_supported(const dd_gconv_desc* d);
+int64_t dd_dconv_split_input_bytes(const dd_gconv_desc* d);
+int64_t dd_dconv_split_packed_bytes(const dd_gconv_desc* d);
+int dd_dconv_split_input(const float* x, void* xs, const dd_gconv_desc* d, void* stream);
+int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc, int32_t flip,
+                        int32_t n_real, int32_t c_real, void* stream);
+int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, float* y, const dd_gconv_desc* d, int32_t epilogue,
+                       void* stream);
+
 /* Weight gradient of the same layers (ConvTranspose2d stride 1, dilation `dil`, kernel k x k, no padding):
  *   dw[c][o][ky][kx] (IOHW, PyTorch's layout) (+)= sum over images and pixels of x[iy][ix][c] * g[iy + dil*ky][ix + dil*kx][o]
  * x [batch,h,w,x_cstore] (channels [x_coff,+cin)), g = dL/dy [batch,gh,gw,g_cstore] (channels [g_coff,+cout)) with

@@ -425,3 +425,71 @@ BF16_FULLSIZE_BUDGET = {
     "fc1.weight": 0.001,
     "fc1.bias": 0.001
 }
+
+
+# ------------------------------------------------------------------------------------------------ EXPERIMENT: bf16 x 3 split products
+_SPLIT_CASES = [
+    ("up1_96_64_small", 96, 64, (1, 9, 20)),
+    ("up1_full_width", 96, 64, (2, 9, 256)),            # 8 m-tiles: one per wave
+    ("up1_ragged_250", 96, 64, (1, 5, 250)),            # last m-tile 26 pixels: the DMA's range check supplies the zeros
+    ("up2_full_width", 64, 32, (2, 9, 298)),            # 70 tiles over 8 waves
+    ("up2_257_nine_tiles", 64, 32, (1, 3, 257)),
+    ("up2_320_ten_full", 64, 64, (1, 2, 320)),          # widest row, two column tiles
+    ("up2_tall", 64, 32, (2, 40, 100)),                 # every tap-row range of the residue classes
+]
+
+
+@pytest.mark.parametrize("name,cin,cout,shape", _SPLIT_CASES, ids=[c[0] for c in _SPLIT_CASES])
+def test_split_bf16_forward_against_fp64_and_the_exact_kernel(dev, name, cin, cout, shape):
+    """csrc/dconv_split.hip (off by default): the k7 d7 transposed forward with every fp32 product as six bf16 x bf16 products on the
+    bf16 matrix pipe.  Held to the exact kernels' own bound -- 2e-5 of peak against fp64 torch -- and compared with the exact fp32
+    kernel on the same operands (both errors are reported; the split path must not be the worse one by more than 4x)."""
+    from torch import nn
+    from torch.nn import functional as F
+    from driving_dirty_amd import gconv, synth
+    b, h, w = shape
+    mod = synth.fill_module(nn.ConvTranspose2d(cin, cout, 7, dilation=7), seed=21).double()
+    x = synth.hash_uniform((b, cin, h, w), synth.key_salt("spx" + name), -1.0, 1.0).double()
+    y_ref = F.relu(mod(x))
+    layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+    oh, ow = layer.out_hw(h, w)
+    xb = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, bd = mod.weight.detach().float().to(dev), mod.bias.detach().float().to(dev)
+    errs = {}
+    for split in (False, True):
+        yb = torch.full((b, oh, ow, cout), float("nan"), device=dev)
+        old = gconv.SPLIT_BF16
+        gconv.SPLIT_BF16 = split
+        try:
+            layer.forward(wd, bd, gconv.View(xb), gconv.View(yb), gconv.EPI_BIAS_RELU)
+        finally:
+            gconv.SPLIT_BF16 = old
+        got = yb.permute(0, 3, 1, 2).double().cpu()
+        assert torch.isfinite(got).all()
+        errs[split] = float((got - y_ref).abs().max() / y_ref.abs().max())
+    assert errs[True] < 2e-5, errs
+    assert errs[True] <= 4.0 * errs[False] + 1e-7, errs
+
+
+def test_split_bf16_pieces_are_exact(dev):
+    """dd_dconv_split_input: hi + mid + lo == x bit for bit (three truncations), for normal numbers of every magnitude the layers see."""
+    import ctypes as C
+    from driving_dirty_amd import _lib, gconv
+    b, h, w, c = 1, 3, 40, 32
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(b, h, w, c, generator=g) * torch.logspace(-6, 3, c)).to(dev)
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.0])
+    layer = gconv.Layer(c, 32, 7, dil=7, transposed=True)
+    oh, ow = layer.out_hw(h, w)
+    y = torch.empty(b, oh, ow, 32, device=dev)
+    d = gconv._desc(b, gconv.View(x), gconv.View(y), c, 32, (7, 7), (1, 1), (7, 7), (42, 42))
+    lib = _lib.lib()
+    assert lib.dd_dconv_split_supported(C.byref(d)) == 1
+    xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+    _lib.check(lib.dd_dconv_split_input(C.c_void_p(x.data_ptr()), C.c_void_p(xs.data_ptr()), C.byref(d), None), "split_input")
+    torch.cuda.synchronize()
+    img = xs.view(torch.int16).view(b, h, c // 16, w, 56)[..., :48].reshape(b, h, c // 16, w, 3, 16)      # [b, y, q, px, plane, ch]
+    planes = (img.to(torch.int32) << 16).view(torch.float32)
+    total = planes[..., 0, :].double() + planes[..., 1, :].double() + planes[..., 2, :].double()
+    back = total.permute(0, 1, 3, 2, 4).reshape(b, h, w, c)
+    assert torch.equal(back, x.double())

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""A/B of the box heads' up-conv forwards at bs 32: exact fp32 MFMA kernel vs the bf16 x 3 split-product kernel (csrc/dconv_split.hip).
+
+    python tools/bench_split.py [--batch 32] [--iters 10]
+Prints per layer: exact ms, split ms (kernel alone, and with the input split + weight pack passes), max |difference| / peak.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from driving_dirty_amd import gconv  # noqa: E402
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    import ctypes as C
+    from driving_dirty_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    res = {}
+    for name, cin, cout, hw in (("up_conv_1", 96, 64, 256), ("up_conv_2", 64, 32, 298)):
+        g = torch.Generator(device=dev).manual_seed(1)
+        layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+        oh, ow = layer.out_hw(hw, hw)
+        x = torch.rand(a.batch, hw, hw, cin, device=dev, generator=g)
+        w = (torch.rand(cin, cout, 7, 7, device=dev, generator=g) - 0.5) * 0.05
+        bias = torch.rand(cout, device=dev, generator=g) - 0.5
+        y0 = torch.empty(a.batch, oh, ow, cout, device=dev)
+        y1 = torch.empty_like(y0)
+
+        def run(split, y):
+            gconv.SPLIT_BF16 = split
+            layer.forward(w, bias, gconv.View(x), gconv.View(y), gconv.EPI_BIAS_RELU)
+        t_exact = timed(lambda: run(False, y0), a.iters)
+        t_split_all = timed(lambda: run(True, y1), a.iters)
+        # the kernel alone: operands split once
+        d = gconv._desc(a.batch, gconv.View(x), gconv.View(y1), cin, cout, (7, 7), (1, 1), (7, 7), (42, 42))
+        xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+        pk = torch.empty(lib.dd_dconv_split_packed_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+        t_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(x), P(xs), C.byref(d), st), "in"), a.iters)
+        t_pk = timed(lambda: _lib.check(lib.dd_dconv_split_pack(P(w), P(pk), C.byref(d), 0, 49, cout * 49, 1, cout, cin, st), "pk"), a.iters)
+        t_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(xs), P(pk), P(bias), P(y1), C.byref(d), gconv.EPI_BIAS_RELU, st), "k"), a.iters)
+        flop = 2.0 * a.batch * hw * hw * 49 * cin * cout
+        diff = float((y1 - y0).abs().max() / y0.abs().max())
+        res[name] = {"exact_ms": round(t_exact, 3), "split_total_ms": round(t_split_all, 3), "split_kernel_ms": round(t_k, 3),
+                     "split_input_ms": round(t_in, 3), "split_pack_ms": round(t_pk, 3), "exact_TF": round(flop / t_exact / 1e9, 1),
+                     "split_kernel_TF_equiv": round(flop / t_k / 1e9, 1), "max_diff_of_peak": diff}
+    gconv.SPLIT_BF16 = False
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
