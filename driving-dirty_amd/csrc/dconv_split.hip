@@ -131,17 +131,20 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
   const int row_bytes = d.in_w * SP_PXB;
   const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
 
-  // this wave's tiles: linear index L = m-tile * K + kx (MODE 0: m-tile = wave, kx = slot)
-  int s_kx[NSLOT], s_mt[NSLOT];
-  bool s_ok[NSLOT];
-#pragma unroll
-  for (int i = 0; i < NSLOT; ++i) {
-    const int L = ONE_MT ? wave * K + i : wave * NSLOT + i;
-    s_ok[i] = L < n_mt * K;
-    const int mt = s_ok[i] ? L / K : 0;
-    s_kx[i] = s_ok[i] ? L - mt * K : 0;
-    s_mt[i] = mt;
-  }
+  // this wave's tiles: linear index L = m-tile * K + kx (MODE 0: m-tile = wave, kx = slot).  Slot -> (valid, m-tile, kx) is
+  // recomputed where it is used from a wave id the compiler cannot see through (`wv`, laundered per use): kept as arrays the 3 x
+  // NSLOT loop-invariant scalars live across the whole persistent loop and spill (MODE 1: 206 SGPRs parked in VGPR lanes, 72 B of
+  // scratch on top)
+  auto slot = [&](int wv, int i, bool& ok, int& mt, int& kx) {
+    if constexpr (ONE_MT) {
+      ok = true; mt = wv; kx = i;
+    } else {
+      const int L = wv * NSLOT + i;
+      ok = L < n_mt * K;
+      mt = ok ? L / K : 0;
+      kx = ok ? L - mt * K : 0;
+    }
+  };
   const int a_lane = (lane & 31) * SP_PXB + (lane >> 5) * 16;      // this lane's A fragment inside an m-tile's 32 pixels
   const int ioff_lane = 4 * (lane >> 5) * P + (lane & 31);         // its accumulator element 0 in the output row image
 
@@ -205,37 +208,56 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
       for (int s = 0; s < nstage; ++s) {
         int qn = q, kyn = ky + 1;
         if (kyn > ky1) { kyn = ky0; qn = q + 1; }
-        if (s + 1 < nstage) fill(par ^ 1, cur, qn, kyn);
         const char* sb = lds + par * STAGE;
         const char* bp = sb + AROW + lane * 16;
-        if constexpr (ONE_MT) {
-          const char* ap = sb + wave * (32 * SP_PXB) + a_lane;
-          const bf16x8 Ah = *(const bf16x8*)ap, Am = *(const bf16x8*)(ap + 32), Al = *(const bf16x8*)(ap + 64);
+        // Operand reads run ONE SLOT AHEAD of the MFMAs that consume them (left to itself the compiler issues each slot's reads
+        // right in front of its MFMAs and waits out the LDS latency three times a slot: measured 2x the MFMA time).  The stage's
+        // first reads go out before the next stage's DMA is issued, so that its ~100 scalar instructions sit in their shadow.
+        bf16x8 A[3], An[3], Bc[3], Bn[3];
+        int wv = wave;
+        asm volatile("" : "+s"(wv));
+        auto lda = [&](int i, bf16x8(&a)[3]) {
+          bool ok; int mt, kx;
+          slot(wv, i, ok, mt, kx);
+          const char* ap = sb + mt * (32 * SP_PXB) + a_lane;
+          a[0] = *(const bf16x8*)ap;
+          a[1] = *(const bf16x8*)(ap + 32);
+          a[2] = *(const bf16x8*)(ap + 64);
+        };
+        auto ldb = [&](int i, bf16x8(&b)[3]) {
+          bool ok; int mt, kx;
+          slot(wv, i, ok, mt, kx);
+          const char* bq = bp + kx * 3072;
+          b[0] = *(const bf16x8*)bq;
+          b[1] = *(const bf16x8*)(bq + 1024);
+          b[2] = *(const bf16x8*)(bq + 2048);
+        };
+        auto valid = [&](int i) { bool ok; int mt, kx; slot(wv, i, ok, mt, kx); return ok; };
+        lda(0, A);
+        ldb(0, Bc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nstage) fill(par ^ 1, cur, qn, kyn);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < NSLOT; ++i) {
-            const bf16x8 Bh = *(const bf16x8*)(bp + i * 3072), Bm = *(const bf16x8*)(bp + i * 3072 + 1024), Bl = *(const bf16x8*)(bp + i * 3072 + 2048);
-            acc[i] = SP_MFMA(Al, Bh, acc[i]);
-            acc[i] = SP_MFMA(Ah, Bl, acc[i]);
-            acc[i] = SP_MFMA(Am, Bm, acc[i]);
-            acc[i] = SP_MFMA(Am, Bh, acc[i]);
-            acc[i] = SP_MFMA(Ah, Bm, acc[i]);
-            acc[i] = SP_MFMA(Ah, Bh, acc[i]);
+        for (int i = 0; i < NSLOT; ++i) {
+          if (i + 1 < NSLOT && valid(i + 1)) {
+            ldb(i + 1, Bn);
+            if constexpr (!ONE_MT) lda(i + 1, An);
           }
-        } else {
+          __builtin_amdgcn_sched_barrier(0);
+          if (valid(i)) {                                     // hi = [0], mid = [1], lo = [2]; smallest products first
+            acc[i] = SP_MFMA(A[2], Bc[0], acc[i]);
+            acc[i] = SP_MFMA(A[0], Bc[2], acc[i]);
+            acc[i] = SP_MFMA(A[1], Bc[1], acc[i]);
+            acc[i] = SP_MFMA(A[1], Bc[0], acc[i]);
+            acc[i] = SP_MFMA(A[0], Bc[1], acc[i]);
+            acc[i] = SP_MFMA(A[0], Bc[0], acc[i]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < NSLOT; ++i) {
-            if (s_ok[i]) {
-              const char* ap = sb + s_mt[i] * (32 * SP_PXB) + a_lane;
-              const char* bq = bp + s_kx[i] * 3072;
-              const bf16x8 Ah = *(const bf16x8*)ap, Am = *(const bf16x8*)(ap + 32), Al = *(const bf16x8*)(ap + 64);
-              const bf16x8 Bh = *(const bf16x8*)bq, Bm = *(const bf16x8*)(bq + 1024), Bl = *(const bf16x8*)(bq + 2048);
-              acc[i] = SP_MFMA(Al, Bh, acc[i]);
-              acc[i] = SP_MFMA(Ah, Bl, acc[i]);
-              acc[i] = SP_MFMA(Am, Bm, acc[i]);
-              acc[i] = SP_MFMA(Am, Bh, acc[i]);
-              acc[i] = SP_MFMA(Ah, Bm, acc[i]);
-              acc[i] = SP_MFMA(Ah, Bh, acc[i]);
-            }
+          for (int pl = 0; pl < 3; ++pl) {
+            Bc[pl] = Bn[pl];
+            if constexpr (!ONE_MT) A[pl] = An[pl];
           }
         }
         sp_barrier();                                         // this wave's DMA has landed, every wave is done with buffer `par`
@@ -259,10 +281,14 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
 #pragma unroll
       for (int pass = K - 1; pass >= 0; --pass) {
         const int shift = D * (K - 1 - pass);
+        int wv = wave;
+        asm volatile("" : "+s"(wv));
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-          if (ONE_MT ? (i == pass && s_ok[i]) : (s_ok[i] && s_kx[i] == pass)) {
-            float* p0 = img + ioff_lane + s_mt[i] * (TW * P);
+          bool ok; int mt, kx;
+          slot(wv, i, ok, mt, kx);
+          if (ONE_MT ? i == pass : (ok && kx == pass)) {
+            float* p0 = img + ioff_lane + mt * (TW * P);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
               float* pe = p0 + ((e & 3) + 8 * (e >> 2) + shift) * P;
