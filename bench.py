@@ -416,6 +416,18 @@ def other_configs(a, dev, steps=10, warmup=3):
         ms = res[names[c]]["ms_per_step"]
         res[names[c]].update(algorithmic_TFLOPs=round(algo / (ms * 1e-3) / 1e12, 1),
                              **{("frac_bf16_mfma_peak" if c == 5 else "frac_fp32_mfma_peak"): round(algo / (ms * 1e-3) / 1e12 / peak, 4)})
+        if c == 3:
+            # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with the forwards of up_conv_1 / up_conv_2 taking every fp32
+            # product as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulate) on the bf16 matrix pipe
+            from driving_dirty_amd import gconv
+            watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[4]).cin == 96), "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[4]).cin == 64),
+                     "split_input_pass": ("dd_dconv_split_input", lambda *x: True)}
+            gconv.SPLIT_BF16 = True
+            try:
+                run("config3_bbox_split_products_bs32", cfg["model"], cfg["batch"], cfg["per_gpu_batch"],
+                    {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forwards of up_conv_1 / up_conv_2; everything else exact fp32"}, watch, "3s")
+            finally:
+                gconv.SPLIT_BF16 = False
         del cfg
         torch.cuda.empty_cache()
     # config 2 at the reference's DEFAULT width (autoencoder.py:33-34,164-166: hidden 256 / latent 128; SURVEY.md 8d "also report 256/128"):
@@ -623,7 +635,16 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
         if ms is None:
             continue
         entry = {"launch_ms": round(ms, 4), "launches_timed": len(timer.pairs[key])}
-        if cfg in (3, 4):
+        if cfg == "3s":
+            if key == "split_input_pass":
+                entry.update(kernel="split_input_kernel (fp32 -> three bf16 planes; both layers' launches averaged)", bound="hbm")
+            else:
+                flop = (UPCONV1_FLOP_PER_SCENE if key.startswith("up_conv_1") else UPCONV2_FLOP_PER_SCENE) * per_gpu_batch
+                # 6 bf16 products per fp32 product: the matrix work ISSUED is 6x the algorithmic flops, priced at the dense bf16 peak
+                entry.update(kernel="dconv_stfwd_kernel (%s forward, split products)" % key[:9], bound="mfma", achieved=round(6 * flop / (ms * 1e-3) / 1e12, 1),
+                             peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s (bf16 products issued)", frac=round(6 * flop / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF, 4),
+                             fp32_equivalent_TFLOPs=round(flop / (ms * 1e-3) / 1e12, 1))
+        elif cfg in (3, 4):
             layer, what = key.rsplit("_", 1)
             flop = {"up_conv_1": UPCONV1_FLOP_PER_SCENE, "up_conv_2": UPCONV2_FLOP_PER_SCENE}[layer] * per_gpu_batch
             entry.update(kernel={"up_conv_1_fwd": "dconv_tfwd_kernel (up_conv_1 forward, input-aligned)",
@@ -654,7 +675,7 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
         kernels[key] = entry
     if not kernels:
         return None
-    dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])
+    dom = max((k for k in kernels if "achieved" in kernels[k]), key=lambda k: kernels[k]["launch_ms"])
     k = kernels[dom]
     roof = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
             "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"], "traffic": None, "kernels": kernels}

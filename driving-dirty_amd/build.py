@@ -36,6 +36,28 @@ def needs_build():
     return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
+def build_diag(verbose=True):
+    """``csrc/libdd_hotpath_diag.so``: the same library compiled with -DDD_TIMING_DIAG (timing ablations of single kernels whose
+    results are then WRONG: DD_DCONV_REPEAT, DD_SPLIT_ABL).  Never loaded unless DD_HOTPATH_LIB points at it; not built by build()."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(CSRC, "build_diag")
+    os.makedirs(out, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(out, os.path.splitext(src)[0] + ".o")
+        if _stale(obj, [os.path.join(CSRC, src)] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-DDD_TIMING_DIAG", "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        objs = list(pool.map(one, SOURCES))
+    lib = os.path.join(CSRC, "libdd_hotpath_diag.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -59,4 +81,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--diag" in sys.argv:
+        print(build_diag())
+    else:
+        build(force="--force" in sys.argv)

@@ -107,10 +107,12 @@ struct SpTask {
   int b, nt, oy, ry, ky0, ky1;
 };
 
-template <int K, int D, int NSLOT, int MODE, int IWP>
+template <int K, int D, int NSLOT, int MODE, int IWP, int abl, int NBUF>
 __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __restrict__ xs, const char* __restrict__ wp,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
                                                                  const dd_gconv_desc d, int epi) {
+  // abl (template): timing ablations of DD_TIMING_DIAG builds (results are then wrong; 0 in every other build): 1 no MFMAs, 2 no DMA after a
+  // task's first stage, 4 no shift-add passes in the epilogue, 8 no operand reads after a stage's first
   constexpr bool ONE_MT = MODE == 0;
   constexpr int TW = 32, NE = 16, P = 40, HALO = D * (K - 1);
   constexpr int AROW = IWP * SP_PXB;                       // bytes of the A image of a stage (one input row, one chunk)
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
   constexpr int NA = AROW / 1024, NB = K * 3, NI = NA + NB;      // 1 KB wave-instructions of a stage fill
   static_assert(AROW % 1024 == 0, "the A image is filled in whole 1 KB wave-instructions");
   constexpr int IMG = (IWP + HALO) * P * 4;
-  constexpr int LDSB = 2 * STAGE > IMG ? 2 * STAGE : IMG;
+  constexpr int LDSB = NBUF * STAGE > IMG ? NBUF * STAGE : IMG;
+  static_assert(NBUF == 2 || NBUF == 3, "two buffers: the next stage's fill must land inside this stage; three: it has two");
+  static_assert(LDSB <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) char lds[LDSB];
   using acc_t = f32x16;
 
@@ -173,13 +177,16 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
 
   // ---- stage fill by LDS-DMA: wave-instruction j of the stage copies 1 KB; lanes past the end of the row read zeros (the buffer
   // descriptor ends with the row), which is what the pixels of a ragged last m-tile must hold
-  auto fill = [&](int buf, const SpTask& k, int q, int ky) {
+  // piece i of a wave's share of a stage fill (wave-instruction j = wave + 8 i of the stage's NI); i = -1: the whole share
+  constexpr int NPW = (NI + 7) / 8;
+  auto fill = [&](int buf, const SpTask& k, int q, int ky, int only) {
     const long arow = ((long)(k.b * d.in_h + k.ry + D * ky) * NC + q) * row_bytes;
     const __amdgpu_buffer_rsrc_t ra = dd_rsrc(xs + arow, row_bytes);
     const __amdgpu_buffer_rsrc_t rb = dd_rsrc(wp + ((long)(q * K + ky) * NTC + k.nt) * BST, BST);
     char* base = lds + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < (NI + 7) / 8; ++i) {
+    for (int i = 0; i < NPW; ++i) {
+      if (only >= 0 && i != only) continue;
       const int j = wave + 8 * i;
       if (j < NA)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, lane * 16, j * 1024, 0, 0);
@@ -188,7 +195,6 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
                                                  (j - NA) * 1024, 0, 0);
     }
   };
-
   SpTask cur;
   long t = next_task(len * xcd / 8 + (blockIdx.x >> 3), cur);
   while (t < seg1) {
@@ -200,19 +206,35 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
       for (int e = 0; e < NE; ++e) acc[i][e] = 0.f;
 
     if (ky1 >= ky0) {
-      int par = 0;
-      fill(0, cur, 0, ky0);
-      sp_barrier();
+      // NBUF - 1 stages are in flight ahead of the one being multiplied.  A wave's vector-memory counter retires in order, so
+      // "everything but the pieces of the newest fill" is a counted wait: this wave issued `mine` pieces per fill.
+      const int mine = (NI - 1 - wave) / 8 + 1;
+      auto wait_all_but_newest = [&](bool newest_issued) {
+        if (!newest_issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (mine == NPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW - 1) : "memory");
+      };
       const int nky = ky1 - ky0 + 1, nstage = NC * nky;
-      int q = 0, ky = ky0;
+      int par = 0;
+      // (q, ky) of the stage being filled, NBUF - 1 ahead of the one being multiplied
+      int fq = 0, fky = ky0, fbuf = 0, filled = 0;
+      auto fill_next = [&]() {
+        fill(fbuf, cur, fq, fky, -1);
+        ++filled;
+        fbuf = fbuf + 1 == NBUF ? 0 : fbuf + 1;
+        if (++fky > ky1) { fky = ky0; ++fq; }
+      };
+      fill_next();
+      if (NBUF == 3 && nstage > 1) fill_next();
+      wait_all_but_newest(NBUF == 3 && nstage > 1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       for (int s = 0; s < nstage; ++s) {
-        int qn = q, kyn = ky + 1;
-        if (kyn > ky1) { kyn = ky0; qn = q + 1; }
         const char* sb = lds + par * STAGE;
         const char* bp = sb + AROW + lane * 16;
         // Operand reads run ONE SLOT AHEAD of the MFMAs that consume them (left to itself the compiler issues each slot's reads
         // right in front of its MFMAs and waits out the LDS latency three times a slot: measured 2x the MFMA time).  The stage's
-        // first reads go out before the next stage's DMA is issued, so that its ~100 scalar instructions sit in their shadow.
+        // first reads go out before the next stage's fill is issued.  (One DMA piece per slot instead of all seven here: 5.42 ->
+        // 5.71 ms, dropped.)
         bf16x8 A[3], An[3], Bc[3], Bn[3];
         int wv = wave;
         asm volatile("" : "+s"(wv));
@@ -236,16 +258,17 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
         lda(0, A);
         ldb(0, Bc);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nstage) fill(par ^ 1, cur, qn, kyn);
+        const bool dma = filled < nstage && !(abl & 2);
+        if (dma) fill_next();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-          if (i + 1 < NSLOT && valid(i + 1)) {
+          if (i + 1 < NSLOT && valid(i + 1) && !(abl & 8)) {
             ldb(i + 1, Bn);
             if constexpr (!ONE_MT) lda(i + 1, An);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (valid(i)) {                                     // hi = [0], mid = [1], lo = [2]; smallest products first
+          if (valid(i) && !(abl & 1)) {                       // hi = [0], mid = [1], lo = [2]; smallest products first
             acc[i] = SP_MFMA(A[2], Bc[0], acc[i]);
             acc[i] = SP_MFMA(A[0], Bc[2], acc[i]);
             acc[i] = SP_MFMA(A[1], Bc[1], acc[i]);
@@ -260,10 +283,11 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
             if constexpr (!ONE_MT) A[pl] = An[pl];
           }
         }
-        sp_barrier();                                         // this wave's DMA has landed, every wave is done with buffer `par`
-        par ^= 1;
-        q = qn;
-        ky = kyn;
+        // the NEXT stage's fill has landed (this wave's share; the barrier adds the others'), every wave is done with buffer `par`
+        if (abl & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_all_but_newest(NBUF == 3 && filled > s + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        par = par + 1 == NBUF ? 0 : par + 1;
       }
     }
 
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
       if (tid < HALO * (P / 4)) *(f32x4*)&img[n_mt * TW * P + tid * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
       static_assert(HALO * (P / 4) <= SP_THREADS, "one zeroing store per thread");
 #pragma unroll
-      for (int pass = K - 1; pass >= 0; --pass) {
+      for (int pass = K - 1; pass >= ((abl & 4) ? K - 1 : 0); --pass) {
         const int shift = D * (K - 1 - pass);
         int wv = wave;
         asm volatile("" : "+s"(wv));
@@ -388,12 +412,36 @@ int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, fl
   const int grid = dd_cu_budget_internal() & ~7;
   DD_REQUIRE(grid >= 8, DD_ERR_UNSUPPORTED, "dconv_fwd_split: CU budget below 8");
   hipStream_t st = (hipStream_t)stream;
-  if (d->in_w <= 256)
-    hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 7, 0, 256>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, bias, y, *d,
-                       epilogue);
-  else
-    hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 9, 1, 320>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, bias, y, *d,
-                       epilogue);
+#define SP_LAUNCH_(ABL, NBUF_)                                                                                                                  \
+  do {                                                                                                                                    \
+    if (d->in_w <= 256)                                                                                                                   \
+      hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 7, 0, 256, ABL, NBUF_>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, \
+                         bias, y, *d, epilogue);                                                                                          \
+    else                                                                                                                                  \
+      hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 9, 1, 320, ABL, 2>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, \
+                         bias, y, *d, epilogue);                                                                                          \
+  } while (0)
+  // A/B: DD_SPLIT_NBUF=3 = three LDS buffers for the 256-wide form (a fill has two stages to land): 5.63-5.67 ms against 5.57-5.58 with
+  // two -- the fills' latency is not what the kernel waits for (it runs power-limited at 1.88 GHz, matrix pipe 64 % busy)
+  static const bool three = getenv("DD_SPLIT_NBUF") && atoi(getenv("DD_SPLIT_NBUF")) == 3;
+#define SP_LAUNCH(ABL) do { if (three) SP_LAUNCH_(ABL, 3); else SP_LAUNCH_(ABL, 2); } while (0)
+#ifdef DD_TIMING_DIAG      // diagnostic builds only (build.py --diag): DD_SPLIT_ABL selects a timing ablation, the results are then wrong
+  switch (getenv("DD_SPLIT_ABL") ? atoi(getenv("DD_SPLIT_ABL")) : 0) {
+    case 1: SP_LAUNCH(1); break;
+    case 2: SP_LAUNCH(2); break;
+    case 3: SP_LAUNCH(3); break;
+    case 4: SP_LAUNCH(4); break;
+    case 8: SP_LAUNCH(8); break;
+    case 9: SP_LAUNCH(9); break;
+    case 11: SP_LAUNCH(11); break;
+    case 15: SP_LAUNCH(15); break;
+    default: SP_LAUNCH(0); break;
+  }
+#else
+  SP_LAUNCH(0);
+#endif
+#undef SP_LAUNCH
+#undef SP_LAUNCH_
   DD_LAUNCH_CHECK("dconv_fwd_split");
   return 0;
 }
