@@ -420,7 +420,10 @@ def other_configs(a, dev, steps=10, warmup=3):
             # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with the forwards of up_conv_1 / up_conv_2 taking every fp32
             # product as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulate) on the bf16 matrix pipe
             from driving_dirty_amd import gconv
-            watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[4]).cin == 96), "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[4]).cin == 64),
+            watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 96 and _desc(x[5]).pad_h > 0),
+                     "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 32 and _desc(x[5]).pad_h > 0),
+                     "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96 and _desc(x[5]).pad_h == 0),
+                     "up_conv_2_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 32 and _desc(x[5]).cout == 64 and _desc(x[5]).pad_h == 0),
                      "split_input_pass": ("dd_dconv_split_input", lambda *x: True)}
             gconv.SPLIT_BF16 = True
             try:
@@ -641,7 +644,7 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
             else:
                 flop = (UPCONV1_FLOP_PER_SCENE if key.startswith("up_conv_1") else UPCONV2_FLOP_PER_SCENE) * per_gpu_batch
                 # 6 bf16 products per fp32 product: the matrix work ISSUED is 6x the algorithmic flops, priced at the dense bf16 peak
-                entry.update(kernel="dconv_stfwd_kernel (%s forward, split products)" % key[:9], bound="mfma", achieved=round(6 * flop / (ms * 1e-3) / 1e12, 1),
+                entry.update(kernel="%s (%s %s, split products)" % ("dconv_sgfwd_kernel" if "dgrad" in key else "dconv_stfwd_kernel", key[:9], "data gradient" if "dgrad" in key else "forward"), bound="mfma", achieved=round(6 * flop / (ms * 1e-3) / 1e12, 1),
                              peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s (bf16 products issued)", frac=round(6 * flop / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF, 4),
                              fp32_equivalent_TFLOPs=round(flop / (ms * 1e-3) / 1e12, 1))
         elif cfg in (3, 4):

@@ -348,16 +348,205 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
   }
 }
 
-bool sp_layer_ok(const dd_gconv_desc* d) {
+// =====================================================================================================================
+// The DATA GRADIENT of the same layers with split products: a plain dilated convolution (pad 0, out = in - d(k-1)) in gather form, as
+// dconv_gfwd_kernel: one output row per workgroup, wave w = m-tile w (32 output pixels) x all NTC column tiles, one accumulator per
+// column tile (no shift-add epilogue).  The A operand of a (chunk, tap row) -- the seven tap-shifted fragments of the wave's pixels, three
+// planes each -- is read ONCE from LDS into registers (84 VGPRs) and multiplied with the B images of the NTC column tiles in turn; the B
+// image of one (chunk, tap row, column tile) is 21 KB, so the stage is cut per column tile: two A buffers (alternating per (chunk, tap
+// row)), two B buffers (alternating per sub-stage), everything filled by LDS-DMA one sub-stage ahead, one s_barrier per sub-stage of 42
+// MFMAs per wave.  NW = 8 waves (rows up to 256 output pixels: up_conv_1) or 10 (up to 320: up_conv_2; SIMDs then hold 3 / 3 / 2 / 2 waves).
+template <int K, int D, int NTC, int NW, int IWP>
+__global__ __launch_bounds__(NW * 64) void dconv_sgfwd_kernel(const char* __restrict__ xs, const char* __restrict__ wp,
+                                                              const float* __restrict__ msk, float* __restrict__ y, const dd_gconv_desc d,
+                                                              int epi) {
+  constexpr int AROW = IWP * SP_PXB, BST = K * 3 * 1024;
+  constexpr int NA = AROW / 1024, NB = K * 3;
+  static_assert(AROW % 1024 == 0, "the A image is filled in whole 1 KB wave-instructions");
+  static_assert(2 * AROW + 2 * BST <= 160 * 1024, "LDS");
+  static_assert(NW * 32 + D * (K - 1) <= IWP, "the last wave's last tap stays inside the A image");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * AROW + 2 * BST];
+  char* const abuf = lds;
+  char* const bbuf = lds + 2 * AROW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31;
+  const int NC = d.cin >> 4;
+  const int rows_max = (d.out_h + D - 1) / D;
+  const int n_mt = (d.out_w + 31) >> 5;
+  const int row_bytes = d.in_w * SP_PXB;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+  const int a_lane = (wave * 32 + n) * SP_PXB + (lane >> 5) * 16;      // this lane's A fragment of tap column 0 inside a row image
+
+  const int per_x = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int per_img = D * rows_max;
+  const long len = (long)d.batch * per_img;
+  const long seg1 = len * (xcd + 1) / 8;
+  auto decode = [&](long t, int& b, int& oy) -> bool {
+    b = (int)(t / per_img);
+    const int rem = (int)(t - (long)b * per_img);
+    const int r = rem / rows_max, jy = rem - r * rows_max;
+    oy = r + D * jy;
+    return oy < d.out_h;
+  };
+  auto next_task = [&](long t, int& b, int& oy) -> long {
+    while (t < seg1 && !decode(t, b, oy)) t += per_x;
+    return t < seg1 ? t : seg1;
+  };
+
+  auto fill_a = [&](int buf, int b, int row, int q) {
+    const long arow = ((long)(b * d.in_h + row) * NC + q) * row_bytes;
+    const __amdgpu_buffer_rsrc_t ra = dd_rsrc(xs + arow, row_bytes);
+#pragma unroll
+    for (int i = 0; i < (NA + NW - 1) / NW; ++i) {
+      const int j = wave + NW * i;
+      if (j < NA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(abuf + buf * AROW + j * 1024), 16, lane * 16, j * 1024, 0, 0);
+    }
+  };
+  auto fill_b = [&](int buf, int q, int ky, int nt) {
+    const __amdgpu_buffer_rsrc_t rb = dd_rsrc(wp + ((long)(q * K + ky) * NTC + nt) * BST, BST);
+#pragma unroll
+    for (int i = 0; i < (NB + NW - 1) / NW; ++i) {
+      const int j = wave + NW * i;
+      if (j < NB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(bbuf + buf * BST + j * 1024), 16, lane * 16, j * 1024, 0, 0);
+    }
+  };
+
+  int cb, coy;
+  long t = next_task(len * xcd / 8 + (blockIdx.x >> 3), cb, coy);
+  while (t < seg1) {
+    f32x16 acc[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    fill_a(0, cb, coy, 0);
+    fill_b(0, 0, 0, 0);
+    sp_barrier();
+    int apar = 0, bpar = 0;
+    bf16x8 A[K][3];
+    for (int q = 0; q < NC; ++q) {
+      for (int ky = 0; ky < K; ++ky) {
+        const bool last_qk = q == NC - 1 && ky == K - 1;
+        const int qn = ky == K - 1 ? q + 1 : q, kyn = ky == K - 1 ? 0 : ky + 1;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+          const char* bp = bbuf + bpar * BST + lane * 16;
+          bf16x8 Bc[3], Bn[3];
+          if (nt == 0) {      // the (chunk, tap row)'s A fragments: read once, used for every column tile
+            const char* ap = abuf + apar * AROW + a_lane;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+              A[kx][0] = *(const bf16x8*)(ap + kx * (D * SP_PXB));
+              A[kx][1] = *(const bf16x8*)(ap + kx * (D * SP_PXB) + 32);
+              A[kx][2] = *(const bf16x8*)(ap + kx * (D * SP_PXB) + 64);
+            }
+          }
+          Bc[0] = *(const bf16x8*)bp;
+          Bc[1] = *(const bf16x8*)(bp + 1024);
+          Bc[2] = *(const bf16x8*)(bp + 2048);
+          __builtin_amdgcn_sched_barrier(0);
+          // the next sub-stage's images: the next column tile's B, or (last column tile) the next (chunk, tap row)'s A and first B
+          if (nt + 1 < NTC) {
+            fill_b(bpar ^ 1, q, ky, nt + 1);
+          } else if (!last_qk) {
+            fill_a(apar ^ 1, cb, coy + D * kyn, qn);
+            fill_b(bpar ^ 1, qn, kyn, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            if (kx + 1 < K) {
+              Bn[0] = *(const bf16x8*)(bp + (kx + 1) * 3072);
+              Bn[1] = *(const bf16x8*)(bp + (kx + 1) * 3072 + 1024);
+              Bn[2] = *(const bf16x8*)(bp + (kx + 1) * 3072 + 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[nt] = SP_MFMA(A[kx][2], Bc[0], acc[nt]);      // hi = [0], mid = [1], lo = [2]; smallest products first
+            acc[nt] = SP_MFMA(A[kx][0], Bc[2], acc[nt]);
+            acc[nt] = SP_MFMA(A[kx][1], Bc[1], acc[nt]);
+            acc[nt] = SP_MFMA(A[kx][1], Bc[0], acc[nt]);
+            acc[nt] = SP_MFMA(A[kx][0], Bc[1], acc[nt]);
+            acc[nt] = SP_MFMA(A[kx][0], Bc[0], acc[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Bc[pl] = Bn[pl];
+          }
+          sp_barrier();
+          bpar ^= 1;
+        }
+        apar ^= 1;
+      }
+    }
+
+    // ---- write-out (as dconv_gfwd_kernel: all mask values of a tile requested before the first is used)
+    {
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cb * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)cb * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+      const bool masked = epi == DD_EPI_RELU_MASK;
+      const int base = ((coy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) {
+        const int ch = nt * 32 + n;
+        const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+        int off[16];
+        float mv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int xo = wave * 32 + dd_acc_row(r, lane);
+          const bool ok = wave < n_mt && xo < d.out_w && ch < d.cout;
+          off[r] = ok ? (base + xo * d.out_cstore + ch) * 4 : -16;
+          mv[r] = 1.f;
+        }
+        if (masked) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float m = dd_bload1(ms, pass ? -16 : off[r]);
+            mv[r] = pass ? 1.f : m;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dd_bstore1(ys, off[r], mv[r] > 0.f ? acc[nt][r] : 0.f);
+      }
+    }
+    sp_barrier();
+    t = next_task(t + per_x, cb, coy);
+  }
+}
+
+bool sp_common_ok(const dd_gconv_desc* d) {
   if (!dd_dconv_desc_ok(d)) return false;
   if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7) return false;
-  if (d->pad_h != 42 || d->pad_w != 42) return false;                                          // the full transposed form only
-  if (d->out_h < d->in_h + 42 || d->out_w < d->in_w + 42) return false;
-  if (d->cin % 16 || d->cout <= 16 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
-  if (d->in_w > 320 || d->out_w > ((d->in_w + 31) / 32) * 32 + 42) return false;
+  if (d->cin % 16 || d->cout <= 16 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4 || d->cout > 96) return false;
   if ((long)d->in_w * SP_PXB * (d->cin / 16) * d->in_h * d->batch >= (1L << 40)) return false;
   return true;
 }
+
+// the forward: the full transposed form (pad = d(k-1), out = in + d(k-1))
+bool sp_fwd_ok(const dd_gconv_desc* d) {
+  if (!sp_common_ok(d)) return false;
+  if (d->pad_h != 42 || d->pad_w != 42) return false;
+  if (d->out_h < d->in_h + 42 || d->out_w < d->in_w + 42) return false;
+  if (d->in_w > 320 || d->out_w > ((d->in_w + 31) / 32) * 32 + 42) return false;
+  return true;
+}
+
+// the data gradient: a plain dilated convolution (pad 0, out = in - d(k-1)), rows of at most 320 output pixels
+bool sp_dgrad_ok(const dd_gconv_desc* d) {
+  if (!sp_common_ok(d)) return false;
+  if (d->pad_h != 0 || d->pad_w != 0) return false;
+  if (d->out_h > d->in_h - 42 || d->out_w > d->in_w - 42) return false;
+  if (d->out_w > 320 || d->in_w > 384) return false;
+  if ((d->out_w > 256 || d->in_w > 320) && d->cout > 64) return false;      // the 10-wave form holds at most two column tiles in 170 registers
+  return true;
+}
+
+bool sp_layer_ok(const dd_gconv_desc* d) { return sp_fwd_ok(d) || sp_dgrad_ok(d); }
 
 }  // namespace
 
@@ -401,18 +590,34 @@ int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, in
   return 0;
 }
 
-int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, float* y, const dd_gconv_desc* d, int32_t epilogue,
-                       void* stream) {
+int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                       int32_t epilogue, void* stream) {
   DD_REQUIRE(d && sp_layer_ok(d), DD_ERR_UNSUPPORTED, "dconv_fwd_split: unsupported layer");
   DD_REQUIRE(xs && packed && y, DD_ERR_BAD_ARG, "dconv_fwd_split: NULL pointer");
+  const int grid = dd_cu_budget_internal() & ~7;
+  DD_REQUIRE(grid >= 8, DD_ERR_UNSUPPORTED, "dconv_fwd_split: CU budget below 8");
+  hipStream_t st = (hipStream_t)stream;
+  if (sp_dgrad_ok(d)) {      // gather form: the data gradient (no bias; NONE or the ReLU mask of the layer's input)
+    DD_REQUIRE(epilogue == DD_EPI_NONE || epilogue == DD_EPI_RELU_MASK, DD_ERR_BAD_ARG, "dconv_fwd_split: data-gradient epilogue %d", epilogue);
+    DD_REQUIRE(epilogue != DD_EPI_RELU_MASK || mask, DD_ERR_BAD_ARG, "dconv_fwd_split: RELU_MASK needs a mask");
+    const int ntc = (d->cout + 31) / 32;
+#define SG_LAUNCH(NTC_, NW_, IWP_)                                                                                                   \
+  hipLaunchKernelGGL((dconv_sgfwd_kernel<7, 7, NTC_, NW_, IWP_>), dim3(grid), dim3(NW_ * 64), 0, st, (const char*)xs, (const char*)packed, \
+                     mask, y, *d, epilogue)
+    if (d->out_w <= 256 && d->in_w <= 320) {
+      if (ntc == 1) SG_LAUNCH(1, 8, 320); else if (ntc == 2) SG_LAUNCH(2, 8, 320); else SG_LAUNCH(3, 8, 320);
+    } else {
+      if (ntc == 1) SG_LAUNCH(1, 10, 384); else SG_LAUNCH(2, 10, 384);
+    }
+#undef SG_LAUNCH
+    DD_LAUNCH_CHECK("dconv_fwd_split (data gradient)");
+    return 0;
+  }
   DD_REQUIRE(epilogue == DD_EPI_NONE || epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU, DD_ERR_BAD_ARG, "dconv_fwd_split: epilogue %d",
              epilogue);
   DD_REQUIRE(!(epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) || (bias && ((uintptr_t)bias & 15) == 0), DD_ERR_BAD_ARG,
              "dconv_fwd_split: bias epilogue needs a 16-byte aligned bias");
-  const int grid = dd_cu_budget_internal() & ~7;
-  DD_REQUIRE(grid >= 8, DD_ERR_UNSUPPORTED, "dconv_fwd_split: CU budget below 8");
-  hipStream_t st = (hipStream_t)stream;
-#define SP_LAUNCH_(ABL, NBUF_)                                                                                                                  \
+#define SP_LAUNCH_(ABL, NBUF_)                                                                                                            \
   do {                                                                                                                                    \
     if (d->in_w <= 256)                                                                                                                   \
       hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 7, 0, 256, ABL, NBUF_>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, \

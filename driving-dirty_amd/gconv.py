@@ -103,7 +103,7 @@ DCONV = os.environ.get("DD_DCONV", "1") != "0"
 PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
 
 
-# EXPERIMENT (csrc/dconv_split.hip), off by default: the forward of up_conv_1 / up_conv_2 with every fp32 product taken as
+# EXPERIMENT (csrc/dconv_split.hip), off by default: the forward and the data gradient of up_conv_1 / up_conv_2 with every fp32 product taken as
 # six bf16 x bf16 products (exact 3-way operand split, fp32 accumulation) on the bf16 matrix pipe.  DD_DCONV_SPLIT=1 or
 # gconv.SPLIT_BF16 = True selects it; the default stays the exact-fp32 MFMA kernels.
 SPLIT_BF16 = os.environ.get("DD_DCONV_SPLIT", "0") == "1"
@@ -121,12 +121,13 @@ def _dconv_ok(d):
 def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real):
     """pack + launch on the dilated kernel when the descriptor qualifies, on the generic one otherwise"""
     lib = _lib.lib()
-    if SPLIT_BF16 and mask is None and epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU) and lib.dd_dconv_split_supported(C.byref(d)):
+    if SPLIT_BF16 and lib.dd_dconv_split_supported(C.byref(d)) and (
+            (d.pad_h > 0 and mask is None and epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU)) or (d.pad_h == 0 and epi in (EPI_NONE, EPI_RELU_MASK))):
         xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=x.device, dtype=torch.uint8)
         packed = torch.empty(lib.dd_dconv_split_packed_bytes(C.byref(d)), device=x.device, dtype=torch.uint8)
         check(lib.dd_dconv_split_input(_p(x), _p(xs), C.byref(d), _stream()), "dd_dconv_split_input")
         check(lib.dd_dconv_split_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_split_pack")
-        check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(y), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
+        check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
         return
     if _dconv_ok(d):
         n = lib.dd_dconv_packed_floats(C.byref(d))

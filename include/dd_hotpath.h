@@ -340,16 +340,19 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
  * parameters and epilogues (NONE / BIAS / BIAS_RELU) as dd_dconv_pack + dd_dconv_fwd; the operands are split once, outside:
  *   dd_dconv_split_input   x (NHWC fp32, channels [in_coff, +cin)) -> xs, dd_dconv_split_input_bytes(d) bytes
  *   dd_dconv_split_pack    weights -> packed, dd_dconv_split_packed_bytes(d) bytes
- *   dd_dconv_fwd_split     y = epilogue(conv_transpose(x, w))
- * dd_dconv_split_supported(d): 1 for the layers it is built for (full transposed form, cin % 16 == 0, in_w <= 320). */
+ *   dd_dconv_fwd_split     y = epilogue(conv_transpose(x, w)) -- and, for a descriptor in gather form (pad 0, out = in - d(k-1):
+ *                          what dd_dconv_fwd takes for the data gradient), the DATA GRADIENT of the same layers, epilogue NONE or
+ *                          RELU_MASK (`mask` = the layer's input, as for dd_dconv_fwd; mask_pass_lo/hi honoured)
+ * dd_dconv_split_supported(d): 1 for the descriptors it is built for (k7 d7, cin % 16 == 0, 16 < cout <= 96; forward: full transposed
+ * form, in_w <= 320; data gradient: out_w <= 320). */
 int32_t dd_dconv_split_supported(const dd_gconv_desc* d);
 int64_t dd_dconv_split_input_bytes(const dd_gconv_desc* d);
 int64_t dd_dconv_split_packed_bytes(const dd_gconv_desc* d);
 int dd_dconv_split_input(const float* x, void* xs, const dd_gconv_desc* d, void* stream);
 int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc, int32_t flip,
                         int32_t n_real, int32_t c_real, void* stream);
-int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, float* y, const dd_gconv_desc* d, int32_t epilogue,
-                       void* stream);
+int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                       int32_t epilogue, void* stream);
 
 /* Weight gradient of the same layers (ConvTranspose2d stride 1, dilation `dil`, kernel k x k, no padding):
  *   dw[c][o][ky][kx] (IOHW, PyTorch's layout) (+)= sum over images and pixels of x[iy][ix][c] * g[iy + dil*ky][ix + dil*kx][o]

@@ -440,35 +440,74 @@ _SPLIT_CASES = [
 
 
 @pytest.mark.parametrize("name,cin,cout,shape", _SPLIT_CASES, ids=[c[0] for c in _SPLIT_CASES])
-def test_split_bf16_forward_against_fp64_and_the_exact_kernel(dev, name, cin, cout, shape):
-    """csrc/dconv_split.hip (off by default): the k7 d7 transposed forward with every fp32 product as six bf16 x bf16 products on the
-    bf16 matrix pipe.  Held to the exact kernels' own bound -- 2e-5 of peak against fp64 torch -- and compared with the exact fp32
-    kernel on the same operands (both errors are reported; the split path must not be the worse one by more than 4x)."""
+def test_split_bf16_forward_and_data_gradient_against_fp64_and_the_exact_kernels(dev, name, cin, cout, shape):
+    """csrc/dconv_split.hip (off by default): the k7 d7 transposed forward and its data gradient (with and without the fused ReLU mask
+    of the producer) with every fp32 product as six bf16 x bf16 products on the bf16 matrix pipe.  Held to the exact kernels' own
+    bound -- 2e-5 of peak against fp64 torch -- and compared with the exact fp32 kernels on the same operands (the split path must
+    not be the worse one by more than 4x)."""
     from torch import nn
     from torch.nn import functional as F
     from driving_dirty_amd import gconv, synth
     b, h, w = shape
     mod = synth.fill_module(nn.ConvTranspose2d(cin, cout, 7, dilation=7), seed=21).double()
-    x = synth.hash_uniform((b, cin, h, w), synth.key_salt("spx" + name), -1.0, 1.0).double()
+    x = synth.hash_uniform((b, cin, h, w), synth.key_salt("spx" + name), -1.0, 1.0).double().requires_grad_(True)
     y_ref = F.relu(mod(x))
+    gy = synth.hash_uniform(tuple(y_ref.shape), synth.key_salt("spg" + name), -1.0, 1.0).double()
+    y_ref.backward(gy * (y_ref > 0))
     layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
     oh, ow = layer.out_hw(h, w)
-    xb = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    xb = x.detach().float().permute(0, 2, 3, 1).contiguous().to(dev)
+    gb = (gy * (y_ref > 0)).detach().float().permute(0, 2, 3, 1).contiguous().to(dev)
+    mb = (x.detach() - 0.25).float().permute(0, 2, 3, 1).contiguous().to(dev)          # a stand-in producer activation for the mask
     wd, bd = mod.weight.detach().float().to(dev), mod.bias.detach().float().to(dev)
     errs = {}
     for split in (False, True):
         yb = torch.full((b, oh, ow, cout), float("nan"), device=dev)
+        dxb = torch.full((b, h, w, cin), float("nan"), device=dev)
+        dxm = torch.full((b, h, w, cin), float("nan"), device=dev)
         old = gconv.SPLIT_BF16
         gconv.SPLIT_BF16 = split
         try:
             layer.forward(wd, bd, gconv.View(xb), gconv.View(yb), gconv.EPI_BIAS_RELU)
+            layer.backward_data(wd, gconv.View(gb), gconv.View(dxb))
+            layer.backward_data(wd, gconv.View(gb), gconv.View(dxm), relu_src=mb)
         finally:
             gconv.SPLIT_BF16 = old
         got = yb.permute(0, 3, 1, 2).double().cpu()
-        assert torch.isfinite(got).all()
-        errs[split] = float((got - y_ref).abs().max() / y_ref.abs().max())
-    assert errs[True] < 2e-5, errs
-    assert errs[True] <= 4.0 * errs[False] + 1e-7, errs
+        gdx = dxb.permute(0, 3, 1, 2).double().cpu()
+        gdm = dxm.permute(0, 3, 1, 2).double().cpu()
+        assert torch.isfinite(got).all() and torch.isfinite(gdx).all() and torch.isfinite(gdm).all()
+        errs[split] = (float((got - y_ref).abs().max() / y_ref.abs().max()), float((gdx - x.grad).abs().max() / x.grad.abs().max()),
+                       float((gdm - x.grad * (x.detach() > 0.25)).abs().max() / x.grad.abs().max()))
+    for e_split, e_exact in zip(errs[True], errs[False]):
+        assert e_split < 2e-5, errs
+        assert e_split <= 4.0 * e_exact + 1e-7, errs
+
+
+def test_split_bf16_data_gradient_mask_pass_and_channel_slice(dev):
+    """The split data gradient writes a channel slice of a wider buffer and exempts `mask_pass` channels from the ReLU mask exactly as
+    the exact kernel does (the 96-channel concat buffer of RoadMapBoxesMergingCNN: components.py:159)."""
+    from driving_dirty_amd import gconv, synth
+    b, h, w, cin, cout = 1, 9, 64, 96, 64
+    layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+    oh, ow = layer.out_hw(h, w)
+    wd = synth.hash_uniform((cin, cout, 7, 7), synth.key_salt("mpw"), -0.05, 0.05).to(dev)
+    g = synth.hash_uniform((b, oh, ow, cout), synth.key_salt("mpg")).to(dev)
+    msk = synth.hash_uniform((b, h, w, 128), synth.key_salt("mpm")).to(dev)
+    outs = []
+    for split in (False, True):
+        dx = torch.zeros(b, h, w, 128, device=dev)
+        old = gconv.SPLIT_BF16
+        gconv.SPLIT_BF16 = split
+        try:
+            layer.backward_data(wd, gconv.View(g), gconv.View(dx, 16, cin), relu_src=msk, mask_pass=(48, 80))
+        finally:
+            gconv.SPLIT_BF16 = old
+        outs.append(dx)
+    a, c = outs
+    assert float(a[..., :16].abs().max()) == 0 and float(c[..., :16].abs().max()) == 0 and float(c[..., 112:].abs().max()) == 0
+    assert torch.equal(a == 0, c == 0)                       # the same elements masked
+    assert float((a - c).abs().max() / a.abs().max()) < 2e-5
 
 
 def test_split_bf16_pieces_are_exact(dev):

@@ -60,7 +60,7 @@ def main():
         P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
         t_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(x), P(xs), C.byref(d), st), "in"), a.iters)
         t_pk = timed(lambda: _lib.check(lib.dd_dconv_split_pack(P(w), P(pk), C.byref(d), 0, 49, cout * 49, 1, cout, cin, st), "pk"), a.iters)
-        t_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(xs), P(pk), P(bias), P(y1), C.byref(d), gconv.EPI_BIAS_RELU, st), "k"), a.iters)
+        t_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(xs), P(pk), P(bias), None, P(y1), C.byref(d), gconv.EPI_BIAS_RELU, st), "k"), a.iters)
         flop = 2.0 * a.batch * hw * hw * 49 * cin * cout
         diff = float((y1 - y0).abs().max() / y0.abs().max())
         res[name] = {"exact_ms": round(t_exact, 3), "split_total_ms": round(t_split_all, 3), "split_kernel_ms": round(t_k, 3),
