@@ -61,11 +61,31 @@ def main():
         t_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(x), P(xs), C.byref(d), st), "in"), a.iters)
         t_pk = timed(lambda: _lib.check(lib.dd_dconv_split_pack(P(w), P(pk), C.byref(d), 0, 49, cout * 49, 1, cout, cin, st), "pk"), a.iters)
         t_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(xs), P(pk), P(bias), None, P(y1), C.byref(d), gconv.EPI_BIAS_RELU, st), "k"), a.iters)
+        # the data gradient: dx = dilated conv of dy (ReLU mask of the producer fused)
+        g = torch.randn(a.batch, oh, ow, cout, device=dev, generator=g0) if False else torch.rand(a.batch, oh, ow, cout, device=dev) - 0.5
+        dx0 = torch.empty(a.batch, hw, hw, cin, device=dev)
+        dx1 = torch.empty_like(dx0)
+
+        def rund(split, dx):
+            gconv.SPLIT_BF16 = split
+            layer.backward_data(w, gconv.View(g), gconv.View(dx), relu_src=x)
+        td_exact = timed(lambda: rund(False, dx0), a.iters)
+        td_split_all = timed(lambda: rund(True, dx1), a.iters)
+        dd = gconv._desc(a.batch, gconv.View(g), gconv.View(dx1), cout, cin, (7, 7), (1, 1), (7, 7), (0, 0))
+        gs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(dd)), device=dev, dtype=torch.uint8)
+        pkd = torch.empty(lib.dd_dconv_split_packed_bytes(C.byref(dd)), device=dev, dtype=torch.uint8)
+        _lib.check(lib.dd_dconv_split_input(P(g), P(gs), C.byref(dd), st), "in")
+        _lib.check(lib.dd_dconv_split_pack(P(w), P(pkd), C.byref(dd), 0, cout * 49, 49, 0, cin, cout, st), "pk")
+        td_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(g), P(gs), C.byref(dd), st), "in"), a.iters)
+        td_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(gs), P(pkd), None, P(x), P(dx1), C.byref(dd), gconv.EPI_RELU_MASK, st), "k"), a.iters)
+        ddiff = float((dx1 - dx0).abs().max() / dx0.abs().max())
         flop = 2.0 * a.batch * hw * hw * 49 * cin * cout
         diff = float((y1 - y0).abs().max() / y0.abs().max())
         res[name] = {"exact_ms": round(t_exact, 3), "split_total_ms": round(t_split_all, 3), "split_kernel_ms": round(t_k, 3),
                      "split_input_ms": round(t_in, 3), "split_pack_ms": round(t_pk, 3), "exact_TF": round(flop / t_exact / 1e9, 1),
-                     "split_kernel_TF_equiv": round(flop / t_k / 1e9, 1), "max_diff_of_peak": diff}
+                     "split_kernel_TF_equiv": round(flop / t_k / 1e9, 1), "max_diff_of_peak": diff,
+                     "dgrad_exact_ms": round(td_exact, 3), "dgrad_split_total_ms": round(td_split_all, 3), "dgrad_split_kernel_ms": round(td_k, 3),
+                     "dgrad_split_input_ms": round(td_in, 3), "dgrad_split_kernel_TF_equiv": round(flop / td_k / 1e9, 1), "dgrad_max_diff_of_peak": ddiff}
     gconv.SPLIT_BF16 = False
     print(json.dumps(res, indent=1))
 
