@@ -519,6 +519,149 @@ __global__ __launch_bounds__(NW * 64) void dconv_sgfwd_kernel(const char* __rest
   }
 }
 
+// =====================================================================================================================
+// The WEIGHT GRADIENT of the same layers with split products:
+//     dW[c][o][ky][kx] = sum over images and input pixels (iy, ix) of  x[iy][ix][c] * g[iy + D*ky][ix + D*kx][o]
+// GEMM per tap: M = Cin, N = Cout, K = pixels -- both operands need PIXELS along k, eight consecutive ones per lane.  They come out of
+// the same [pixel][plane][16 channels] images the forward and the data gradient use (xs of the layer's input, gs of dL/dy: no further
+// split pass) through the hardware transpose read ds_read_b64_tr_b16: per 16-lane group a block of 4 pixels x 16 channels, delivered
+// channel-major, so a tap's pixel shift is just a row offset of the read.  As dconv_wgrad_kernel a workgroup owns ONE tap row ky and a
+// range of input rows; per step a 32-pixel piece of an x row (all chunks) and the matching 74-pixel piece of the g row iy + D*ky sit in
+// LDS (two buffers, filled by LDS-DMA one step ahead); wave w < K owns tap column kx = w and its (Cin/32) x (Cout/32) accumulator tiles
+// (the eighth wave only helps with the fills); partials per workgroup, fixed-order fp64 second stage (deterministic).
+typedef __attribute__((ext_vector_type(4))) short sp_s16x4;
+typedef sp_s16x4 __attribute__((address_space(3))) * sp_lds_s16x4_ptr;
+__device__ __forceinline__ sp_s16x4 sp_tr_read(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((sp_lds_s16x4_ptr)p); }
+__device__ __forceinline__ bf16x8 sp_join(sp_s16x4 a, sp_s16x4 b) {
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int C, int O>
+struct SwGeom {
+  static constexpr int K = 7, D = 7, XT = 32, GT = XT + D * (K - 1);
+  static constexpr int NCX = C / 16, NCO = O / 16, MT = C / 32, NTO = O / 32, TPW = MT * NTO;
+  static constexpr int PX = (XT * SP_PXB + 1023) / 1024, PG = (GT * SP_PXB + 1023) / 1024;      // 1 KB DMA pieces per chunk piece
+  static constexpr int RX = PX * 1024, RG = PG * 1024;                                          // LDS bytes per chunk region
+  static constexpr int BUF = NCX * RX + NCO * RG;
+  static constexpr int NP = NCX * PX + NCO * PG;
+  static_assert(C % 32 == 0 && O % 32 == 0 && 2 * BUF <= 160 * 1024, "channel tiles / LDS");
+};
+
+template <int C, int O>
+__global__ __launch_bounds__(SP_THREADS) void dconv_swgrad_kernel(const char* __restrict__ xs, const char* __restrict__ gs,
+                                                                  float* __restrict__ part, int wg_per_ky, int B, int H, int W, int gh, int gw) {
+  using G = SwGeom<C, O>;
+  constexpr int K = G::K, D = G::D;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * G::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ky = blockIdx.x / wg_per_ky, wl = blockIdx.x - ky * wg_per_ky;
+  const long rows = (long)B * H;
+  const long r0 = rows * wl / wg_per_ky, r1 = rows * (wl + 1) / wg_per_ky;
+  const int nxt = (W + G::XT - 1) / G::XT;
+  const long nsteps = (r1 - r0) * nxt;
+
+  // transpose-read coordinates of this lane: group (k half, channel half), row q and element quad p inside the 4 x 16 block
+  const int grp = lane >> 4, e = lane & 15, q = e >> 2, p = e & 3;
+  const int hk = grp >> 1, half = grp & 1;
+  const int a_lane = half * G::RX + (8 * hk + q) * SP_PXB + 8 * p;
+  const int b_lane = G::NCX * G::RX + half * G::RG + (8 * hk + q + D * wave) * SP_PXB + 8 * p;      // tap column kx = wave
+
+  f32x16 acc[G::TPW];
+#pragma unroll
+  for (int t = 0; t < G::TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto fill = [&](int buf, long s) {
+    const long row = r0 + s / nxt;
+    const int xt = (int)(s % nxt), b = (int)(row / H), iy = (int)(row - (long)b * H);
+    const int x0 = xt * G::XT, gy = iy + D * ky;
+    const int xlen = min(G::XT, W - x0) * SP_PXB, glen = max(0, min(G::GT, gw - x0)) * SP_PXB;
+    const char* xrow = xs + ((long)(b * H + iy) * G::NCX * W + x0) * SP_PXB;
+    const char* grow = gs + ((long)(b * gh + gy) * G::NCO * gw + x0) * SP_PXB;
+    char* base = lds + buf * G::BUF;
+#pragma unroll
+    for (int i = 0; i < (G::NP + 7) / 8; ++i) {
+      const int j = wave + 8 * i;
+      if (j < G::NCX * G::PX) {
+        const int c = j / G::PX, pc = j - c * G::PX;
+        const __amdgpu_buffer_rsrc_t r = dd_rsrc(xrow + (long)c * W * SP_PXB, xlen);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(base + c * G::RX + pc * 1024), 16, lane * 16, pc * 1024, 0, 0);
+      } else if (j < G::NP) {
+        const int jj = j - G::NCX * G::PX, c = jj / G::PG, pc = jj - c * G::PG;
+        const __amdgpu_buffer_rsrc_t r = dd_rsrc(grow + (long)c * gw * SP_PXB, glen);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(base + G::NCX * G::RX + c * G::RG + pc * 1024), 16, lane * 16,
+                                                 pc * 1024, 0, 0);
+      }
+    }
+  };
+
+  if (nsteps > 0) fill(0, 0);
+  sp_barrier();
+  int par = 0;
+  for (long s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) fill(par ^ 1, s + 1);
+    if (wave < K) {
+      const char* lb = lds + par * G::BUF;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {      // the piece's 32 pixels = two k16 blocks
+        bf16x8 A[G::MT][3], Bv[G::NTO][3];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const char* a = lb + a_lane + mt * (2 * G::RX) + (16 * kb) * SP_PXB + pl * 32;
+            A[mt][pl] = sp_join(sp_tr_read(a), sp_tr_read(a + 4 * SP_PXB));
+          }
+#pragma unroll
+        for (int nt = 0; nt < G::NTO; ++nt)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const char* bq = lb + b_lane + nt * (2 * G::RG) + (16 * kb) * SP_PXB + pl * 32;
+            Bv[nt][pl] = sp_join(sp_tr_read(bq), sp_tr_read(bq + 4 * SP_PXB));
+          }
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < G::NTO; ++nt) {
+            f32x16& c = acc[mt * G::NTO + nt];
+            c = SP_MFMA(A[mt][2], Bv[nt][0], c);      // hi = [0], mid = [1], lo = [2]; smallest products first
+            c = SP_MFMA(A[mt][0], Bv[nt][2], c);
+            c = SP_MFMA(A[mt][1], Bv[nt][1], c);
+            c = SP_MFMA(A[mt][1], Bv[nt][0], c);
+            c = SP_MFMA(A[mt][0], Bv[nt][1], c);
+            c = SP_MFMA(A[mt][0], Bv[nt][0], c);
+          }
+      }
+    }
+    sp_barrier();
+    par ^= 1;
+  }
+  if (wave < K) {
+#pragma unroll
+    for (int t = 0; t < G::TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[((((long)blockIdx.x * K + wave) * G::TPW + t) * 16 + r) * 64 + lane] = acc[t][r];
+  }
+}
+
+// One block = one accumulator tile of one tap (1024 threads = 16 registers x 64 lanes): sums the tap row's workgroups in fp64, in a fixed
+// order, and scatters to the ConvTranspose2d weight layout [Cin][Cout][K][K].
+template <int C, int O>
+__global__ __launch_bounds__(1024) void dconv_swgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int wg_per_ky, int accumulate) {
+  using G = SwGeom<C, O>;
+  constexpr int K = G::K;
+  const int t = blockIdx.x % G::TPW, kx = (blockIdx.x / G::TPW) % K, ky = blockIdx.x / (G::TPW * K);
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int w = 0; w < wg_per_ky; ++w) s += (double)part[((((long)(ky * wg_per_ky + w) * K + kx) * G::TPW + t) * 16 + r) * 64 + lane];
+  const int mt = t / G::NTO, nt = t - mt * G::NTO;
+  const int c = mt * 32 + dd_acc_row(r, lane), o = nt * 32 + (lane & 31);
+  const long wi = (((long)c * O + o) * K + ky) * K + kx;
+  dw[wi] = accumulate ? dw[wi] + (float)s : (float)s;
+}
+
 bool sp_common_ok(const dd_gconv_desc* d) {
   if (!dd_dconv_desc_ok(d)) return false;
   if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7) return false;
@@ -587,6 +730,52 @@ int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, in
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed,
                      d->cin / 16, NT, 7, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real);
   DD_LAUNCH_CHECK("dconv_split_pack");
+  return 0;
+}
+
+/* fp32 NHWC rows -> the three-plane bf16 image, without a layer descriptor: `rows` image rows of `w` pixels, channels [coff, coff + c)
+ * of `cstore`; xs = rows * (c / 16) * w * 112 bytes.  (dd_dconv_split_input is this for a descriptor's input.) */
+int dd_dconv_split_rows(const float* x, void* xs, int64_t rows, int32_t w, int32_t cstore, int32_t coff, int32_t c, void* stream) {
+  DD_REQUIRE(x && xs && rows > 0 && w > 0 && c > 0 && c % 16 == 0 && coff >= 0 && coff % 4 == 0 && cstore % 4 == 0 && coff + c <= cstore,
+             DD_ERR_BAD_ARG, "dconv_split_rows: bad argument");
+  DD_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)xs & 15) == 0, DD_ERR_BAD_ARG, "dconv_split_rows: 16-byte alignment");
+  const long total = rows * (c / 16) * w * 2;
+  hipLaunchKernelGGL(split_input_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 16)), dim3(256), 0, (hipStream_t)stream, x,
+                     (char*)xs, (long)rows, w, cstore, coff, c / 16);
+  DD_LAUNCH_CHECK("dconv_split_rows");
+  return 0;
+}
+
+int32_t dd_dconv_wgrad_split_supported(int32_t k, int32_t dil, int32_t cin, int32_t cout) {
+  return (k == 7 && dil == 7 && ((cin == 96 && cout == 64) || (cin == 64 && cout == 32))) ? 1 : 0;
+}
+
+static int sp_wg_per_ky() { return max(1, dd_cu_budget_internal() / 7); }
+
+int64_t dd_dconv_wgrad_split_workspace_bytes(int32_t cin, int32_t cout) {
+  if (!dd_dconv_wgrad_split_supported(7, 7, cin, cout)) return dd_fail(DD_ERR_UNSUPPORTED, "dconv_wgrad_split_workspace_bytes: unsupported layer"), -1;
+  return (int64_t)sp_wg_per_ky() * 7 * 7 * (cin / 32) * (cout / 32) * 16 * 64 * 4;
+}
+
+/* xs: split image of the layer's input x [batch, h, w, cin]; gs: split image of g = dL/dy [batch, gh, gw, cout] (gh >= h + 42,
+ * gw >= w + 42); dw [cin][cout][7][7] (ConvTranspose2d's layout), accumulate != 0 adds. */
+int dd_dconv_wgrad_split(const void* xs, const void* gs, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t gh, int32_t gw,
+                         int32_t cout, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  DD_REQUIRE(dd_dconv_wgrad_split_supported(7, 7, cin, cout), DD_ERR_UNSUPPORTED, "dconv_wgrad_split: unsupported layer %d -> %d", cin, cout);
+  DD_REQUIRE(xs && gs && dw && workspace, DD_ERR_BAD_ARG, "dconv_wgrad_split: NULL pointer");
+  DD_REQUIRE(batch > 0 && h > 0 && w > 0 && gh >= h + 42 && gw >= w + 42, DD_ERR_BAD_ARG, "dconv_wgrad_split: sizes");
+  const int wg = sp_wg_per_ky();
+  DD_REQUIRE(workspace_bytes >= (int64_t)wg * 7 * 7 * (cin / 32) * (cout / 32) * 16 * 64 * 4, DD_ERR_WORKSPACE, "dconv_wgrad_split: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+#define SW_LAUNCH(CC, OO)                                                                                                                  \
+  do {                                                                                                                                     \
+    hipLaunchKernelGGL((dconv_swgrad_kernel<CC, OO>), dim3(wg * 7), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)gs, (float*)workspace, wg, \
+                       batch, h, w, gh, gw);                                                                                               \
+    hipLaunchKernelGGL((dconv_swgrad_reduce<CC, OO>), dim3(7 * 7 * SwGeom<CC, OO>::TPW), dim3(1024), 0, st, (const float*)workspace, dw, wg, accumulate); \
+  } while (0)
+  if (cin == 96) SW_LAUNCH(96, 64); else SW_LAUNCH(64, 32);
+#undef SW_LAUNCH
+  DD_LAUNCH_CHECK("dconv_wgrad_split");
   return 0;
 }
 

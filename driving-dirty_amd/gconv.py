@@ -109,6 +109,16 @@ PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
 SPLIT_BF16 = os.environ.get("DD_DCONV_SPLIT", "0") == "1"
 
 
+def split_rows(view):
+    """The three-plane bf16 image (csrc/dconv_split.hip) of the channels of a whole-buffer View: [B][H][chans / 16][W][112 B]."""
+    if not (_whole(view) and view.chans % 16 == 0):
+        raise _lib.HotpathError("split_rows: a whole-buffer View with a multiple of 16 channels")
+    b, h, w, cs = view.buf.shape
+    xs = torch.empty(b * h * (view.chans // 16) * w * 112, device=view.buf.device, dtype=torch.uint8)
+    check(_lib.lib().dd_dconv_split_rows(_p(_chk(view.buf, "x")), _p(xs), b * h, w, cs, view.coff, view.chans, _stream()), "dd_dconv_split_rows")
+    return xs
+
+
 def _whole(v):
     """The View covers every pixel of its buffer (the kernels that take whole-buffer dimensions must not be handed a window)."""
     return v.off_h == 0 and v.off_w == 0 and v.h == v.buf.shape[1] and v.w == v.buf.shape[2]
@@ -118,17 +128,19 @@ def _dconv_ok(d):
     return DCONV and bool(_lib.lib().dd_dconv_supported(C.byref(d)))
 
 
-def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real):
-    """pack + launch on the dilated kernel when the descriptor qualifies, on the generic one otherwise"""
+def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real, xs=None):
+    """pack + launch on the dilated kernel when the descriptor qualifies, on the generic one otherwise.  Returns the split image of
+    x when the split-product path ran (``xs``: one a caller already holds), None otherwise."""
     lib = _lib.lib()
     if SPLIT_BF16 and lib.dd_dconv_split_supported(C.byref(d)) and (
             (d.pad_h > 0 and mask is None and epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU)) or (d.pad_h == 0 and epi in (EPI_NONE, EPI_RELU_MASK))):
-        xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=x.device, dtype=torch.uint8)
         packed = torch.empty(lib.dd_dconv_split_packed_bytes(C.byref(d)), device=x.device, dtype=torch.uint8)
-        check(lib.dd_dconv_split_input(_p(x), _p(xs), C.byref(d), _stream()), "dd_dconv_split_input")
+        if xs is None:
+            xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=x.device, dtype=torch.uint8)
+            check(lib.dd_dconv_split_input(_p(x), _p(xs), C.byref(d), _stream()), "dd_dconv_split_input")
         check(lib.dd_dconv_split_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_split_pack")
         check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
-        return
+        return xs
     if _dconv_ok(d):
         n = lib.dd_dconv_packed_floats(C.byref(d))
         packed = torch.empty(n, device=weight.device, dtype=torch.float32)
@@ -172,7 +184,9 @@ class Layer:
         return tuple(self.dil[i] * (self.k[i] - 1) - self.pad[i] for i in range(2))
 
     # ---- forward: writes dst (View) from src (View)
-    def forward(self, weight, bias, src, dst, epilogue, mask=None):
+    def forward(self, weight, bias, src, dst, epilogue, mask=None, keep=None):
+        """``keep`` (a dict): receives ``keep['xs']``, the split image of the input, when the split-product experiment ran -- the
+        weight gradient of the same layer takes it back (``backward_weight(xs=...)``) instead of splitting x again."""
         b = src.buf.shape[0]
         cs = src.chans if src.chans % 4 == 0 else self.cin_store
         _chk(weight, "weight")
@@ -187,10 +201,12 @@ class Layer:
                 _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
         else:
             d = _desc(b, src, dst, cs, self.cout, self.k, (1, 1), self.dil, self._flip_pad())
-            _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.T, self.cout * self.T, True, self.cout, self.cin)
+            xs = _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.T, self.cout * self.T, True, self.cout, self.cin)
+            if keep is not None and xs is not None:
+                keep["xs"] = xs
 
     # ---- data gradient: dsrc (View with the input's geometry, >= 4-aligned channels) from ddst (View of dy)
-    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0)):
+    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0), gs=None):
         """dsrc.buf[..., dsrc.coff : +cin] = dL/dx (x masked by ``relu_src > 0`` when given; channels
         [mask_pass[0], mask_pass[1]) of the dsrc buffer are exempt: a concat slice that is not a ReLU output)."""
         b = ddst.buf.shape[0]
@@ -201,7 +217,7 @@ class Layer:
             # the dilated kernel takes up to 96 output channels in one launch (three column tiles per wave)
             d = _desc(b, ddst, dsrc, cos, cin_out, self.k, (1, 1), self.dil, self.pad, mask_pass=mask_pass)
             if _dconv_ok(d):
-                _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout)
+                _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout, xs=gs)
                 return
         if (not self.transposed and self.stride != (1, 1) and self.dil == (1, 1) and self.pad == (0, 0) and cin_out <= 64
                 and PHASED_DGRAD):
@@ -251,7 +267,14 @@ class Layer:
                     dsrc.buf[:, dsrc.off_h + ry:dsrc.off_h + dsrc.h:sh, dsrc.off_w + rx:dsrc.off_w + dsrc.w:sw, dsrc.coff:dsrc.coff + self.cin] = 0
 
     # ---- weight (+bias) gradient
-    def backward_weight(self, src, ddst, want_bias=True):
+    def split_wgrad_ok(self, src, ddst):
+        """The split-product weight gradient (csrc/dconv_split.hip) serves this call: the experiment is on, a k7 d7 layer it is built
+        for, whole-buffer Views."""
+        return (SPLIT_BF16 and self.transposed and not self.k2s2 and self.k[0] == self.k[1] and self.dil[0] == self.dil[1] and self.pad == (0, 0)
+                and src.chans == self.cin and ddst.chans == self.cout and _whole(src) and _whole(ddst)
+                and bool(_lib.lib().dd_dconv_wgrad_split_supported(self.k[0], self.dil[0], self.cin, self.cout)))
+
+    def backward_weight(self, src, ddst, want_bias=True, xs=None, gs=None):
         b = src.buf.shape[0]
         dev = src.buf.device
         cs = src.chans if src.chans % 4 == 0 else self.cin_store
@@ -268,6 +291,20 @@ class Layer:
             for ph in range(4):
                 d = _desc(b, src, ddst, cs, self.cout, (1, 1), out_hw=(ih, iw), ostride=(2, 2), ooff=(ph // 2, ph % 2))
                 _wgrad(src.buf, ddst.buf, dw, db, d, ph, 4, self.cout * 4, False, self.cout, self.cin, 2 if ph > 0 else 0)
+        elif self.split_wgrad_ok(src, ddst):
+            # EXPERIMENT: both operands as three bf16 planes, six bf16 x bf16 products per fp32 product (csrc/dconv_split.hip); the
+            # split images of x (from the forward) and of dL/dy (from the data gradient) are taken over when the caller holds them
+            lib = _lib.lib()
+            xs = split_rows(src) if xs is None else xs
+            gs = split_rows(ddst) if gs is None else gs
+            nbytes = lib.dd_dconv_wgrad_split_workspace_bytes(self.cin, self.cout)
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            _, ih, iw, _ = src.buf.shape
+            _, gh, gw, _ = ddst.buf.shape
+            check(lib.dd_dconv_wgrad_split(_p(xs), _p(gs), _p(dw), b, ih, iw, self.cin, gh, gw, self.cout, 0, _p(ws), nbytes, _stream()),
+                  "dd_dconv_wgrad_split")
+            if want_bias:
+                channel_sum(ddst, db)
         elif (DCONV and self.k[0] == self.k[1] and self.dil[0] == self.dil[1] and self.pad == (0, 0) and src.chans == self.cin
               and ddst.chans == self.cout and _whole(src) and _whole(ddst)
               and _lib.lib().dd_dconv_wgrad_supported(self.k[0], self.dil[0], self.cin, self.cout)):

@@ -14,6 +14,7 @@ import torch
 from . import _lib, ops
 from ._lib import check
 from .gconv import EPI_BIAS, EPI_BIAS_RELU, Layer, View, _p, _stream, add, copy_channels, view_to_nhwc4
+from .gconv import split_rows as gconv_split_rows
 
 
 # Test hook: when set to a dict, the nodes below leave their ReLU outputs (NHWC) in it so that a checker can replay the
@@ -223,12 +224,16 @@ class MergeFn(torch.autograd.Function):
             assert cls.RM2.out_hw(rh, rw) == (ch, cw)
             cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
         acts = [cat]
+        split_x = []                                 # split-product experiment (gconv.SPLIT_BF16): each layer input's bf16 planes, kept for its weight gradient
         for layer, (w, bias) in zip(ups, p_up):
             src = acts[-1]
             oh, ow = layer.out_hw(src.shape[1], src.shape[2])
             dst = _empty((b, oh, ow, layer.cout), dev)
-            layer.forward(w, bias, View(src), View(dst), EPI_BIAS_RELU)
+            keep = {}
+            layer.forward(w, bias, View(src), View(dst), EPI_BIAS_RELU, keep=keep)
+            split_x.append(keep.get("xs"))
             acts.append(dst)
+        ctx.split_x = split_x
         u = acts[-1]
         probs = _empty((b, 2 * u.shape[1], 2 * u.shape[2]), dev)
         check(_lib.lib().dd_deconv2x2_c1_fwd(_p(u), _p(p_last[0]), _p(p_last[1]), _p(probs), b, u.shape[1], u.shape[2], 8,
@@ -261,11 +266,14 @@ class MergeFn(torch.autograd.Function):
         g_up = []
         for i in range(nup - 1, -1, -1):
             layer, src = ups[i], acts[i]
-            g_up.append(layer.backward_weight(View(src), View(g)))
+            # split-product experiment: dL/dy is split into its bf16 planes ONCE for the layer's weight and data gradient, the input's
+            # planes come from the forward
+            gs = gconv_split_rows(View(g)) if layer.split_wgrad_ok(View(src), View(g)) else None
+            g_up.append(layer.backward_weight(View(src), View(g), xs=ctx.split_x[i] if gs is not None else None, gs=gs))
             gsrc = _empty(src.shape, dev)
             # masks with the producer's ReLU output; in the concat buffer (i == 0) only the slices this node's own ReLUs
             # wrote (ss_deconv 0:32, rm_conv_2 64:96): the spatial-map slice 32:64 is an external input
-            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0))
+            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0), gs=gs)
             g = gsrc
         g_up.reverse()
         gcat = g                                                                 # [B,256,256,64|96]; slices 0:32 / 64:96 ReLU-masked

@@ -353,6 +353,15 @@ int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, in
                         int32_t n_real, int32_t c_real, void* stream);
 int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
                        int32_t epilogue, void* stream);
+/* ... and the WEIGHT GRADIENT of the 96->64 / 64->32 layers from the same split images (xs of the layer's input, gs of dL/dy: produced
+ * by dd_dconv_split_input or, without a descriptor, dd_dconv_split_rows -- `rows` image rows of `w` pixels, channels [coff, coff + c) of
+ * `cstore`, rows * (c / 16) * w * 112 bytes): dw [cin][cout][7][7], per-workgroup partials in `workspace`, fixed-order fp64 second
+ * stage; same contract as dd_dconv_wgrad. */
+int dd_dconv_split_rows(const float* x, void* xs, int64_t rows, int32_t w, int32_t cstore, int32_t coff, int32_t c, void* stream);
+int32_t dd_dconv_wgrad_split_supported(int32_t k, int32_t dil, int32_t cin, int32_t cout);
+int64_t dd_dconv_wgrad_split_workspace_bytes(int32_t cin, int32_t cout);
+int dd_dconv_wgrad_split(const void* xs, const void* gs, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t gh, int32_t gw,
+                         int32_t cout, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Weight gradient of the same layers (ConvTranspose2d stride 1, dilation `dil`, kernel k x k, no padding):
  *   dw[c][o][ky][kx] (IOHW, PyTorch's layout) (+)= sum over images and pixels of x[iy][ix][c] * g[iy + dil*ky][ix + dil*kx][o]

@@ -441,8 +441,8 @@ _SPLIT_CASES = [
 
 @pytest.mark.parametrize("name,cin,cout,shape", _SPLIT_CASES, ids=[c[0] for c in _SPLIT_CASES])
 def test_split_bf16_forward_and_data_gradient_against_fp64_and_the_exact_kernels(dev, name, cin, cout, shape):
-    """csrc/dconv_split.hip (off by default): the k7 d7 transposed forward and its data gradient (with and without the fused ReLU mask
-    of the producer) with every fp32 product as six bf16 x bf16 products on the bf16 matrix pipe.  Held to the exact kernels' own
+    """csrc/dconv_split.hip (off by default): the k7 d7 transposed forward, its data gradient (with and without the fused ReLU mask
+    of the producer) and its weight gradient with every fp32 product as six bf16 x bf16 products on the bf16 matrix pipe.  Held to the exact kernels' own
     bound -- 2e-5 of peak against fp64 torch -- and compared with the exact fp32 kernels on the same operands (the split path must
     not be the worse one by more than 4x)."""
     from torch import nn
@@ -471,14 +471,19 @@ def test_split_bf16_forward_and_data_gradient_against_fp64_and_the_exact_kernels
             layer.forward(wd, bd, gconv.View(xb), gconv.View(yb), gconv.EPI_BIAS_RELU)
             layer.backward_data(wd, gconv.View(gb), gconv.View(dxb))
             layer.backward_data(wd, gconv.View(gb), gconv.View(dxm), relu_src=mb)
+            assert layer.split_wgrad_ok(gconv.View(xb), gconv.View(gb)) == (split and (cin, cout) in ((96, 64), (64, 32)))
+            dw, db = layer.backward_weight(gconv.View(xb), gconv.View(gb))
         finally:
             gconv.SPLIT_BF16 = old
         got = yb.permute(0, 3, 1, 2).double().cpu()
         gdx = dxb.permute(0, 3, 1, 2).double().cpu()
         gdm = dxm.permute(0, 3, 1, 2).double().cpu()
         assert torch.isfinite(got).all() and torch.isfinite(gdx).all() and torch.isfinite(gdm).all()
+        gw_ref = mod.weight.grad
         errs[split] = (float((got - y_ref).abs().max() / y_ref.abs().max()), float((gdx - x.grad).abs().max() / x.grad.abs().max()),
-                       float((gdm - x.grad * (x.detach() > 0.25)).abs().max() / x.grad.abs().max()))
+                       float((gdm - x.grad * (x.detach() > 0.25)).abs().max() / x.grad.abs().max()),
+                       float((dw.double().cpu() - gw_ref).abs().max() / gw_ref.abs().max()),
+                       float((db.double().cpu() - mod.bias.grad).abs().max() / mod.bias.grad.abs().max()))
     for e_split, e_exact in zip(errs[True], errs[False]):
         assert e_split < 2e-5, errs
         assert e_split <= 4.0 * e_exact + 1e-7, errs
