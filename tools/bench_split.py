@@ -79,13 +79,29 @@ def main():
         td_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(g), P(gs), C.byref(dd), st), "in"), a.iters)
         td_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(gs), P(pkd), None, P(x), P(dx1), C.byref(dd), gconv.EPI_RELU_MASK, st), "k"), a.iters)
         ddiff = float((dx1 - dx0).abs().max() / dx0.abs().max())
+        # the weight gradient from the two split images (none of the split passes is repeated: xs comes from the forward, gs from the data gradient)
+        def runw(split):
+            gconv.SPLIT_BF16 = split
+            return layer.backward_weight(gconv.View(x), gconv.View(g))
+        tw_exact = timed(lambda: runw(False), a.iters)
+        dw0 = runw(False)[0]
+        xs_c, gs_c = gconv.split_rows(gconv.View(x)), gconv.split_rows(gconv.View(g))
+
+        def runw_split():
+            gconv.SPLIT_BF16 = True
+            return layer.backward_weight(gconv.View(x), gconv.View(g), xs=xs_c, gs=gs_c)
+        tw_split = timed(runw_split, a.iters)
+        dw1 = runw_split()[0]
+        wdiff = float((dw1 - dw0).abs().max() / dw0.abs().max())
         flop = 2.0 * a.batch * hw * hw * 49 * cin * cout
         diff = float((y1 - y0).abs().max() / y0.abs().max())
         res[name] = {"exact_ms": round(t_exact, 3), "split_total_ms": round(t_split_all, 3), "split_kernel_ms": round(t_k, 3),
                      "split_input_ms": round(t_in, 3), "split_pack_ms": round(t_pk, 3), "exact_TF": round(flop / t_exact / 1e9, 1),
                      "split_kernel_TF_equiv": round(flop / t_k / 1e9, 1), "max_diff_of_peak": diff,
                      "dgrad_exact_ms": round(td_exact, 3), "dgrad_split_total_ms": round(td_split_all, 3), "dgrad_split_kernel_ms": round(td_k, 3),
-                     "dgrad_split_input_ms": round(td_in, 3), "dgrad_split_kernel_TF_equiv": round(flop / td_k / 1e9, 1), "dgrad_max_diff_of_peak": ddiff}
+                     "dgrad_split_input_ms": round(td_in, 3), "dgrad_split_kernel_TF_equiv": round(flop / td_k / 1e9, 1), "dgrad_max_diff_of_peak": ddiff,
+                     "wgrad_exact_ms": round(tw_exact, 3), "wgrad_split_ms_planes_given": round(tw_split, 3), "wgrad_split_TF_equiv": round(flop / tw_split / 1e9, 1),
+                     "wgrad_max_diff_of_peak": wdiff}
     gconv.SPLIT_BF16 = False
     print(json.dumps(res, indent=1))
 
