@@ -417,18 +417,20 @@ def other_configs(a, dev, steps=10, warmup=3):
         res[names[c]].update(algorithmic_TFLOPs=round(algo / (ms * 1e-3) / 1e12, 1),
                              **{("frac_bf16_mfma_peak" if c == 5 else "frac_fp32_mfma_peak"): round(algo / (ms * 1e-3) / 1e12 / peak, 4)})
         if c == 3:
-            # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with the forwards of up_conv_1 / up_conv_2 taking every fp32
+            # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with up_conv_1 / up_conv_2 taking every fp32
             # product as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulate) on the bf16 matrix pipe
             from driving_dirty_amd import gconv
             watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 96 and _desc(x[5]).pad_h > 0),
                      "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 32 and _desc(x[5]).pad_h > 0),
                      "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96 and _desc(x[5]).pad_h == 0),
                      "up_conv_2_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 32 and _desc(x[5]).cout == 64 and _desc(x[5]).pad_h == 0),
-                     "split_input_pass": ("dd_dconv_split_input", lambda *x: True)}
+                     "up_conv_1_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 96),
+                     "split_input_pass": ("dd_dconv_split_input", lambda *x: True), "split_rows_pass": ("dd_dconv_split_rows", lambda *x: True)}
             gconv.SPLIT_BF16 = True
             try:
                 run("config3_bbox_split_products_bs32", cfg["model"], cfg["batch"], cfg["per_gpu_batch"],
-                    {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forwards of up_conv_1 / up_conv_2; everything else exact fp32"}, watch, "3s")
+                    {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forwards and data gradients of up_conv_1 / up_conv_2 and the weight gradient of "
+                              "up_conv_1; everything else exact fp32"}, watch, "3s")
             finally:
                 gconv.SPLIT_BF16 = False
         del cfg
@@ -639,12 +641,14 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
             continue
         entry = {"launch_ms": round(ms, 4), "launches_timed": len(timer.pairs[key])}
         if cfg == "3s":
-            if key == "split_input_pass":
-                entry.update(kernel="split_input_kernel (fp32 -> three bf16 planes; both layers' launches averaged)", bound="hbm")
+            if key in ("split_input_pass", "split_rows_pass"):
+                entry.update(kernel="split_input_kernel (fp32 -> three bf16 planes; all of the step's launches averaged)", bound="hbm")
             else:
                 flop = (UPCONV1_FLOP_PER_SCENE if key.startswith("up_conv_1") else UPCONV2_FLOP_PER_SCENE) * per_gpu_batch
                 # 6 bf16 products per fp32 product: the matrix work ISSUED is 6x the algorithmic flops, priced at the dense bf16 peak
-                entry.update(kernel="%s (%s %s, split products)" % ("dconv_sgfwd_kernel" if "dgrad" in key else "dconv_stfwd_kernel", key[:9], "data gradient" if "dgrad" in key else "forward"), bound="mfma", achieved=round(6 * flop / (ms * 1e-3) / 1e12, 1),
+                kname = "dconv_sgfwd_kernel" if "dgrad" in key else "dconv_swgrad_kernel" if "wgrad" in key else "dconv_stfwd_kernel"
+                what = "data gradient" if "dgrad" in key else "weight gradient" if "wgrad" in key else "forward"
+                entry.update(kernel="%s (%s %s, split products)" % (kname, key[:9], what), bound="mfma", achieved=round(6 * flop / (ms * 1e-3) / 1e12, 1),
                              peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s (bf16 products issued)", frac=round(6 * flop / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF, 4),
                              fp32_equivalent_TFLOPs=round(flop / (ms * 1e-3) / 1e12, 1))
         elif cfg in (3, 4):
