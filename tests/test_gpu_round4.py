@@ -553,3 +553,31 @@ def test_box_head_model_tests_pass_on_the_split_product_path(dev):
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in tail and "failed" not in tail, tail
+
+
+def test_split_product_kernels_are_deterministic(dev):
+    """Two launches on the same operands agree bit for bit: the forward adds its partial rows in barrier-separated passes, the data
+    gradient has no cross-wave sums, the weight gradient sums its per-workgroup partials in a fixed-order fp64 second stage."""
+    from driving_dirty_amd import gconv, synth
+    cin, cout, b, h, w = 96, 64, 2, 16, 256
+    layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+    oh, ow = layer.out_hw(h, w)
+    wd = synth.hash_uniform((cin, cout, 7, 7), synth.key_salt("dtw"), -0.05, 0.05).to(dev)
+    bd = synth.hash_uniform((cout,), synth.key_salt("dtb")).to(dev)
+    x = synth.hash_uniform((b, h, w, cin), synth.key_salt("dtx")).to(dev)
+    g = synth.hash_uniform((b, oh, ow, cout), synth.key_salt("dtg")).to(dev)
+    old = gconv.SPLIT_BF16
+    gconv.SPLIT_BF16 = True
+    try:
+        outs = []
+        for _ in range(2):
+            y = torch.empty(b, oh, ow, cout, device=dev)
+            layer.forward(wd, bd, gconv.View(x), gconv.View(y), gconv.EPI_BIAS_RELU)
+            dx = torch.empty(b, h, w, cin, device=dev)
+            layer.backward_data(wd, gconv.View(g), gconv.View(dx), relu_src=x)
+            dw, db = layer.backward_weight(gconv.View(x), gconv.View(g))
+            outs.append((y, dx, dw.clone(), db.clone()))
+    finally:
+        gconv.SPLIT_BF16 = old
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
