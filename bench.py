@@ -425,12 +425,13 @@ def other_configs(a, dev, steps=10, warmup=3):
                      "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96 and _desc(x[5]).pad_h == 0),
                      "up_conv_2_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 32 and _desc(x[5]).cout == 64 and _desc(x[5]).pad_h == 0),
                      "up_conv_1_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 96),
+                     "up_conv_2_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 64),
                      "split_input_pass": ("dd_dconv_split_input", lambda *x: True), "split_rows_pass": ("dd_dconv_split_rows", lambda *x: True)}
             gconv.SPLIT_BF16 = True
             try:
                 run("config3_bbox_split_products_bs32", cfg["model"], cfg["batch"], cfg["per_gpu_batch"],
-                    {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forwards and data gradients of up_conv_1 / up_conv_2 and the weight gradient of "
-                              "up_conv_1; everything else exact fp32"}, watch, "3s")
+                    {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forward, data gradient and weight gradient of up_conv_1 and "
+                              "up_conv_2; everything else exact fp32"}, watch, "3s")
             finally:
                 gconv.SPLIT_BF16 = False
         del cfg

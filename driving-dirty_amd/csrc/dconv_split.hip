@@ -769,16 +769,17 @@ int dd_dconv_split_rows(const float* x, void* xs, int64_t rows, int32_t w, int32
 }
 
 int32_t dd_dconv_wgrad_split_supported(int32_t k, int32_t dil, int32_t cin, int32_t cout) {
-  // 64 -> 32 (up_conv_2) compiles and is correct, but its two accumulator tiles per wave leave 24 MFMAs per 36 transpose reads: it ties
-  // the exact kernel (4.82 against 4.85 ms), so the exact one keeps that layer
-  return (k == 7 && dil == 7 && cin == 96 && cout == 64) ? 1 : 0;
+  return (k == 7 && dil == 7 && ((cin == 96 && cout == 64) || (cin == 64 && cout == 32))) ? 1 : 0;
 }
 
-static int sp_wg_per_ky() { return max(1, dd_cu_budget_internal() / 7); }
+// workgroups per tap row: one resident round.  96 -> 64 holds 120 KB of LDS: one workgroup per CU.  64 -> 32 (70 KB, 88 registers) fits TWO per
+// CU, and needs them: with two accumulator tiles per wave a step is 24 MFMAs behind 36 transpose reads and a barrier -- one workgroup per CU
+// ties the exact kernel (4.82 against 4.85 ms), two take 3.34
+static int sp_wg_per_ky(int cin) { return max(1, dd_cu_budget_internal() / 7) * (cin == 64 ? 2 : 1); }
 
 int64_t dd_dconv_wgrad_split_workspace_bytes(int32_t cin, int32_t cout) {
   if (!dd_dconv_wgrad_split_supported(7, 7, cin, cout)) return dd_fail(DD_ERR_UNSUPPORTED, "dconv_wgrad_split_workspace_bytes: unsupported layer"), -1;
-  return (int64_t)sp_wg_per_ky() * 7 * 7 * (cin / 32) * (cout / 32) * 16 * 64 * 4;
+  return (int64_t)sp_wg_per_ky(cin) * 7 * 7 * (cin / 32) * (cout / 32) * 16 * 64 * 4;
 }
 
 /* xs: split image of the layer's input x [batch, h, w, cin]; gs: split image of g = dL/dy [batch, gh, gw, cout] (gh >= h + 42,
@@ -788,7 +789,7 @@ int dd_dconv_wgrad_split(const void* xs, const void* gs, float* dw, int32_t batc
   DD_REQUIRE(dd_dconv_wgrad_split_supported(7, 7, cin, cout), DD_ERR_UNSUPPORTED, "dconv_wgrad_split: unsupported layer %d -> %d", cin, cout);
   DD_REQUIRE(xs && gs && dw && workspace, DD_ERR_BAD_ARG, "dconv_wgrad_split: NULL pointer");
   DD_REQUIRE(batch > 0 && h > 0 && w > 0 && gh >= h + 42 && gw >= w + 42, DD_ERR_BAD_ARG, "dconv_wgrad_split: sizes");
-  const int wg = sp_wg_per_ky();
+  const int wg = sp_wg_per_ky(cin);
   DD_REQUIRE(workspace_bytes >= (int64_t)wg * 7 * 7 * (cin / 32) * (cout / 32) * 16 * 64 * 4, DD_ERR_WORKSPACE, "dconv_wgrad_split: workspace too small");
   hipStream_t st = (hipStream_t)stream;
 #define SW_LAUNCH(CC, OO)                                                                                                                  \
@@ -797,7 +798,7 @@ int dd_dconv_wgrad_split(const void* xs, const void* gs, float* dw, int32_t batc
                        batch, h, w, gh, gw);                                                                                               \
     hipLaunchKernelGGL((dconv_swgrad_reduce<CC, OO>), dim3(7 * 7 * SwGeom<CC, OO>::TPW), dim3(1024), 0, st, (const float*)workspace, dw, wg, accumulate); \
   } while (0)
-  SW_LAUNCH(96, 64);
+  if (cin == 96) SW_LAUNCH(96, 64); else SW_LAUNCH(64, 32);
 #undef SW_LAUNCH
   DD_LAUNCH_CHECK("dconv_wgrad_split");
   return 0;
