@@ -2,8 +2,8 @@
 // (spatial_bb/components.py:135-136) with fp32-equivalent products on the BF16 matrix pipe.
 //
 // The exact-fp32 kernels of dconv_t.hip keep the fp32 matrix pipe 87-90 % busy: on that pipe (157 TF) they are done.  The bf16
-// pipe runs 16x faster per multiply, and an fp32 number splits EXACTLY into three bf16 pieces (8 + 8 + 8 = 24 significant bits, by
-// truncation: x = hi + mid + lo with no rounding anywhere), so
+// pipe runs 16x faster per multiply, and an fp32 number splits into three bf16 pieces (8 + 8 + 8 significant bits: x = hi + mid + lo to
+// 2^-27 |x|, each piece the round-to-nearest of the remainder of the one before), so
 //     a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + [am*bl + al*bm + al*bl]
 // and the three terms in brackets are below 2^-23 of |a*b| -- the size of fp32's own rounding of the product.  The six others are
 // issued on v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact in fp32, accumulation is fp32), smallest first:
@@ -45,13 +45,24 @@ __device__ __forceinline__ const char* sp_uni(const char* p) {
 
 __device__ __forceinline__ void sp_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- x = hi + mid + lo, exactly: three truncations (the upper 16 bits of an fp32 ARE a bf16)
+// ---- x = hi + mid + lo: three ROUNDINGS to nearest-even (v_cvt_pk_bf16_f32), each of the remainder of the one before.  Both
+// remainders are exact fp32 subtractions, so the three pieces miss x by the last rounding only (<= 2^-27 |x|).  Truncation would make
+// the sum exact, but every piece then has the sign of x and the three dropped cross products (am*bl + al*bm + al*bl) the sign of a*b: a
+// BIASED 2^-23 |a b| per product, which a 67 M-term weight-gradient sum with heavy cancellation turns into 2e-5 of its result (measured:
+// the B = 32 box step against the mean of 32 single-scene steps); with rounded pieces the dropped terms are zero-mean and the error
+// grows like a random walk, as the exact fp32 kernels' own rounding does.
+typedef __attribute__((ext_vector_type(2))) __bf16 sp_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float sp_f32x2;
+__device__ __forceinline__ unsigned sp_rne_bits(float x) {      // the bf16 nearest x, as the upper half of an fp32 pattern
+  const unsigned two = __builtin_bit_cast(unsigned, __builtin_convertvector((sp_f32x2){x, 0.f}, sp_bf16x2));
+  return two << 16;
+}
 __device__ __forceinline__ void sp_split(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+  hi = sp_rne_bits(x);
   const float r = x - __builtin_bit_cast(float, hi);
-  mid = __builtin_bit_cast(unsigned, r) & 0xFFFF0000u;
+  mid = sp_rne_bits(r);
   const float s = r - __builtin_bit_cast(float, mid);
-  lo = __builtin_bit_cast(unsigned, s) & 0xFFFF0000u;
+  lo = sp_rne_bits(s);
 }
 
 // one thread per (image row, chunk, pixel, 8-channel half): 32 B in, 3 x 16 B out (+ the 16 B pad from half 0)

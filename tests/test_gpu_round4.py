@@ -515,8 +515,10 @@ def test_split_bf16_data_gradient_mask_pass_and_channel_slice(dev):
     assert float((a - c).abs().max() / a.abs().max()) < 2e-5
 
 
-def test_split_bf16_pieces_are_exact(dev):
-    """dd_dconv_split_input: hi + mid + lo == x bit for bit (three truncations), for normal numbers of every magnitude the layers see."""
+def test_split_bf16_pieces_reassemble_the_operand(dev):
+    """dd_dconv_split_input: hi + mid + lo == x to 2^-26 |x| (three roundings to nearest, each of the exact remainder of the one
+    before), every piece a bf16, and the pieces carry no sign bias (round to nearest: `mid` and `lo` are as often opposite in sign to x
+    as not -- what keeps the dropped cross products zero-mean)."""
     import ctypes as C
     from driving_dirty_amd import _lib, gconv
     b, h, w, c = 1, 3, 40, 32
@@ -532,11 +534,18 @@ def test_split_bf16_pieces_are_exact(dev):
     xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
     _lib.check(lib.dd_dconv_split_input(C.c_void_p(x.data_ptr()), C.c_void_p(xs.data_ptr()), C.byref(d), None), "split_input")
     torch.cuda.synchronize()
+    assert torch.equal(xs, gconv.split_rows(gconv.View(x)))                                        # the descriptor-free entry point: same image
     img = xs.view(torch.int16).view(b, h, c // 16, w, 56)[..., :48].reshape(b, h, c // 16, w, 3, 16)      # [b, y, q, px, plane, ch]
     planes = (img.to(torch.int32) << 16).view(torch.float32)
     total = planes[..., 0, :].double() + planes[..., 1, :].double() + planes[..., 2, :].double()
     back = total.permute(0, 1, 3, 2, 4).reshape(b, h, w, c)
-    assert torch.equal(back, x.double())
+    err = (back - x.double()).abs()
+    assert bool((err <= x.double().abs() * 2.0 ** -26).all())
+    hi = planes[..., 0, :].permute(0, 1, 3, 2, 4).reshape(b, h, w, c)
+    assert torch.equal(hi, x.to(torch.bfloat16).float())                                           # hi = the bf16 nearest x
+    mid = planes[..., 1, :].permute(0, 1, 3, 2, 4).reshape(b, h, w, c)
+    opposite = float(((mid * x) < 0).float().mean())
+    assert 0.35 < opposite < 0.65, opposite
 
 
 def test_box_head_model_tests_pass_on_the_split_product_path(dev):
