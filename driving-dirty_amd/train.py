@@ -53,6 +53,7 @@ class TrainStep:
             scheduler = self._reference_has_scheduler(model)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, patience=10) if scheduler else None
         self.last = None
+        self._one = None
 
     @staticmethod
     def _make_optimizer(params, lr):
@@ -72,7 +73,10 @@ class TrainStep:
         """One training step; returns ``training_step``'s dict (``out['loss']`` is the step's loss, still on the device)."""
         self.model.zero_grad(set_to_none=True)
         out = self.model.training_step(batch, batch_idx)
-        out["loss"].backward()
+        loss = out["loss"]
+        if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+            self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        loss.backward(self._one)                 # the root gradient is a kept tensor: no ones_like fill launch per step
         self.sync.finish()
         self.optimizer.step(grad_scale=self.sync.grad_scale)
         self.last = out
