@@ -416,7 +416,7 @@ def other_configs(a, dev, steps=10, warmup=3):
         ms = res[names[c]]["ms_per_step"]
         res[names[c]].update(algorithmic_TFLOPs=round(algo / (ms * 1e-3) / 1e12, 1),
                              **{("frac_bf16_mfma_peak" if c == 5 else "frac_fp32_mfma_peak"): round(algo / (ms * 1e-3) / 1e12 / peak, 4)})
-        if c == 3:
+        if c in (3, 4):
             # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with up_conv_1 / up_conv_2 taking every fp32
             # product as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulate) on the bf16 matrix pipe
             from driving_dirty_amd import gconv
@@ -429,7 +429,7 @@ def other_configs(a, dev, steps=10, warmup=3):
                      "split_input_pass": ("dd_dconv_split_input", lambda *x: True), "split_rows_pass": ("dd_dconv_split_rows", lambda *x: True)}
             gconv.SPLIT_BF16 = True
             try:
-                run("config3_bbox_split_products_bs32", cfg["model"], cfg["batch"], cfg["per_gpu_batch"],
+                run("config3_bbox_split_products_bs32" if c == 3 else "config4_joint_split_products_bs32_per_gpu", cfg["model"], cfg["batch"], cfg["per_gpu_batch"],
                     {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forward, data gradient and weight gradient of up_conv_1 and "
                               "up_conv_2; everything else exact fp32"}, watch, "3s")
             finally:
@@ -458,23 +458,35 @@ def u8_h2d_step(dev, steps, warmup):
     model = build_model(dev)
     ts = TrainStep(model, lr=1e-3, scheduler=False)
     g = torch.Generator().manual_seed(SEED)
-    host = []
+    host_tuple, host_stacked = [], []
     for _ in range(2):
         frames = torch.randint(0, 256, (BATCH, 6, H, W, 3), dtype=torch.uint8, generator=g)
         road = torch.rand(BATCH, 800, 800, generator=g) < 0.3
-        host.append((tuple(f.clone().pin_memory() for f in frames), tuple({} for _ in range(BATCH)), tuple(r.clone().pin_memory() for r in road)))
+        # (a) the reference's collate as it is: a tuple of per-sample tensors, each pinned by itself (64 small copies per batch)
+        host_tuple.append((tuple(f.clone().pin_memory() for f in frames), tuple({} for _ in range(BATCH)), tuple(r.clone().pin_memory() for r in road)))
+        # (b) a collate that stacks: one pinned [B,6,H,W,3] block + one [B,800,800] block (2 copies per batch); training_step takes both forms
+        host_stacked.append((frames.pin_memory(), tuple({} for _ in range(BATCH)), road.pin_memory()))
     nbytes = BATCH * (6 * H * W * 3 + 800 * 800)
-    t0 = None
-    for i, batch in enumerate(DevicePrefetcher((host[i & 1] for i in range(warmup + steps)), dev)):
-        if i == warmup:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        ts(batch, i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+
+    def timed(host, unstack_road):
+        t0 = None
+        for i, batch in enumerate(DevicePrefetcher((host[i & 1] for i in range(warmup + steps)), dev)):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            if unstack_road:
+                batch = (batch[0], batch[1], tuple(batch[2]))      # views of the one device block: the loss reads them through its pointer table
+            ts(batch, i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    dt_tuple = timed(host_tuple, False)
+    dt = timed(host_stacked, True)
     ts.close()
     return {"ms_per_step": round(dt * 1e3, 3), "scenes_per_s": round(BATCH / dt, 1), "batch": BATCH, "steps": steps, "warmup": warmup, "dtype": "f32",
-            "input": "uint8 frames [6,256,306,3] per sample + bool road masks from pinned host memory, prefetched one batch ahead on a copy stream",
+            "input": "uint8 frames [B,6,256,306,3] + bool road masks [B,800,800], each ONE pinned host block (a stacking collate), prefetched one batch "
+                     "ahead on a copy stream: 2 copies per batch",
+            "per_sample_copies": {"ms_per_step": round(dt_tuple * 1e3, 3), "scenes_per_s": round(BATCH / dt_tuple, 1),
+                                  "input": "the reference's collate as it is: tuples of per-sample pinned tensors, 64 copies per batch"},
             "pcie_bytes_per_step": nbytes, "pcie_GBs_needed": round(nbytes / dt / 1e9, 2)}
 
 
