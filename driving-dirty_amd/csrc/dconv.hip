@@ -571,7 +571,11 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
     return 0;
   }
   const DcPlan plan = dc_plan(*d, d->dil_h);
-  const int grid = (int)max(1, min(dd_cu_budget_internal(), plan.total));      // one 8-wave workgroup per CU, all resident
+  // one 8-wave workgroup per CU, all resident -- TWO for the stride-1 3x3 layers on at most one column tile (out_conv, rm_conv_2, the decoder's
+  // dc2: 58 KB of LDS and <= 118 registers fit twice; their short tap loops (9 taps) leave a single workgroup waiting on its fills)
+  static const int wgs3 = getenv("DD_DCONV3_WGS_PER_CU") ? max(1, min(2, atoi(getenv("DD_DCONV3_WGS_PER_CU")))) : 2;
+  const int per_cu = (d->kh == 3 && nt <= 1) ? wgs3 : 1;
+  const int grid = (int)max(1, min(dd_cu_budget_internal() * per_cu, plan.total));
 #define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes, dbg_repeat)
 #define DD_DC_NT(KK, DD_) do { if (nt == 0) DD_DC(KK, DD_, 0); else if (nt == 1) DD_DC(KK, DD_, 1); else if (nt == 2) DD_DC(KK, DD_, 2); else DD_DC(KK, DD_, 3); } while (0)
   switch (dc_variant(d)) {
