@@ -108,7 +108,7 @@ def _worker(rank, world, port, out, shard, how):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,how", [(2, "lightning"), (2, "by_hand"), (4, "lightning")])
+@pytest.mark.parametrize("world,how", [(2, "lightning"), (2, "by_hand"), (4, "lightning"), (8, "lightning")])
 def test_sharded_optimizer_is_bit_identical_to_the_all_reduce_path(tmp_path, world, how):
     out = str(tmp_path / "s.pt")
     for shard in (False, True):
