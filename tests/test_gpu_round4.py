@@ -556,7 +556,7 @@ def test_box_head_model_tests_pass_on_the_split_product_path(dev):
     env = dict(os.environ, DD_DCONV_SPLIT="1")
     sel = ("test_spatial_heads_three_way or test_bbox_training_step_three_way or test_merging_heads_signed_inputs_three_way or "
            "test_joint_training_step_three_way or test_bbox_step_b32_equals_mean_of_single_scene_steps or "
-           "test_box_head_layers_full_size_linearity_and_adjointness or test_layer_fwd_dgrad_wgrad")
+           "test_box_head_layers_full_size_linearity_and_adjointness")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
