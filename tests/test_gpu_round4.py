@@ -550,13 +550,12 @@ def test_split_bf16_pieces_reassemble_the_operand(dev):
 
 def test_box_head_model_tests_pass_on_the_split_product_path(dev):
     """The model-level tests of the box heads -- the three-way checks against the fp64 oracle (same-branch 2e-4, flip census, reference
-    fixtures), the B = 32 step against the mean of 32 single-scene steps, adjointness of every layer at bs 32, the joint step -- re-run
+    fixtures), the B = 32 step against the mean of 32 single-scene steps, adjointness of every layer at bs 32 -- re-run
     in a child process with DD_DCONV_SPLIT=1: the forwards, data gradients and (96 -> 64) weight gradient of up_conv_1 / up_conv_2 on the
     split-product kernels.  Same tests, same tolerances, no allowance for the experiment."""
     env = dict(os.environ, DD_DCONV_SPLIT="1")
     sel = ("test_spatial_heads_three_way or test_bbox_training_step_three_way or test_merging_heads_signed_inputs_three_way or "
-           "test_joint_training_step_three_way or test_bbox_step_b32_equals_mean_of_single_scene_steps or "
-           "test_box_head_layers_full_size_linearity_and_adjointness")
+           "test_bbox_step_b32_equals_mean_of_single_scene_steps or test_box_head_layers_full_size_linearity_and_adjointness")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
