@@ -35,3 +35,9 @@ python3 tools/pmc_traffic_any.py $O/up_fetch $O/up_write gpurun_out/${R}_upconv_
   'dconv_wgrad_kernel<7, 7, 64, 32=1200947200:up_conv_2 weight gradient' > $O/traffic_up.log 2>&1
 cp profiles/${R}_*_kernel_stats.csv gpurun_out/ 2>/dev/null
 for f in $O/*_sum.log $O/traffic_*.log; do tail -n 2 $f; done
+# the split-product experiment (csrc/dconv_split.hip): the same config-3 step with DD_DCONV_SPLIT=1
+export DD_DCONV_SPLIT=1
+run bbox_split_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bbox_split_stats -o b -- python3 bench.py --config 3 --steps 4 --warmup 2
+unset DD_DCONV_SPLIT
+cp $O/bbox_split_stats/b_kernel_stats.csv profiles/${R}_bbox_split_products_kernel_stats.csv 2>/dev/null
+cp profiles/${R}_bbox_split_products_kernel_stats.csv gpurun_out/ 2>/dev/null
