@@ -424,6 +424,7 @@ def other_configs(a, dev, steps=10, warmup=3):
                      "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 32 and _desc(x[5]).pad_h > 0),
                      "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96 and _desc(x[5]).pad_h == 0),
                      "up_conv_2_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 32 and _desc(x[5]).cout == 64 and _desc(x[5]).pad_h == 0),
+                     "up_conv_3_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 16 and _desc(x[5]).cout == 32 and _desc(x[5]).pad_h == 0),
                      "up_conv_1_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 96),
                      "up_conv_2_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 64),
                      "split_input_pass": ("dd_dconv_split_input", lambda *x: True), "split_rows_pass": ("dd_dconv_split_rows", lambda *x: True)}
@@ -657,7 +658,7 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
             if key in ("split_input_pass", "split_rows_pass"):
                 entry.update(kernel="split_input_kernel (fp32 -> three bf16 planes; all of the step's launches averaged)", bound="hbm")
             else:
-                flop = (UPCONV1_FLOP_PER_SCENE if key.startswith("up_conv_1") else UPCONV2_FLOP_PER_SCENE) * per_gpu_batch
+                flop = {"up_conv_1": UPCONV1_FLOP_PER_SCENE, "up_conv_2": UPCONV2_FLOP_PER_SCENE, "up_conv_3": 2.0 * 340 * 340 * 49 * 32 * 16}[key[:9]] * per_gpu_batch
                 # 6 bf16 products per fp32 product: the matrix work ISSUED is 6x the algorithmic flops, priced at the dense bf16 peak
                 kname = "dconv_sgfwd_kernel" if "dgrad" in key else "dconv_swgrad_kernel" if "wgrad" in key else "dconv_stfwd_kernel"
                 what = "data gradient" if "dgrad" in key else "weight gradient" if "wgrad" in key else "forward"

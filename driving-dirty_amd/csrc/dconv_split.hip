@@ -374,7 +374,8 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
 // planes each -- is read ONCE from LDS into registers (84 VGPRs) and multiplied with the B images of the NTC column tiles in turn; the B
 // image of one (chunk, tap row, column tile) is 21 KB, so the stage is cut per column tile: two A buffers (alternating per (chunk, tap
 // row)), two B buffers (alternating per sub-stage), everything filled by LDS-DMA one sub-stage ahead, one s_barrier per sub-stage of 42
-// MFMAs per wave.  NW = 8 waves (rows up to 256 output pixels: up_conv_1) or 10 (up to 320: up_conv_2; SIMDs then hold 3 / 3 / 2 / 2 waves).
+// MFMAs per wave.  NW = 8 waves (rows up to 256 output pixels: up_conv_1), 10 (up to 320: up_conv_2; SIMDs then hold 3 / 3 / 2 / 2 waves) or 11 (up to
+// 352: up_conv_3, one column tile).
 template <int K, int D, int NTC, int NW, int IWP>
 __global__ __launch_bounds__(NW * 64) void dconv_sgfwd_kernel(const char* __restrict__ xs, const char* __restrict__ wp,
                                                               const float* __restrict__ msk, float* __restrict__ y, const dd_gconv_desc d,
@@ -712,13 +713,14 @@ bool sp_fwd_ok(const dd_gconv_desc* d) {
   return true;
 }
 
-// the data gradient: a plain dilated convolution (pad 0, out = in - d(k-1)), rows of at most 320 output pixels
+// the data gradient: a plain dilated convolution (pad 0, out = in - d(k-1)), rows of at most 352 output pixels
 bool sp_dgrad_ok(const dd_gconv_desc* d) {
   if (!sp_common_ok(d)) return false;
   if (d->pad_h != 0 || d->pad_w != 0) return false;
   if (d->out_h > d->in_h - 42 || d->out_w > d->in_w - 42) return false;
-  if (d->out_w > 320 || d->in_w > 384) return false;
+  if (d->out_w > 352 || d->in_w > 448) return false;
   if ((d->out_w > 256 || d->in_w > 320) && d->cout > 64) return false;      // the 10-wave form holds at most two column tiles in 170 registers
+  if ((d->out_w > 320 || d->in_w > 384) && d->cout > 32) return false;      // the 11-wave form (up_conv_3: 340 output pixels) one
   return true;
 }
 
@@ -831,8 +833,10 @@ int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, co
                      mask, y, *d, epilogue)
     if (d->out_w <= 256 && d->in_w <= 320) {
       if (ntc == 1) SG_LAUNCH(1, 8, 320); else if (ntc == 2) SG_LAUNCH(2, 8, 320); else SG_LAUNCH(3, 8, 320);
-    } else {
+    } else if (d->out_w <= 320 && d->in_w <= 384) {
       if (ntc == 1) SG_LAUNCH(1, 10, 384); else SG_LAUNCH(2, 10, 384);
+    } else {
+      SG_LAUNCH(1, 11, 448);
     }
 #undef SG_LAUNCH
     DD_LAUNCH_CHECK("dconv_fwd_split (data gradient)");

@@ -436,6 +436,8 @@ _SPLIT_CASES = [
     ("up2_257_nine_tiles", 64, 32, (1, 3, 257)),
     ("up2_320_ten_full", 64, 64, (1, 2, 320)),          # widest row, two column tiles
     ("up2_tall", 64, 32, (2, 40, 100)),                 # every tap-row range of the residue classes
+    ("up3_full_width", 32, 16, (1, 9, 340)),            # Cout 16: forward and weight gradient stay exact, the data gradient on the 11-wave form
+    ("up3_352_widest", 32, 16, (1, 2, 352)),
 ]
 
 
