@@ -771,7 +771,8 @@ def init_distributed(world, rank, dev, backend, dog):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("NCCL_DEBUG", "WARN")             # RCCL's own warnings carry host:pid:rank
+    # NCCL_DEBUG is left alone: at WARN (or VERSION) RCCL prints a five-line version banner on STDOUT, in front of the one JSON line
+    # this script owes its caller; RCCL's fatal errors reach stderr through torch's exception text either way
     limit = datetime.timedelta(seconds=float(os.environ.get("DD_DIST_TIMEOUT_S", "120")))
     dog.beat("rendezvous")
     if backend == "nccl":

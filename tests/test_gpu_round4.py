@@ -160,7 +160,9 @@ def _bench(env_extra, *args, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--no-others", "--no-cpu-baseline"], env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"bench.py owes its caller ONE line on stdout, got {len(lines)}: {[ln[:60] for ln in lines]}"      # e.g. RCCL's banner at NCCL_DEBUG=WARN
+    return json.loads(lines[0]), r.stderr
 
 
 def test_bench_sharded_step_over_a_one_rank_rccl_communicator(dev):
