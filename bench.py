@@ -765,24 +765,43 @@ class Watchdog:
                     os._exit(3)
 
 
+class StdoutToStderr:
+    """File-descriptor-level redirect of stdout into stderr for the span of communicator creation: with NCCL_DEBUG=VERSION (the GPU boxes
+    of this pool export it) or WARN, RCCL prints a five-line version banner with printf on STDOUT the first time a communicator is
+    created -- in front of the one JSON line this script owes its caller.  The user's NCCL_DEBUG stays as it is; the banner lands on stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_distributed(world, rank, dev, backend, dog):
     """Rendezvous with a BOUNDED wait, then one collective that every rank must reach (the preflight count)."""
     import datetime
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # NCCL_DEBUG is left alone: at WARN (or VERSION) RCCL prints a five-line version banner on STDOUT, in front of the one JSON line
-    # this script owes its caller; RCCL's fatal errors reach stderr through torch's exception text either way
     limit = datetime.timedelta(seconds=float(os.environ.get("DD_DIST_TIMEOUT_S", "120")))
     dog.beat("rendezvous")
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
-    dog.beat("preflight collective")
-    ones = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-    seen = int(round(float(ones.item())))
+    with StdoutToStderr():      # RCCL's version banner (NCCL_DEBUG=VERSION / WARN) belongs on stderr
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+        dog.beat("preflight collective")
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        seen = int(round(float(ones.item())))
+        if backend == "nccl":
+            torch.cuda.synchronize()
     info = {"backend": backend, "n_ranks_seen": seen, "world_size": world, "dist_timeout_s": limit.total_seconds()}
     if dev is not None:
         info.update(visible_devices=torch.cuda.device_count(), device=torch.cuda.get_device_name(dev),
