@@ -369,6 +369,15 @@ def time_steps(step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+_T0 = time.perf_counter()
+
+
+def _phase(name):
+    if os.environ.get("DD_BENCH_PHASES") == "1":
+        sys.stderr.write(f"bench.py phase {name}: {time.perf_counter() - _T0:.1f} s since start\n")
+        sys.stderr.flush()
+
+
 def other_configs(a, dev, steps=10, warmup=3):
     """Per-GPU step rates of the other BASELINE configurations, measured in this process after the headline timing (same
     synthetic-data conventions, the same TrainStep; diagnostic numbers, not `value`).  Configs 3 / 4 / 5 carry the `roofline` of their
@@ -398,6 +407,7 @@ def other_configs(a, dev, steps=10, warmup=3):
             timer.uninstall()
         res[name] = entry
         ts.close()
+        _phase(name)
 
     # config 1's GPU twin: BasicAE masked-view pre-training step (autoencoder.py:78-93), fwd+bwd+Adam
     for b in (4, BATCH):
@@ -446,6 +456,7 @@ def other_configs(a, dev, steps=10, warmup=3):
     del m, ae
     torch.cuda.empty_cache()
     res["config2_u8_h2d"] = u8_h2d_step(dev, steps, warmup)
+    _phase("config2_u8_h2d")
     return res
 
 
@@ -986,6 +997,7 @@ def run_rank(a):
         }
         if preflight is not None:
             line["preflight"] = preflight
+        _phase("headline")
         if world == 1 and a.config == 2 and not a.no_others and not a.simulate_shard:
             ts.close()
             timer.uninstall()
@@ -995,8 +1007,10 @@ def run_rank(a):
         if world == 1 and a.config == 2 and pmc is not None and not a.no_others and not a.simulate_shard:
             torch.cuda.empty_cache()      # this process's models are gone by now (deleted before `others`): the children get the GPU to themselves
             refresh_traffic(roof, pmc)
+        _phase("traffic")
         if not a.no_cpu_baseline and world == 1 and a.config == 2 and not a.simulate_shard:
             line["cpu_baseline"] = cpu_baseline()
+            _phase("cpu_baseline")
         print(json.dumps(line), flush=True)
     if comm:
         dist.barrier()
