@@ -430,11 +430,11 @@ def other_configs(a, dev, steps=10, warmup=3):
             # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with up_conv_1 / up_conv_2 taking every fp32
             # product as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulate) on the bf16 matrix pipe
             from driving_dirty_amd import gconv
-            watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 96 and _desc(x[5]).pad_h > 0),
-                     "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 32 and _desc(x[5]).pad_h > 0),
-                     "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 64 and _desc(x[5]).cout == 96 and _desc(x[5]).pad_h == 0),
-                     "up_conv_2_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 32 and _desc(x[5]).cout == 64 and _desc(x[5]).pad_h == 0),
-                     "up_conv_3_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[5]).cin == 16 and _desc(x[5]).cout == 32 and _desc(x[5]).pad_h == 0),
+            watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 96 and _desc(x[6]).pad_h > 0),
+                     "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 64 and _desc(x[6]).cout == 32 and _desc(x[6]).pad_h > 0),
+                     "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 64 and _desc(x[6]).cout == 96 and _desc(x[6]).pad_h == 0),
+                     "up_conv_2_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 32 and _desc(x[6]).cout == 64 and _desc(x[6]).pad_h == 0),
+                     "up_conv_3_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 16 and _desc(x[6]).cout == 32 and _desc(x[6]).pad_h == 0),
                      "up_conv_1_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 96),
                      "up_conv_2_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 64),
                      "split_input_pass": ("dd_dconv_split_input", lambda *x: True), "split_rows_pass": ("dd_dconv_split_rows", lambda *x: True)}

@@ -112,7 +112,7 @@ SIGNATURES = {
     "dd_dconv_split_packed_bytes": (_i64, [_GP]),
     "dd_dconv_split_input": (_i32, [_p, _p, _GP, _p]),
     "dd_dconv_split_pack": (_i32, [_p, _p, _GP, _i64, _i64, _i64, _i32, _i32, _i32, _p]),
-    "dd_dconv_fwd_split": (_i32, [_p, _p, _p, _p, _p, _GP, _i32, _p]),
+    "dd_dconv_fwd_split": (_i32, [_p, _p, _p, _p, _p, _p, _GP, _i32, _p]),
     "dd_dconv_split_rows": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dd_dconv_wgrad_split_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "dd_dconv_wgrad_split_workspace_bytes": (_i64, [_i32, _i32]),

@@ -129,7 +129,9 @@ struct SpTask {
 template <int K, int D, int NSLOT, int MODE, int IWP, int abl, int NBUF>
 __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __restrict__ xs, const char* __restrict__ wp,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
-                                                                 const dd_gconv_desc d, int epi) {
+                                                                 char* __restrict__ yplanes, const dd_gconv_desc d, int epi) {
+  // yplanes (optional): the three-plane bf16 image of the OUTPUT, [b][oy][cout / 16][out_w][112 B] -- what dd_dconv_split_rows would make
+  // of y, written from the epilogue's registers so that the next layer's split pass (read 4 B, write 6 B per element) disappears.
   // abl (template): timing ablations of DD_TIMING_DIAG builds (results are then wrong; 0 in every other build): 1 no MFMAs, 2 no DMA after a
   // task's first stage, 4 no shift-add passes in the epilogue, 8 no operand reads after a stage's first
   constexpr bool ONE_MT = MODE == 0;
@@ -360,6 +362,17 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
         }
         const int off = (px < d.out_w && cch < d.cout) ? (base + px * d.out_cstore) * 4 : -16;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), ys, off, 0, 0);
+        if (yplanes) {      // this thread's four channels of the pixel: 8 bytes per plane
+          const int ncp = d.cout >> 4;
+          const __amdgpu_buffer_rsrc_t ps = dd_rsrc(yplanes + (long)cur.b * d.out_h * ncp * d.out_w * SP_PXB, d.out_h * ncp * d.out_w * SP_PXB);
+          const int poff = (px < d.out_w && cch < d.cout) ? ((cur.oy * ncp + (cch >> 4)) * d.out_w + px) * SP_PXB + (cch & 15) * 2 : -16;
+          unsigned h[4], m[4], l[4];
+          sp_split(o.x, h[0], m[0], l[0]); sp_split(o.y, h[1], m[1], l[1]); sp_split(o.z, h[2], m[2], l[2]); sp_split(o.w, h[3], m[3], l[3]);
+          typedef __attribute__((ext_vector_type(2))) unsigned u32x2s;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2s{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]}, ps, poff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2s{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]}, ps, poff < 0 ? poff : poff + 32, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2s{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]}, ps, poff < 0 ? poff : poff + 64, 0, 0);
+        }
       }
     }
     sp_barrier();
@@ -378,8 +391,8 @@ __global__ __launch_bounds__(SP_THREADS) void dconv_stfwd_kernel(const char* __r
 // 352: up_conv_3, one column tile).
 template <int K, int D, int NTC, int NW, int IWP>
 __global__ __launch_bounds__(NW * 64) void dconv_sgfwd_kernel(const char* __restrict__ xs, const char* __restrict__ wp,
-                                                              const float* __restrict__ msk, float* __restrict__ y, const dd_gconv_desc d,
-                                                              int epi) {
+                                                              const float* __restrict__ msk, float* __restrict__ y, char* __restrict__ yplanes,
+                                                              const dd_gconv_desc d, int epi) {
   constexpr int AROW = IWP * SP_PXB, BST = K * 3 * 1024;
   constexpr int NA = AROW / 1024, NB = K * 3;
   static_assert(AROW % 1024 == 0, "the A image is filled in whole 1 KB wave-instructions");
@@ -504,8 +517,11 @@ __global__ __launch_bounds__(NW * 64) void dconv_sgfwd_kernel(const char* __rest
       }
     }
 
-    // ---- write-out (as dconv_gfwd_kernel: all mask values of a tile requested before the first is used)
+    // ---- write-out (as dconv_gfwd_kernel: all mask values of a tile requested before the first is used).  Lane-derived values come from
+    // a fresh lane id (dd_fresh_lane) so that nothing of the epilogue's addressing lives across the MFMA loop (170 registers at 10-11 waves)
     {
+      const int fl = dd_fresh_lane();
+      const int n = fl & 31, lane = fl;
       const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cb * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
       const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)cb * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
       const bool masked = epi == DD_EPI_RELU_MASK;
@@ -531,7 +547,25 @@ __global__ __launch_bounds__(NW * 64) void dconv_sgfwd_kernel(const char* __rest
           }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dd_bstore1(ys, off[r], mv[r] > 0.f ? acc[nt][r] : 0.f);
+        for (int r = 0; r < 16; ++r) {
+          acc[nt][r] = mv[r] > 0.f ? acc[nt][r] : 0.f;      // masked in place: the plane stores below need no mask and no offset kept alive
+          dd_bstore1(ys, off[r], acc[nt][r]);
+        }
+        if (yplanes) {      // the output's bf16 planes (see dconv_stfwd_kernel): a lane holds ONE channel of 16 pixels -> 2-byte stores
+          const int ncp = d.cout >> 4;
+          const __amdgpu_buffer_rsrc_t ps = dd_rsrc(yplanes + (long)cb * d.out_h * ncp * d.out_w * SP_PXB, d.out_h * ncp * d.out_w * SP_PXB);
+          const int pbase = ((coy * ncp + (ch >> 4)) * d.out_w) * SP_PXB + (ch & 15) * 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int xo = wave * 32 + dd_acc_row(r, lane);
+            const int poff = (wave < n_mt && xo < d.out_w && ch < d.cout) ? pbase + xo * SP_PXB : (int)0x80000000;
+            unsigned hi, mid, lo;
+            sp_split(acc[nt][r], hi, mid, lo);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(hi >> 16), ps, poff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(mid >> 16), ps, poff + 32, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(lo >> 16), ps, poff + 64, 0, 0);
+          }
+        }
       }
     }
     sp_barrier();
@@ -817,10 +851,12 @@ int dd_dconv_wgrad_split(const void* xs, const void* gs, float* dw, int32_t batc
   return 0;
 }
 
-int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
-                       int32_t epilogue, void* stream) {
+int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, void* y_planes,
+                       const dd_gconv_desc* d, int32_t epilogue, void* stream) {
   DD_REQUIRE(d && sp_layer_ok(d), DD_ERR_UNSUPPORTED, "dconv_fwd_split: unsupported layer");
   DD_REQUIRE(xs && packed && y, DD_ERR_BAD_ARG, "dconv_fwd_split: NULL pointer");
+  DD_REQUIRE(!y_planes || (d->cout % 16 == 0 && ((uintptr_t)y_planes & 15) == 0 && (long)d->out_h * (d->cout / 16) * d->out_w * SP_PXB < (1L << 31)),
+             DD_ERR_UNSUPPORTED, "dconv_fwd_split: y_planes needs cout % 16 == 0 and an image below 2 GB per batch element");
   const int grid = dd_cu_budget_internal() & ~7;
   DD_REQUIRE(grid >= 8, DD_ERR_UNSUPPORTED, "dconv_fwd_split: CU budget below 8");
   hipStream_t st = (hipStream_t)stream;
@@ -830,7 +866,7 @@ int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, co
     const int ntc = (d->cout + 31) / 32;
 #define SG_LAUNCH(NTC_, NW_, IWP_)                                                                                                   \
   hipLaunchKernelGGL((dconv_sgfwd_kernel<7, 7, NTC_, NW_, IWP_>), dim3(grid), dim3(NW_ * 64), 0, st, (const char*)xs, (const char*)packed, \
-                     mask, y, *d, epilogue)
+                     mask, y, (char*)y_planes, *d, epilogue)
     if (d->out_w <= 256 && d->in_w <= 320) {
       if (ntc == 1) SG_LAUNCH(1, 8, 320); else if (ntc == 2) SG_LAUNCH(2, 8, 320); else SG_LAUNCH(3, 8, 320);
     } else if (d->out_w <= 320 && d->in_w <= 384) {
@@ -850,10 +886,10 @@ int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, co
   do {                                                                                                                                    \
     if (d->in_w <= 256)                                                                                                                   \
       hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 7, 0, 256, ABL, NBUF_>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, \
-                         bias, y, *d, epilogue);                                                                                          \
+                         bias, y, (char*)y_planes, *d, epilogue);                                                                         \
     else                                                                                                                                  \
       hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 9, 1, 320, ABL, 2>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, \
-                         bias, y, *d, epilogue);                                                                                          \
+                         bias, y, (char*)y_planes, *d, epilogue);                                                                         \
   } while (0)
   // A/B: DD_SPLIT_NBUF=3 = three LDS buffers for the 256-wide form (a fill has two stages to land): 5.63-5.67 ms against 5.57-5.58 with
   // two -- the fills' latency is not what the kernel waits for (it runs power-limited at 1.88 GHz, matrix pipe 64 % busy)

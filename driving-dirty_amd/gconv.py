@@ -128,9 +128,10 @@ def _dconv_ok(d):
     return DCONV and bool(_lib.lib().dd_dconv_supported(C.byref(d)))
 
 
-def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real, xs=None):
+def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real, xs=None, emit=None):
     """pack + launch on the dilated kernel when the descriptor qualifies, on the generic one otherwise.  Returns the split image of
-    x when the split-product path ran (``xs``: one a caller already holds), None otherwise."""
+    x when the split-product path ran (``xs``: one a caller already holds), None otherwise.  ``emit`` (a dict): on the split path the
+    kernel also writes the split image of its OUTPUT from its epilogue (``emit['ys']``: the next layer's operand, no split pass)."""
     lib = _lib.lib()
     if SPLIT_BF16 and lib.dd_dconv_split_supported(C.byref(d)) and (
             (d.pad_h > 0 and mask is None and epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU)) or (d.pad_h == 0 and epi in (EPI_NONE, EPI_RELU_MASK))):
@@ -139,7 +140,11 @@ def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real,
             xs = torch.empty(lib.dd_dconv_split_input_bytes(C.byref(d)), device=x.device, dtype=torch.uint8)
             check(lib.dd_dconv_split_input(_p(x), _p(xs), C.byref(d), _stream()), "dd_dconv_split_input")
         check(lib.dd_dconv_split_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_split_pack")
-        check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
+        ys = None
+        if emit is not None and d.cout % 16 == 0 and d.out_coff == 0 and d.ooff_h == 0 and d.ooff_w == 0 and d.omem_h == d.out_h and d.omem_w == d.out_w:
+            ys = torch.empty(d.batch * d.out_h * (d.cout // 16) * d.out_w * 112, device=x.device, dtype=torch.uint8)
+            emit["ys"] = ys
+        check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(mask), _p(y), _p(ys), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
         return xs
     if _dconv_ok(d):
         n = lib.dd_dconv_packed_floats(C.byref(d))
@@ -184,9 +189,10 @@ class Layer:
         return tuple(self.dil[i] * (self.k[i] - 1) - self.pad[i] for i in range(2))
 
     # ---- forward: writes dst (View) from src (View)
-    def forward(self, weight, bias, src, dst, epilogue, mask=None, keep=None):
+    def forward(self, weight, bias, src, dst, epilogue, mask=None, keep=None, xs=None, emit=None):
         """``keep`` (a dict): receives ``keep['xs']``, the split image of the input, when the split-product experiment ran -- the
-        weight gradient of the same layer takes it back (``backward_weight(xs=...)``) instead of splitting x again."""
+        weight gradient of the same layer takes it back (``backward_weight(xs=...)``) instead of splitting x again.  ``xs``: that image
+        when the caller already holds it (the previous layer's ``emit['ys']``); ``emit`` (a dict): also write the output's."""
         b = src.buf.shape[0]
         cs = src.chans if src.chans % 4 == 0 else self.cin_store
         _chk(weight, "weight")
@@ -201,12 +207,12 @@ class Layer:
                 _fwd(src.buf, pk, bias, mask, dst.buf, d, epilogue)
         else:
             d = _desc(b, src, dst, cs, self.cout, self.k, (1, 1), self.dil, self._flip_pad())
-            xs = _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.T, self.cout * self.T, True, self.cout, self.cin)
+            xs = _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.T, self.cout * self.T, True, self.cout, self.cin, xs=xs, emit=emit)
             if keep is not None and xs is not None:
                 keep["xs"] = xs
 
     # ---- data gradient: dsrc (View with the input's geometry, >= 4-aligned channels) from ddst (View of dy)
-    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0), gs=None):
+    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0), gs=None, emit=None):
         """dsrc.buf[..., dsrc.coff : +cin] = dL/dx (x masked by ``relu_src > 0`` when given; channels
         [mask_pass[0], mask_pass[1]) of the dsrc buffer are exempt: a concat slice that is not a ReLU output)."""
         b = ddst.buf.shape[0]
@@ -217,7 +223,7 @@ class Layer:
             # the dilated kernel takes up to 96 output channels in one launch (three column tiles per wave)
             d = _desc(b, ddst, dsrc, cos, cin_out, self.k, (1, 1), self.dil, self.pad, mask_pass=mask_pass)
             if _dconv_ok(d):
-                _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout, xs=gs)
+                _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout, xs=gs, emit=emit)
                 return
         if (not self.transposed and self.stride != (1, 1) and self.dil == (1, 1) and self.pad == (0, 0) and cin_out <= 64
                 and PHASED_DGRAD):

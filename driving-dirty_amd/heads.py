@@ -225,13 +225,17 @@ class MergeFn(torch.autograd.Function):
             cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
         acts = [cat]
         split_x = []                                 # split-product experiment (gconv.SPLIT_BF16): each layer input's bf16 planes, kept for its weight gradient
-        for layer, (w, bias) in zip(ups, p_up):
+        planes = None                                # ... and the planes of the previous layer's OUTPUT, written by its epilogue (no split pass)
+        for li, (layer, (w, bias)) in enumerate(zip(ups, p_up)):
             src = acts[-1]
             oh, ow = layer.out_hw(src.shape[1], src.shape[2])
             dst = _empty((b, oh, ow, layer.cout), dev)
-            keep = {}
-            layer.forward(w, bias, View(src), View(dst), EPI_BIAS_RELU, keep=keep)
+            nxt_up = ups[li + 1] if li + 1 < len(ups) else None
+            # the output's planes are worth their stores only if the next layer's forward runs on the split kernels too (k7 d7, Cout > 16)
+            keep, emit = {}, ({} if nxt_up is not None and nxt_up.k == (7, 7) and nxt_up.dil == (7, 7) and nxt_up.cout > 16 else None)
+            layer.forward(w, bias, View(src), View(dst), EPI_BIAS_RELU, keep=keep, xs=planes, emit=emit)
             split_x.append(keep.get("xs"))
+            planes = (emit or {}).get("ys")
             acts.append(dst)
         ctx.split_x = split_x
         u = acts[-1]
@@ -263,18 +267,23 @@ class MergeFn(torch.autograd.Function):
         check(_lib.lib().dd_deconv2x2_c1_bwd(_p(u), _p(w_last), _p(probs), _p(gprobs.contiguous()), _p(gu), _p(dw_last), _p(db_last),
                                              b, u.shape[1], u.shape[2], 8, _p(ws), _stream()), "dd_deconv2x2_c1_bwd")
         g = gu
+        g_planes = None                              # split-product experiment: the bf16 planes of g, when the kernel that produced g wrote them
         g_up = []
         for i in range(nup - 1, -1, -1):
             layer, src = ups[i], acts[i]
-            # split-product experiment: dL/dy is split into its bf16 planes ONCE for the layer's weight and data gradient, the input's
-            # planes come from the forward
-            gs = gconv_split_rows(View(g)) if layer.split_wgrad_ok(View(src), View(g)) else None
-            g_up.append(layer.backward_weight(View(src), View(g), xs=ctx.split_x[i] if gs is not None else None, gs=gs))
+            # split-product experiment: dL/dy's bf16 planes exist ONCE for the layer's weight and data gradient -- written by the
+            # epilogue of the data gradient above it, or by one split pass here; the input's planes come from the forward
+            gs = g_planes
+            if gs is None and layer.split_wgrad_ok(View(src), View(g)):
+                gs = gconv_split_rows(View(g))
+            use_w = gs is not None and layer.split_wgrad_ok(View(src), View(g))
+            g_up.append(layer.backward_weight(View(src), View(g), xs=ctx.split_x[i] if use_w else None, gs=gs if use_w else None))
             gsrc = _empty(src.shape, dev)
+            emit = {} if i > 0 else None             # the concat buffer's gradient (i == 0) goes to layers outside the experiment
             # masks with the producer's ReLU output; in the concat buffer (i == 0) only the slices this node's own ReLUs
             # wrote (ss_deconv 0:32, rm_conv_2 64:96): the spatial-map slice 32:64 is an external input
-            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0), gs=gs)
-            g = gsrc
+            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0), gs=gs, emit=emit)
+            g, g_planes = gsrc, (emit or {}).get("ys")
         g_up.reverse()
         gcat = g                                                                 # [B,256,256,64|96]; slices 0:32 / 64:96 ReLU-masked
         g_space = None

@@ -351,8 +351,9 @@ int64_t dd_dconv_split_packed_bytes(const dd_gconv_desc* d);
 int dd_dconv_split_input(const float* x, void* xs, const dd_gconv_desc* d, void* stream);
 int dd_dconv_split_pack(const float* w, void* packed, const dd_gconv_desc* d, int64_t w_off, int64_t sn, int64_t sc, int32_t flip,
                         int32_t n_real, int32_t c_real, void* stream);
-int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
-                       int32_t epilogue, void* stream);
+int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, const float* mask, float* y, void* y_planes,
+                       const dd_gconv_desc* d, int32_t epilogue, void* stream);      /* y_planes (may be NULL): also write the split image of the
+                       OUTPUT, [batch][out_h][cout / 16][out_w][112 B] as dd_dconv_split_rows would make it of y -- the next layer's operand */
 /* ... and the WEIGHT GRADIENT of the 96->64 / 64->32 layers from the same split images (xs of the layer's input, gs of dL/dy: produced
  * by dd_dconv_split_input or, without a descriptor, dd_dconv_split_rows -- `rows` image rows of `w` pixels, channels [coff, coff + c) of
  * `cstore`, rows * (c / 16) * w * 112 bytes): dw [cin][cout][7][7], per-workgroup partials in `workspace`, fixed-order fp64 second

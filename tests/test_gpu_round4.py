@@ -567,6 +567,33 @@ def test_box_head_model_tests_pass_on_the_split_product_path(dev):
     assert " passed" in tail and "failed" not in tail, tail
 
 
+def test_split_kernels_emit_the_planes_of_their_output(dev):
+    """The forward and the data gradient can write the three-plane bf16 image of their OUTPUT from the epilogue (the next layer's
+    operand): bit for bit what a split pass over the fp32 output gives (the 16 pad bytes of a pixel record are never read and not
+    compared)."""
+    from driving_dirty_amd import gconv, synth
+    for cin, cout, b, h, w in ((96, 64, 2, 9, 256), (64, 32, 1, 5, 298)):
+        layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+        oh, ow = layer.out_hw(h, w)
+        wd = synth.hash_uniform((cin, cout, 7, 7), synth.key_salt("epw"), -0.05, 0.05).to(dev)
+        bd = synth.hash_uniform((cout,), synth.key_salt("epb")).to(dev)
+        x = synth.hash_uniform((b, h, w, cin), synth.key_salt("epx")).to(dev)
+        g = synth.hash_uniform((b, oh, ow, cout), synth.key_salt("epg")).to(dev)
+        old = gconv.SPLIT_BF16
+        gconv.SPLIT_BF16 = True
+        try:
+            y = torch.empty(b, oh, ow, cout, device=dev)
+            ef, eb = {}, {}
+            layer.forward(wd, bd, gconv.View(x), gconv.View(y), gconv.EPI_BIAS_RELU, emit=ef)
+            dx = torch.empty(b, h, w, cin, device=dev)
+            layer.backward_data(wd, gconv.View(g), gconv.View(dx), relu_src=x, emit=eb)
+            for planes, t in ((ef["ys"], y), (eb["ys"], dx)):
+                want = gconv.split_rows(gconv.View(t)).view(-1, 112)[:, :96]
+                assert torch.equal(planes.view(-1, 112)[:, :96], want)
+        finally:
+            gconv.SPLIT_BF16 = old
+
+
 def test_split_product_kernels_are_deterministic(dev):
     """Two launches on the same operands agree bit for bit: the forward adds its partial rows in barrier-separated passes, the data
     gradient has no cross-wave sums, the weight gradient sums its per-workgroup partials in a fixed-order fp64 second stage."""

@@ -60,7 +60,7 @@ def main():
         P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
         t_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(x), P(xs), C.byref(d), st), "in"), a.iters)
         t_pk = timed(lambda: _lib.check(lib.dd_dconv_split_pack(P(w), P(pk), C.byref(d), 0, 49, cout * 49, 1, cout, cin, st), "pk"), a.iters)
-        t_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(xs), P(pk), P(bias), None, P(y1), C.byref(d), gconv.EPI_BIAS_RELU, st), "k"), a.iters)
+        t_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(xs), P(pk), P(bias), None, P(y1), None, C.byref(d), gconv.EPI_BIAS_RELU, st), "k"), a.iters)
         # the data gradient: dx = dilated conv of dy (ReLU mask of the producer fused)
         g = torch.randn(a.batch, oh, ow, cout, device=dev, generator=g0) if False else torch.rand(a.batch, oh, ow, cout, device=dev) - 0.5
         dx0 = torch.empty(a.batch, hw, hw, cin, device=dev)
@@ -77,7 +77,7 @@ def main():
         _lib.check(lib.dd_dconv_split_input(P(g), P(gs), C.byref(dd), st), "in")
         _lib.check(lib.dd_dconv_split_pack(P(w), P(pkd), C.byref(dd), 0, cout * 49, 49, 0, cin, cout, st), "pk")
         td_in = timed(lambda: _lib.check(lib.dd_dconv_split_input(P(g), P(gs), C.byref(dd), st), "in"), a.iters)
-        td_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(gs), P(pkd), None, P(x), P(dx1), C.byref(dd), gconv.EPI_RELU_MASK, st), "k"), a.iters)
+        td_k = timed(lambda: _lib.check(lib.dd_dconv_fwd_split(P(gs), P(pkd), None, P(x), P(dx1), None, C.byref(dd), gconv.EPI_RELU_MASK, st), "k"), a.iters)
         ddiff = float((dx1 - dx0).abs().max() / dx0.abs().max())
         # the weight gradient from the two split images (none of the split passes is repeated: xs comes from the forward, gs from the data gradient)
         def runw(split):
