@@ -107,6 +107,8 @@ PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
 # six bf16 x bf16 products (exact 3-way operand split, fp32 accumulation) on the bf16 matrix pipe.  DD_DCONV_SPLIT=1 or
 # gconv.SPLIT_BF16 = True selects it; the default stays the exact-fp32 MFMA kernels.
 SPLIT_BF16 = os.environ.get("DD_DCONV_SPLIT", "0") == "1"
+# ... its kernels write the bf16 planes of their OUTPUT from the epilogue for the next layer (DD_SPLIT_EMIT=0: a split pass per operand again; A/B)
+SPLIT_EMIT = os.environ.get("DD_SPLIT_EMIT", "1") != "0"
 
 
 def split_rows(view):
@@ -141,7 +143,7 @@ def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real,
             check(lib.dd_dconv_split_input(_p(x), _p(xs), C.byref(d), _stream()), "dd_dconv_split_input")
         check(lib.dd_dconv_split_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_split_pack")
         ys = None
-        if emit is not None and d.cout % 16 == 0 and d.out_coff == 0 and d.ooff_h == 0 and d.ooff_w == 0 and d.omem_h == d.out_h and d.omem_w == d.out_w:
+        if emit is not None and SPLIT_EMIT and d.cout % 16 == 0 and d.out_coff == 0 and d.ooff_h == 0 and d.ooff_w == 0 and d.omem_h == d.out_h and d.omem_w == d.out_w:
             ys = torch.empty(d.batch * d.out_h * (d.cout // 16) * d.out_w * 112, device=x.device, dtype=torch.uint8)
             emit["ys"] = ys
         check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(mask), _p(y), _p(ys), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
