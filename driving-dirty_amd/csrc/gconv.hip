@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
 // weight values a lane needs stay in registers.  Output pixel (2y + a, 2x + b) of phase p = 2a + b: one 128-byte line.
 __global__ __launch_bounds__(256) void deconv2x2_c32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                 const float* __restrict__ bias, float* __restrict__ out,
-                                                                long npix, int w, int relu) {
+                                                                long npix, int w, int relu, int ocs, int ocoff) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, n = lane & 31;
   float bw[4][16];                                       // wt[ci][co][a][b] (IOHW): phase p, k-step s -> ci = s + 16h, co = n
@@ -523,12 +523,12 @@ __global__ __launch_bounds__(256) void deconv2x2_c32_fwd_kernel(const float* __r
       long r = r0;
       if (c >= w) { c -= w; r += 1; }
       if (p0 + off < npix) {
-        float* o = out + ((2 * r) * (2L * w) + 2 * c) * 32 + n;
+        float* o = out + ((2 * r) * (2L * w) + 2 * c) * ocs + ocoff + n;      // channels [ocoff, ocoff + 32) of an ocs-channel buffer
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           float v = acc[p][e] + bv;
           if (relu) v = fmaxf(v, 0.f);
-          o[((p >> 1) * (2L * w) + (p & 1)) * 32] = v;
+          o[((p >> 1) * (2L * w) + (p & 1)) * ocs] = v;
         }
       }
     }
@@ -950,16 +950,22 @@ int dd_channel_sum(const float* buf, float* out, int64_t npix, int32_t cstore, i
   return 0;
 }
 
-int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
-                         void* stream) {
+int dd_deconv2x2_c32_fwd_slice(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
+                               int32_t out_cstore, int32_t out_coff, void* stream) {
   DD_REQUIRE(x && wt && out && batch > 0 && h > 0 && w >= 32, DD_ERR_BAD_ARG, "deconv2x2_c32_fwd: bad argument (width at least 32)");
+  DD_REQUIRE(out_cstore >= 32 && out_coff >= 0 && out_coff + 32 <= out_cstore, DD_ERR_BAD_ARG, "deconv2x2_c32_fwd: output channel slice");
   const long npix = (long)batch * h * w;
   DD_REQUIRE(npix * 128 < (1L << 31), DD_ERR_UNSUPPORTED, "deconv2x2_c32_fwd: input exceeds 2 GB");
   const long ntile = (npix + 31) / 32;
   hipLaunchKernelGGL(deconv2x2_c32_fwd_kernel, dim3((unsigned)min((ntile + 3) / 4, (long)DD_NUM_CU * 8)), dim3(256), 0, (hipStream_t)stream, x, wt,
-                     bias, out, npix, w, relu);
+                     bias, out, npix, w, relu, out_cstore, out_coff);
   DD_LAUNCH_CHECK("deconv2x2_c32_fwd");
   return 0;
+}
+
+int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
+                         void* stream) {
+  return dd_deconv2x2_c32_fwd_slice(x, wt, bias, out, batch, h, w, relu, 32, 0, stream);
 }
 
 int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, void* stream) {

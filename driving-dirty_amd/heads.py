@@ -215,7 +215,10 @@ class MergeFn(torch.autograd.Function):
         ch, cw = 2 * sh, 2 * sw
         assert (ch, cw) == tuple(space.shape[1:3]), "ssr and spatial map must meet at the same size"
         cat = _empty((b, ch, cw, 96 if with_rm else 64), dev)
-        cls.SS_DECONV.forward(p_ssd[0], p_ssd[1], View(s1), View(cat, 0, 32), EPI_BIAS_RELU)
+        if s1.shape[2] >= 32:      # all four phases in one launch, straight into the concat slice
+            ops.deconv2x2_c32_fwd_into(s1, p_ssd[0].contiguous(), p_ssd[1], cat, 0, relu=True)
+        else:
+            cls.SS_DECONV.forward(p_ssd[0], p_ssd[1], View(s1), View(cat, 0, 32), EPI_BIAS_RELU)
         copy_channels(View(space.contiguous()), View(cat, 32, 32))
         r1 = None
         if with_rm:

@@ -232,6 +232,15 @@ def deconv2x2_c32_fwd(x, wt, bias, relu=True):
     return out
 
 
+def deconv2x2_c32_fwd_into(x, wt, bias, out, coff, relu=True):
+    """The same into channels [coff, coff+32) of ``out`` [B,2h,2w,C] NHWC (a concat buffer's slice)."""
+    b, h, w, c = x.shape
+    assert c == 32 and tuple(wt.shape) == (32, 32, 2, 2) and x.is_contiguous() and wt.is_contiguous()
+    assert out.is_contiguous() and tuple(out.shape[:3]) == (b, 2 * h, 2 * w) and 0 <= coff and coff + 32 <= out.shape[3]
+    check(_lib.lib().dd_deconv2x2_c32_fwd_slice(_p(x), _p(wt), _p(bias), _p(out), b, h, w, int(relu), out.shape[3], coff, _stream()),
+          "dd_deconv2x2_c32_fwd_slice")
+
+
 def conv1x1_c32_c3_nchw(x, wt, bias):
     """x [B,h,w,32] NHWC, wt [32,3,1,1] -> ConvTranspose2d k1 [B,3,h,w] NCHW."""
     b, h, w, c = x.shape

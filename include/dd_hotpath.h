@@ -397,6 +397,10 @@ int dd_deconv2x2_c1_bwd(const float* x, const float* wt, const float* probs, con
  * x [batch,h,w,32] NHWC, wt [32,3,1,1], out [batch,3,h,w]. */
 int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
                          int32_t relu, void* stream);
+/* The same into channels [out_coff, out_coff + 32) of an out_cstore-channel NHWC buffer (ss_deconv of the merging heads writes its slice of
+ * the 96-channel concat buffer, spatial_bb/components.py:147,159: one launch instead of four phase launches of the generic engine). */
+int dd_deconv2x2_c32_fwd_slice(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
+                               int32_t out_cstore, int32_t out_coff, void* stream);
 int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
                            void* stream);
 
