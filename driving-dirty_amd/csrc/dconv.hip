@@ -560,6 +560,11 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
 #else
   constexpr int dbg_repeat = 1;
 #endif
+  // rows that are not a whole number of 8 m-tiles (up_conv_2 both ways, up_conv_3's data gradient): several rows per workgroup (dconv_m.hip)
+  if (dd_dconv_mfwd_launch(x, packed, bias, mask, y, d, epilogue, wp_bytes, st)) {
+    DD_LAUNCH_CHECK("dconv_mfwd");
+    return 0;
+  }
   // the full transposed forward of the wide layers: input-aligned tiles, no border zero multiplied (dconv_t.hip)
   if (dd_dconv_tfwd_launch(x, packed, bias, y, d, epilogue, wp_bytes, st)) {
     DD_LAUNCH_CHECK("dconv_tfwd");

@@ -1,0 +1,332 @@
+// Dilated stride-1 convolutions of the box heads in gather form, SEVERAL OUTPUT ROWS PER WORKGROUP ("multi-row"):
+//
+//   RoadMapBoxesMergingCNN  up_conv_2 (64->32, k7 d7)   data gradient (a conv 32->64 over rows of 298 pixels)
+//                           up_conv_3 (32->16, k7 d7)   data gradient (a conv 16->32 over rows of 340)        spatial_bb/components.py:136-137
+//
+// The one-row-per-workgroup kernels of dconv_t.hip give wave w the m-tile w of the row: 298 pixels are 9.3 tiles of 32 (7 % of the
+// tenth multiplies nothing, and ten tiles do not deal evenly to the 8 waves of a workgroup), so these rows stayed on the 64-pixel wave
+// tiles of dconv_fwd_kernel: 0.71-0.77 of the fp32 matrix peak.  In GATHER form the pixel a lane works on enters only through its LDS
+// address -- tap (ky, kx) is a wave-uniform offset on top of it -- so an m-tile may straddle a row boundary for free.  Here a task is R
+// consecutive output rows of one image, its R x out_w pixels are numbered row-major and cut into 32-pixel m-tiles (3 x 298 = 894 =
+// 27.9 tiles -> 28: 0.2 % padding; 3 x 340 = 1020 -> 32 tiles: 0.4 %), and wave w owns tiles w, w + 8, ...: NTW accumulator tiles x NTC
+// column tiles per wave (4 x 2 x 16 = 128 registers); 28 tiles are 7 per SIMD (waves w and w + 4 share one).
+//
+// One step = (tap row ky, 8-channel chunk q): the R input rows oy0 + jr - pad + D*ky (out_w + D(K-1) pixels x 32 B each) AND the step's
+// K*NTC weight fragments (1 KB each, the images dd_dconv_pack writes) sit in LDS, double buffered, filled by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no staging registers, nothing but the fill on the vector-memory counter) a whole step ahead -- across
+// task boundaries too.  Per step a wave issues NTW x K x NTC x 4 MFMAs; a weight fragment is read once per NTW tiles, an A fragment
+// once per 4*NTC MFMAs: one ds_read_b128 per 8 (NTC = 2) or 4 MFMAs, all of it LDS traffic (no global operand load in the loop).
+// Tap rows are the OUTER loop: the chunks of a pixel share its 128-byte lines, and with the chunks outside every 32-byte piece cost
+// its whole line again (13 GB fetched per launch for up_conv_2's data gradient; 10 GB and 4.44 -> 4.28 ms with the chunks inside).
+//
+// Rows are dealt to the workgroups as contiguous ranges of the (image, row) list -- 298 x 32 rows over 256 workgroups = 37.25 rows:
+// twelve full tasks and a remainder of one or two rows, 2 % of imbalance instead of the 8 % of whole tasks.
+//
+// Measured (bs 32, one box, tools/ab_mfwd.py): up_conv_2 data gradient 4.71 -> 4.28 ms (121 -> 133 TF, 0.85 of the fp32 matrix
+// peak), up_conv_3's 1.64 -> 1.51 ms (113 -> 123 TF).  What is left, by ablation builds (tools/build_variant.sh -DMF_ABL_*): the fill
+// 0.22 ms (the same input row is fetched for each of its 7 tap rows: 10 GB per launch at 2.3 TB/s), the mask loads of the write-out
+// 0.11 ms.  Tried and dropped: 6-row tasks with 8 tiles per wave for up_conv_3 (1.58 against 1.52 ms); two 4-wave workgroups per CU
+// on 2-row tasks, out of step with each other (4.75 against 4.61 ms at the time); requesting a tile's mask values a tile ahead of their
+// use (no change once the write-out was a request / retire pair per tile).
+//
+// PADDED (the forward of a transposed layer: flipped taps, pad D(K-1)) is implemented -- tap rows that touch no input row of the task
+// are skipped for the whole workgroup, tap columns that touch no input pixel of a tile for that tile (a 7-bit mask per tile slot),
+// the zero border comes from the buffer range check of the fill -- and correct, but SLOWER than the input-aligned forward of
+// dconv_t.hip (up_conv_2: 6.04 against 5.36 ms: a tile that straddles a row needs nearly every tap column): DD_DCONV_MFWD_PADDED=1
+// turns it on for experiments, nothing dispatches to it by default.
+#include <stdlib.h>
+
+#include "dd_common.h"
+
+namespace {
+
+
+// LDS-DMA fills must have landed (vmcnt) before the barrier publishes the buffer; LDS reads of this step are done (lgkmcnt).
+__device__ __forceinline__ void mf_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct MfTask {
+  int b, oy, rows, ky0, ky1;
+};
+
+template <int K, int D, int NTC, int NTW, int R, int PXP, bool PADDED, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void dconv_mfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, const float* __restrict__ msk,
+                                                                float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
+  constexpr int T = K * K, HALO = D * (K - 1);
+  constexpr int PATCH = PXP * 32;                         // bytes of the pixel image of a step (PXP pixels, a multiple of 32)
+  constexpr int WB = K * NTC * 1024;                      // bytes of the step's weight fragments
+  constexpr int STAGE = PATCH + WB;
+  constexpr int NPI = PATCH / 1024;                       // wave-instructions that fill the pixel image
+  constexpr int NPW = (NPI + NW - 1) / NW, NWW = (K * NTC + NW - 1) / NW;
+  static_assert(PXP % 32 == 0 && 2 * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NC = d.cin >> 3;
+  const int W = d.out_w, RW = W + HALO;                   // pixels of an image row in LDS: input columns [-pad_w, out_w - pad_w + HALO)
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+  const __amdgpu_buffer_rsrc_t ws = dd_rsrc(wp, wp_bytes);
+
+  // ---- fill plan of this thread: pixel-image instruction j = wave + 8i covers the 16-byte pieces 64j .. 64j + 63 (piece p = pixel
+  // p >> 1, channel half p & 1; pixel = jr * RW + lam).  Offsets are relative to input row oy0 - pad_h + D*ky of the image.
+  int poff[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int p = 64 * (wave + NW * i) + lane, px = p >> 1;
+    const int jr = px / RW, ix = px - jr * RW - d.pad_w;
+    poff[i] = (jr < R && (unsigned)ix < (unsigned)d.in_w) ? ((jr * d.in_w + ix) * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : (int)0xC0000000;
+  }
+  // ---- this wave's tile slots: tile t = wave + 8i covers pixels 32t .. 32t + 31 of the task's row-major pixel list
+  int aoff[NTW];                                          // byte offset of this lane's A fragment (tap column 0) in the pixel image
+  int kxmask[NTW];                                        // PADDED: tap columns that touch an input pixel of the tile (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int j = 32 * (wave + NW * i) + (lane & 31);
+    const int jr = (j >= W) + (j >= 2 * W) + (R > 3 ? (j >= 3 * W) + (j >= 4 * W) + (j >= 5 * W) : 0);
+    aoff[i] = ((jr * RW + (j - jr * W)) * 8 + 4 * (lane >> 5)) * 4;
+    int m = 0;
+    if (PADDED) {
+      const int j0 = 32 * (wave + NW * i), j1 = j0 + 31;
+      for (int r = 0; r < R; ++r) {                       // the tile's column range inside row r
+        const int c0 = max(j0 - r * W, 0), c1 = min(j1 - r * W, W - 1);
+        if (c0 > c1) continue;
+        for (int kx = 0; kx < K; ++kx)
+          if (c1 - d.pad_w + D * kx >= 0 && c0 - d.pad_w + D * kx < d.in_w) m |= 1 << kx;
+      }
+    } else {
+      m = (1 << K) - 1;
+    }
+    kxmask[i] = __builtin_amdgcn_readfirstlane(m);
+  }
+
+  // ---- tasks: this workgroup's contiguous range of the (image, output row) list, R rows at a time, never across an image
+  const long units = (long)d.batch * d.out_h;
+  const long u0 = units * blockIdx.x / gridDim.x, u1 = units * (blockIdx.x + 1) / gridDim.x;
+  auto decode = [&](long u, MfTask& k) {
+    k.b = (int)(u / d.out_h);
+    k.oy = (int)(u - (long)k.b * d.out_h);
+    k.rows = (int)min((long)R, min(u1 - u, (long)(d.out_h - k.oy)));
+    k.ky0 = 0;
+    k.ky1 = K - 1;
+    if (PADDED) {      // tap rows with an input row for at least one of the task's rows: iy = oy + jr - pad_h + D*ky in [0, in_h)
+      const int lo = d.pad_h - k.oy - (k.rows - 1), hi = d.in_h - 1 + d.pad_h - k.oy;
+      k.ky0 = lo > 0 ? (lo + D - 1) / D : 0;
+      k.ky1 = hi >= 0 ? min(K - 1, hi / D) : -1;
+      if (k.ky1 < k.ky0) k.ky0 = k.ky1 = 0;               // no input row at all: one tap row of zeros (out-of-range fills)
+    }
+  };
+
+  auto fill = [&](int buf, const MfTask& k, int q, int ky) {
+    char* base = lds + buf * STAGE;
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)k.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    const int rowoff = (k.oy - d.pad_h + D * ky) * d.in_w * d.in_cstore * 4;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int j = wave + NW * i;
+      if (j < NPI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (__attribute__((address_space(3))) void*)(base + j * 1024), 16,
+                                                 (int)((unsigned)poff[i] + (unsigned)rowoff), 32 * q, 0, 0);
+    }
+    const int wrow = (q * T + ky * K) * NTC * 1024;
+#pragma unroll
+    for (int i = 0; i < NWW; ++i) {
+      const int j = ((wave + NW - (NPI % NW)) % NW) + NW * i;      // the waves with the fewest pixel-image instructions first
+      if (j < K * NTC)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (__attribute__((address_space(3))) void*)(base + PATCH + j * 1024), 16, lane * 16,
+                                                 wrow + j * 1024, 0, 0);
+    }
+  };
+
+  if (u0 >= u1) return;
+  MfTask cur, nxt;
+  decode(u0, cur);
+  fill(0, cur, 0, cur.ky0);
+  mf_barrier();
+  int par = 0;
+  long u = u0;
+  while (u < u1) {
+    const long un = u + cur.rows;
+    const bool have_next = un < u1;
+    if (have_next) decode(un, nxt); else nxt = cur;
+    const int npix = cur.rows * W;
+    int nact = 0;                                          // active tile slots of this wave (a prefix: tiles ascend with the slot)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) nact += 32 * (wave + NW * i) < npix ? 1 : 0;
+
+    f32x16 acc[NTW][NTC];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][nt][e] = 0.f;
+
+    // Tap rows outside, channel chunks inside: the NC chunks of an input pixel share its 128-byte lines, and read in consecutive steps
+    // the lines are still in the L2 / the memory-side cache for chunks 1 .. NC-1 (chunks outside: 13 GB fetched per launch for
+    // up_conv_2's data gradient, 7 tap rows x 4 chunks x the 0.47 GB input -- every 32-byte piece cost its whole line again)
+    for (int ky = cur.ky0; ky <= cur.ky1; ++ky) {
+      for (int q = 0; q < NC; ++q) {
+        // ---- the next step's images into the other buffer: next chunk, next tap row, or the next task's first step
+        const bool lastk = ky == cur.ky1, lastq = q + 1 == NC;
+#ifndef MF_ABL_NOFILL
+        if (!lastq) fill(par ^ 1, cur, q + 1, ky);
+        else if (!lastk) fill(par ^ 1, cur, 0, ky + 1);
+        else if (have_next) fill(par ^ 1, nxt, 0, nxt.ky0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+
+        const char* pb = lds + par * STAGE;
+        const char* wb = pb + PATCH + lane * 16;
+        f32x4 Bc[NTC], Bn[NTC], Ac, An = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) Bn[nt] = Bc[nt] = *(const f32x4*)(wb + nt * 1024);
+        Ac = *(const f32x4*)(pb + aoff[0]);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          if (kx + 1 < K) {
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) Bn[nt] = *(const f32x4*)(wb + ((kx + 1) * NTC + nt) * 1024);
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i + 1 < NTW) An = *(const f32x4*)(pb + aoff[i + 1] + kx * (D * 32));
+            else if (kx + 1 < K) An = *(const f32x4*)(pb + aoff[0] + (kx + 1) * (D * 32));
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nact && (!PADDED || ((kxmask[i] >> kx) & 1))) {
+#pragma unroll
+              for (int nt = 0; nt < NTC; ++nt) {
+                acc[i][nt] = DD_MFMA(Ac.x, Bc[nt].x, acc[i][nt]);
+                acc[i][nt] = DD_MFMA(Ac.y, Bc[nt].y, acc[i][nt]);
+                acc[i][nt] = DD_MFMA(Ac.z, Bc[nt].z, acc[i][nt]);
+                acc[i][nt] = DD_MFMA(Ac.w, Bc[nt].w, acc[i][nt]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Ac = An;
+          }
+#pragma unroll
+          for (int nt = 0; nt < NTC; ++nt) Bc[nt] = Bn[nt];
+        }
+        mf_barrier();
+        par ^= 1;
+      }
+    }
+
+    // ---- write-out.  The mask values of a 32 x 32 tile are requested one tile AHEAD of their use (a ring of two), so that a tile's
+    // stores go out while the next tile's mask is on its way: requested and used in the same tile, the eight tiles of a wave cost eight
+    // serial memory round trips with the matrix pipe idle (the whole workgroup is in its epilogue at once).
+    {
+      const int fl = dd_fresh_lane();
+      const int n = fl & 31;
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+#ifdef MF_ABL_NOMASK
+      const bool masked = false;
+#else
+      const bool masked = epi == DD_EPI_RELU_MASK;
+#endif
+      const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
+      // (two named register sets: an array indexed by `blk & 1` went to scratch memory)
+      int offA[16], offB[16];
+      float mvA[16], mvB[16];
+      auto request = [&](int (&off)[16], float (&mv)[16], int blk) {      // offsets and mask values of block blk = (tile slot, column tile)
+        const int i = blk / NTC, nt = blk % NTC;
+        const int ch = nt * 32 + n;
+        const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * (wave + NW * i) + dd_acc_row(r, fl);
+          const int jr = (j >= W) + (j >= 2 * W) + (R > 3 ? (j >= 3 * W) + (j >= 4 * W) + (j >= 5 * W) : 0);
+          const bool ok = i < nact && j < npix && ch < d.cout;
+          off[r] = ok ? (base + (jr * d.omem_w + (j - jr * W)) * d.out_cstore + ch) * 4 : -16;
+          mv[r] = 1.f;
+        }
+        if (masked) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float m = dd_bload1(ms, pass ? -16 : off[r]);
+            mv[r] = pass ? 1.f : m;
+          }
+        }
+      };
+      auto retire = [&](const int (&off)[16], const float (&mv)[16], int blk) {
+        const int i = blk / NTC, nt = blk % NTC;
+        const int ch = nt * 32 + n;
+        float bvn = 0.f;
+        if ((epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && ch < d.cout) bvn = bias[ch];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][nt][r] + bvn;
+          if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          v = mv[r] > 0.f ? v : 0.f;
+          dd_bstore1(ys, off[r], v);
+        }
+      };
+      constexpr int NBLK = NTW * NTC;
+      static_assert(NBLK % 2 == 0, "blocks are retired in pairs");
+#ifdef MF_EPI_RING_OFF
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk) {
+        request(offA, mvA, blk);
+        retire(offA, mvA, blk);
+      }
+#else
+      request(offA, mvA, 0);
+#pragma unroll
+      for (int blk = 0; blk < NBLK; blk += 2) {
+        request(offB, mvB, blk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        retire(offA, mvA, blk);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 2 < NBLK) request(offA, mvA, blk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        retire(offB, mvB, blk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    }
+    cur = nxt;
+    u = un;
+  }
+}
+
+}  // namespace
+
+// Launches the multi-row gather kernel if the layer is one it is built for; false = nothing launched.
+bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                          int epilogue, int wp_bytes, hipStream_t st) {
+  static const bool off = getenv("DD_DCONV_MFWD_OFF") && atoi(getenv("DD_DCONV_MFWD_OFF")) != 0;
+  // the padded (transposed-forward) form is correct but slower than the input-aligned forward of dconv_t.hip (up_conv_2: 6.04 against
+  // 5.36 ms -- tiles that straddle a row need nearly every tap column): an experiment knob, off by default
+  static const bool fwd_too = getenv("DD_DCONV_MFWD_PADDED") && atoi(getenv("DD_DCONV_MFWD_PADDED")) != 0;
+  if (off) return false;
+  if (!dd_dconv_desc_ok(d)) return false;
+  if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU && epilogue != DD_EPI_RELU_MASK) return false;
+  if (epilogue == DD_EPI_RELU_MASK && !mask) return false;
+  if ((epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) && !bias) return false;
+  if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7) return false;
+  if (d->cout <= 16 || d->cout > 64 || d->cin % 8) return false;
+  if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;      // rejected fill offsets stay rejected with a row offset added
+  const bool padded = d->pad_h != 0 || d->pad_w != 0;
+  if (padded && !fwd_too) return false;
+  const int halo = 42;
+  if (!padded && (d->out_h > d->in_h - halo || d->out_w > d->in_w - halo)) return false;
+  const int ntc = (d->cout + 31) / 32;
+  const int rw = d->out_w + halo;
+  const int grid = dd_cu_budget_internal();
+  if (grid < 1) return false;
+#define DD_MF(NTC_, NTW_, R_, PXP_, PAD_, NW_)                                                                                         \
+  do {                                                                                                                               \
+    if (R_ * rw > PXP_ || (R_ * d->out_w + 31) / 32 > NW_ * NTW_) return false;                                                      \
+    hipLaunchKernelGGL((dconv_mfwd_kernel<7, 7, NTC_, NTW_, R_, PXP_, PAD_, NW_>), dim3(grid * (NW_ == 4 ? 2 : 1)), dim3(NW_ * 64),   \
+                       0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes);                                                     \
+    return true;                                                                                                                     \
+  } while (0)
+  if (!padded && ntc == 2) DD_MF(2, 4, 3, 1024, false, 8);      // up_conv_2 data gradient: 3 x 340 = 1020 pixels
+  if (!padded && ntc == 1) DD_MF(1, 4, 3, 1152, false, 8);      // up_conv_3 data gradient: 3 x 382 = 1146 (6-row tasks, 8 tiles per wave: 1.58 against 1.52 ms)
+  if (padded && ntc == 1) DD_MF(1, 4, 3, 1152, true, 8);        // up_conv_2 forward: 3 x (340 + 42) = 1146
+#undef DD_MF
+  return false;
+}

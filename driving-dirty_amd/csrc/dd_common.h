@@ -73,3 +73,6 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
                           int wp_bytes, hipStream_t st);
 bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
                           int epilogue, int wp_bytes, hipStream_t st);
+// dconv_m.hip: gather form with several output rows per workgroup (rows that are not a whole number of 8 m-tiles); false = not one of its layers.
+bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                          int epilogue, int wp_bytes, hipStream_t st);
