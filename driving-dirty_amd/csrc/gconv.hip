@@ -210,20 +210,35 @@ __global__ __launch_bounds__(512) void gconv_fwd_kernel(const float* __restrict_
 
     const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
     const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+    // All mask values of a 32 x 32 tile are requested before the first is used (as in dconv.hip): one conditional load per element made
+    // the compiler wait for each load in turn -- 16 serial memory round trips per column tile, which for the short reductions of the
+    // phase launches (ss_conv's data gradient: 64 MFMAs per tile) was most of the launch.
+    const bool masked = epi == DD_EPI_RELU_MASK;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      const int ch = d.out_coff + nt * 32 + n;      // channels [mask_pass_lo, mask_pass_hi) of the buffer are not ReLU outputs
+      const bool pass = ch >= d.mask_pass_lo && ch < d.mask_pass_hi;
+      int off[16];
+      float mv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int off = out_offset(d, yo, x0 + dd_acc_row(r, lane), nt * 32 + n);
+        off[r] = out_offset(d, yo, x0 + dd_acc_row(r, lane), nt * 32 + n);
+        mv[r] = 1.f;
+      }
+      if (masked) {      // lanes of an exempt channel ask an out-of-range offset (no memory request) and keep 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m = dd_bload1(ms, pass ? -16 : off[r]);
+          mv[r] = pass ? 1.f : m;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         float v = acc[nt][r] + bv[nt];
         if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == DD_EPI_BIAS_SIGMOID) v = 1.f / (1.f + expf(-v));
-        if (epi == DD_EPI_RELU_MASK) {
-          const int ch = d.out_coff + nt * 32 + n;      // channels [mask_pass_lo, mask_pass_hi) of the buffer are not ReLU outputs
-          const bool pass = ch >= d.mask_pass_lo && ch < d.mask_pass_hi;
-          v = (pass || dd_bload1(ms, off) > 0.f) ? v : 0.f;
-        }
-        dd_bstore1(ys, off, v);
+        v = mv[r] > 0.f ? v : 0.f;
+        dd_bstore1(ys, off[r], v);
       }
     }
   }
