@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdd_hotpath.so")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["runtime.hip", "conv3x3.hip", "layout_pool.hip", "dense.hip", "linear.hip", "gconv.hip", "dconv.hip", "dconv_t.hip", "dconv_m.hip", "dconv_split.hip", "conv1ch.hip", "bn2d.hip", "raster.hip",
+SOURCES = ["runtime.hip", "conv3x3.hip", "layout_pool.hip", "dense.hip", "linear.hip", "gconv.hip", "dconv.hip", "dconv_t.hip", "dconv_m.hip", "dconv_split.hip", "conv1ch.hip", "ssconv.hip", "bn2d.hip", "raster.hip",
            "conv3x3_bf16.hip", "mlp_tail.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 HEADERS = [os.path.join(CSRC, "dd_common.h"), os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "dd_hotpath.h")]

@@ -121,6 +121,18 @@ def split_rows(view):
     return xs
 
 
+SSCONV_DGRAD = os.environ.get("DD_SSCONV_DGRAD", "1") != "0"      # A/B knob: 0 = ss_conv's data gradient by seven phase launches
+
+
+def _ops():
+    from . import ops      # ops imports nothing from here; deferred so that either module can be imported first
+    return ops
+
+
+def _p_weight(w):
+    return w if w.is_contiguous() else w.contiguous()
+
+
 def _whole(v):
     """The View covers every pixel of its buffer (the kernels that take whole-buffer dimensions must not be handed a window)."""
     return v.off_h == 0 and v.off_w == 0 and v.h == v.buf.shape[1] and v.w == v.buf.shape[2]
@@ -227,6 +239,11 @@ class Layer:
             if _dconv_ok(d):
                 _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout, xs=gs, emit=emit)
                 return
+        if (not self.transposed and self.k == (1, 24) and self.stride == (1, 7) and self.dil == (1, 1) and self.pad == (0, 0)
+                and self.cin == 32 and self.cout == 32 and relu_src is None and SSCONV_DGRAD and _whole(ddst) and _whole(dsrc)
+                and ddst.coff == 0 and dsrc.coff == 0 and _ops().ssconv_dgrad_ok(ddst.buf, dsrc.buf)):
+            _ops().ssconv_dgrad(ddst.buf, _p_weight(weight), dsrc.buf)      # ss_conv: all seven phases in one launch (csrc/ssconv.hip)
+            return
         if (not self.transposed and self.stride != (1, 1) and self.dil == (1, 1) and self.pad == (0, 0) and cin_out <= 64
                 and PHASED_DGRAD):
             return self._backward_data_phased(weight, ddst, dsrc, relu_src, mask_pass, epi, cos)

@@ -241,6 +241,19 @@ def deconv2x2_c32_fwd_into(x, wt, bias, out, coff, relu=True):
           "dd_deconv2x2_c32_fwd_slice")
 
 
+def ssconv_dgrad_ok(g, dx):
+    """ss_conv's data gradient in one launch serves these tensors: dense 32-channel NHWC, gw = (xw - 24) / 7 + 1 <= 128."""
+    return (g.dim() == 4 and dx.dim() == 4 and g.shape[3] == 32 and dx.shape[3] == 32 and g.is_contiguous() and dx.is_contiguous()
+            and g.shape[:2] == dx.shape[:2] and bool(_lib.lib().dd_ssconv_dgrad_supported(g.shape[1], g.shape[2], dx.shape[2])))
+
+
+def ssconv_dgrad(g, wt, dx):
+    """g [B,h,gw,32], wt [32,32,1,24] (Conv2d weight) -> dx [B,h,xw,32] = dL/d(input) of Conv2d(32,32,(1,24),stride (1,7))."""
+    assert tuple(wt.shape) == (32, 32, 1, 24) and wt.is_contiguous() and ssconv_dgrad_ok(g, dx)
+    b, h, gw, _ = g.shape
+    check(_lib.lib().dd_ssconv_dgrad(_p(g), _p(wt), _p(dx), b, h, gw, dx.shape[2], _stream()), "dd_ssconv_dgrad")
+
+
 def conv1x1_c32_c3_nchw(x, wt, bias):
     """x [B,h,w,32] NHWC, wt [32,3,1,1] -> ConvTranspose2d k1 [B,3,h,w] NCHW."""
     b, h, w, c = x.shape

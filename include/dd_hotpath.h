@@ -401,6 +401,12 @@ int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, flo
  * the 96-channel concat buffer, spatial_bb/components.py:147,159: one launch instead of four phase launches of the generic engine). */
 int dd_deconv2x2_c32_fwd_slice(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
                                int32_t out_cstore, int32_t out_coff, void* stream);
+
+/* Data gradient of ss_conv -- Conv2d(32, 32, (1, 24), stride (1, 7)), spatial_bb/components.py:88,129 (what autograd computes for
+ * F.conv2d's input there) -- in one launch: g [batch, h, gw, 32], w [32, 32, 1, 24] (the layer's weight as it is), dx [batch, h, xw, 32],
+ * all dense NHWC fp32, gw = (xw - 24) / 7 + 1 <= 128.  Every element of dx is written (pixels no tap reaches get 0). */
+int32_t dd_ssconv_dgrad_supported(int32_t h, int32_t gw, int32_t xw);
+int dd_ssconv_dgrad(const float* g, const float* w, float* dx, int32_t batch, int32_t h, int32_t gw, int32_t xw, void* stream);
 int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
                            void* stream);
 

@@ -620,3 +620,62 @@ def test_split_product_kernels_are_deterministic(dev):
         gconv.SPLIT_BF16 = old
     for a, c in zip(*outs):
         assert torch.equal(a, c)
+
+
+# ---- round 4, late: the multi-row gather kernel (csrc/dconv_m.hip), ss_conv's one-launch data gradient (csrc/ssconv.hip)
+
+@pytest.mark.parametrize("cin,cout,b,h,w", [(64, 32, 2, 13, 298), (64, 32, 1, 50, 77), (32, 16, 2, 9, 340), (32, 16, 3, 47, 45)])
+def test_multi_row_data_gradient_against_fp64_and_the_one_row_kernels(dev, cin, cout, b, h, w):
+    """up_conv_2 / up_conv_3 data gradients on the multi-row kernel (tiles that straddle rows, tasks cut at image ends and at the ends of a
+    workgroup's row range, a channel slice with an exempt mask range) against torch fp64 at 2e-5 of the largest value; unwritten
+    elements of the output buffer keep their canary."""
+    import torch.nn.functional as F
+    from driving_dirty_amd import gconv, synth
+    layer = gconv.Layer(cin, cout, 7, dil=7, transposed=True)
+    oh, ow = layer.out_hw(h, w)
+    wd = synth.hash_uniform((cin, cout, 7, 7), synth.key_salt("mrw"), -0.05, 0.05).to(dev)
+    g = synth.hash_uniform((b, oh, ow, cout), synth.key_salt("mrg"), -1.0, 1.0).to(dev)
+    x = synth.hash_uniform((b, h, w, cin), synth.key_salt("mrx"), -1.0, 1.0).to(dev)
+    ref = F.conv2d(g.permute(0, 3, 1, 2).double(), wd.double(), dilation=7).permute(0, 2, 3, 1)
+    for masked in (False, True):
+        buf = torch.full((b, h, w, cin + 8), 7.0, device=dev)                      # the layer's slice sits at channel offset 4
+        src = torch.zeros_like(buf)
+        src[..., 4:4 + cin] = x
+        lo, hi = 4 + cin // 2, 4 + cin                                             # the upper half of the slice is exempt from the mask
+        layer.backward_data(wd, gconv.View(g), gconv.View(buf, 4, cin), relu_src=src if masked else None, mask_pass=(lo, hi) if masked else (0, 0))
+        want = ref.clone()
+        if masked:
+            keep = (x > 0).double()
+            keep[..., cin // 2:] = 1.0
+            want = want * keep
+        err = (buf[..., 4:4 + cin].double() - want).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, (masked, err)
+        assert torch.all(buf[..., :4] == 7.0) and torch.all(buf[..., 4 + cin:] == 7.0)
+
+
+@pytest.mark.parametrize("b,h,xw", [(2, 5, 918), (3, 7, 311), (1, 128, 24), (2, 3, 919)])
+def test_ss_conv_data_gradient_in_one_launch(dev, b, h, xw):
+    """csrc/ssconv.hip against torch fp64 (the transposed convolution autograd runs for F.conv2d's input, components.py:129) and against
+    the seven phase launches of the generic engine: full width, a narrow image, a single tap position, trailing pixels no tap reaches."""
+    import torch.nn.functional as F
+    from driving_dirty_amd import gconv, synth
+    layer = gconv.Layer(32, 32, (1, 24), stride=(1, 7))
+    gw = (xw - 24) // 7 + 1
+    wt = synth.hash_uniform((32, 32, 1, 24), synth.key_salt("ssw"), -0.1, 0.1).to(dev)
+    g = synth.hash_uniform((b, h, gw, 32), synth.key_salt("ssg"), -1.0, 1.0).to(dev)
+    ref = F.conv_transpose2d(g.permute(0, 3, 1, 2).double(), wt.double(), stride=(1, 7))
+    ref = F.pad(ref, (0, xw - ref.shape[3])).permute(0, 2, 3, 1)
+    outs = []
+    old = gconv.SSCONV_DGRAD
+    try:
+        for on in (True, False):
+            gconv.SSCONV_DGRAD = on
+            dx = torch.full((b, h, xw, 32), float("nan"), device=dev)
+            layer.backward_data(wt, gconv.View(g), gconv.View(dx))
+            outs.append(dx)
+    finally:
+        gconv.SSCONV_DGRAD = old
+    scale = ref.abs().max().item()
+    for dx in outs:
+        assert (dx.double() - ref).abs().max().item() / scale < 2e-6
+    assert (outs[0] - outs[1]).abs().max().item() / scale < 2e-6
