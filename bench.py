@@ -683,7 +683,7 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
                                  "up_conv_1_dgrad": "dconv_gfwd_kernel (up_conv_1 data gradient)",
                                  "up_conv_1_wgrad": "dconv_wgrad_kernel (up_conv_1 weight gradient)",
                                  "up_conv_2_fwd": "dconv_tfwd_kernel (up_conv_2 forward)",
-                                 "up_conv_2_dgrad": "dconv_mfwd_kernel (up_conv_2 data gradient, gather form, 3 rows per task)",
+                                 "up_conv_2_dgrad": "dconv_mwin_kernel (up_conv_2 data gradient, gather form, 3 phase rows per task)",
                                  "up_conv_2_wgrad": "dconv_wgrad_kernel (up_conv_2 weight gradient)"}[key],
                          bound="mfma", achieved=round(flop / (ms * 1e-3) / 1e12, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                          frac=round(flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4))

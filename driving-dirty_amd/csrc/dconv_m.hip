@@ -23,9 +23,9 @@
 // twelve full tasks and a remainder of one or two rows, 2 % of imbalance instead of the 8 % of whole tasks.
 //
 // Measured (bs 32, one box, tools/ab_mfwd.py): up_conv_2 data gradient 4.71 -> 4.28 ms (121 -> 133 TF, 0.85 of the fp32 matrix
-// peak), up_conv_3's 1.64 -> 1.51 ms (113 -> 123 TF).  What is left, by ablation builds (tools/build_variant.sh -DMF_ABL_*): the fill
-// 0.22 ms (the same input row is fetched for each of its 7 tap rows: 10 GB per launch at 2.3 TB/s), the mask loads of the write-out
-// 0.11 ms.  Tried and dropped: 6-row tasks with 8 tiles per wave for up_conv_3 (1.58 against 1.52 ms); two 4-wave workgroups per CU
+// peak), up_conv_3's 1.64 -> 1.51 ms (113 -> 123 TF).  What is left, by ablation builds (tools/build_variant.sh -DMF_ABL_*): the fills
+// 0.22 ms, the mask loads of the write-out 0.11 ms.  This kernel fetches every input row once per tap row (10 GB per launch for
+// up_conv_2); dconv_mwin_kernel below -- the one the launcher picks for the data gradients -- removes that (5.9 GB) at the same time.  Tried and dropped: 6-row tasks with 8 tiles per wave for up_conv_3 (1.58 against 1.52 ms); two 4-wave workgroups per CU
 // on 2-row tasks, out of step with each other (4.75 against 4.61 ms at the time); requesting a tile's mask values a tile ahead of their
 // use (no change once the write-out was a request / retire pair per tile).
 //
@@ -292,6 +292,236 @@ __global__ __launch_bounds__(NW * 64, 2) void dconv_mfwd_kernel(const float* __r
   }
 }
 
+
+// =====================================================================================================================
+// The same tiles with PHASE ROWS and a SLIDING WINDOW (pad 0: the data gradients).  Above, a task's R rows are consecutive, so each
+// of its K tap rows needs R rows of its own: every input row is fetched K times (10 GB per launch for up_conv_2's data gradient,
+// 5.7 x its algorithmic bytes).  Rows of equal residue oy mod D share their input rows (taps are D rows apart): a task here is R
+// consecutive rows of ONE residue class, oy = res + D(a0 + jr), and tap row ky of row jr reads input row res + D(a0 + jr + ky) --
+// "sweep row" p = jr + ky.  Step ky multiplies the window p = ky .. ky + R - 1 and needs ONE new row for step ky + 1: K - 1 + R rows per
+// sweep for R x K (row, tap row) pairs (9 instead of 21).  The rows live in a ring of 2R slots (slot = running row index mod 2R:
+// R in use, one arriving, R - 1 of the next sweep -- the next chunk's, or the next task's -- arriving during the last R steps), the
+// lane's A address is recomputed per step from its row jr (two conditional subtracts per tile), everything else is the kernel above.
+struct MwTask {
+  int b, res, a0, rows;
+};
+
+template <int K, int D, int NTC, int NTW, int R, int IWP>
+__global__ __launch_bounds__(512, 2) void dconv_mwin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                            const float* __restrict__ bias, const float* __restrict__ msk,
+                                                            float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
+  constexpr int T = K * K;
+  constexpr int NSLOT = 2 * R, SWEEP = K - 1 + R;
+  constexpr int ROWB = IWP * 32;                          // bytes of a row image (IWP pixels x one 8-channel chunk)
+  constexpr int WB = K * NTC * 1024;
+  constexpr int NRI = ROWB / 1024, NRW = (NRI + 7) / 8, NWW = (K * NTC + 7) / 8;
+  static_assert(IWP % 32 == 0 && NSLOT * ROWB + 2 * WB <= 160 * 1024, "LDS");
+  static_assert(R == 3, "the row of a pixel index is found with two comparisons");
+  __shared__ __attribute__((aligned(1024))) char lds[NSLOT * ROWB + 2 * WB];
+  char* const ring = lds;
+  char* const wbuf = lds + NSLOT * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NC = d.cin >> 3;
+  const int W = d.out_w;
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+  const int row_bytes = d.in_w * d.in_cstore * 4;
+  const __amdgpu_buffer_rsrc_t ws = dd_rsrc(wp, wp_bytes);
+
+  // ---- fill plan: row-image instruction j = wave + 8i covers the 16-byte pieces 64j .. 64j + 63 (piece p = pixel p >> 1, channel half p & 1)
+  int poff[NRW];
+#pragma unroll
+  for (int i = 0; i < NRW; ++i) {
+    const int p = 64 * (wave + 8 * i) + lane, px = p >> 1;
+    poff[i] = px < d.in_w ? (px * d.in_cstore + d.in_coff + 4 * (p & 1)) * 4 : (int)0xC0000000;
+  }
+  // ---- this wave's tile slots: tile t = wave + 8i covers pixels 32t .. 32t + 31 of the task's row-major pixel list
+  int jrow[NTW], cb[NTW];                                 // this lane's row of the task and byte offset inside a row image (tap column 0)
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int j = 32 * (wave + 8 * i) + (lane & 31);
+    jrow[i] = (j >= W) + (j >= 2 * W);
+    cb[i] = ((j - jrow[i] * W) * 8 + 4 * (lane >> 5)) * 4;
+  }
+
+  // ---- tasks: this workgroup's contiguous range of the (image, residue class, phase row) list, R rows at a time inside a class
+  const long units = (long)d.batch * d.out_h;
+  const long u0 = units * blockIdx.x / gridDim.x, u1 = units * (blockIdx.x + 1) / gridDim.x;
+  auto decode = [&](long u, MwTask& k) {
+    k.b = (int)(u / d.out_h);
+    int rem = (int)(u - (long)k.b * d.out_h), res = 0, n = (d.out_h + D - 1) / D;
+    while (rem >= n) {                                    // classes 0 .. D-1 hold ceil((out_h - res) / D) rows each
+      rem -= n;
+      ++res;
+      n = (d.out_h - res + D - 1) / D;
+    }
+    k.res = res;
+    k.a0 = rem;
+    k.rows = (int)min((long)R, min(u1 - u, (long)(n - rem)));
+  };
+  auto fill_row = [&](int slot, const MwTask& k, int p, int q) {      // sweep row p of chunk q of task k into ring slot `slot`
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)k.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    // (a sweep row past the image -- only rows the task does not have read it -- is out of the image's range: zeros, no fault)
+    const int rowoff = (k.res + D * (k.a0 + p)) * row_bytes;
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+      const int j = wave + 8 * i;
+      if (j < NRI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (__attribute__((address_space(3))) void*)(ring + slot * ROWB + j * 1024), 16,
+                                                 (int)((unsigned)poff[i] + (unsigned)rowoff), 32 * q, 0, 0);
+    }
+  };
+  auto fill_w = [&](int buf, int q, int ky) {
+    const int wrow = (q * T + ky * K) * NTC * 1024;
+#pragma unroll
+    for (int i = 0; i < NWW; ++i) {
+      const int j = ((wave + 8 - (NRI & 7)) & 7) + 8 * i;      // the waves with the fewest row-image instructions first
+      if (j < K * NTC)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (__attribute__((address_space(3))) void*)(wbuf + buf * WB + j * 1024), 16, lane * 16,
+                                                 wrow + j * 1024, 0, 0);
+    }
+  };
+  auto slot_of = [&](int idx) { return idx % NSLOT; };
+
+  if (u0 >= u1) return;
+  MwTask cur, nxt;
+  decode(u0, cur);
+  int sbase = 0;                                            // ring slot of sweep row 0 of the current sweep
+#pragma unroll
+  for (int p = 0; p < R; ++p) fill_row(p, cur, p, 0);
+  fill_w(0, 0, 0);
+  mf_barrier();
+  int par = 0;
+  long u = u0;
+  while (u < u1) {
+    const long un = u + cur.rows;
+    const bool have_next = un < u1;
+    if (have_next) decode(un, nxt); else nxt = cur;
+    const int npix = cur.rows * W;
+    int nact = 0;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) nact += 32 * (wave + 8 * i) < npix ? 1 : 0;
+
+    f32x16 acc[NTW][NTC];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][nt][e] = 0.f;
+
+    for (int q = 0; q < NC; ++q) {
+      const bool lastq = q + 1 == NC;
+      const bool next_sweep = !lastq || have_next;
+      for (int ky = 0; ky < K; ++ky) {
+        // ---- fills: the row step ky + 1 adds to the window; during the last R steps the first rows of the next sweep; the next weights
+        if (ky + 1 < K) {
+          fill_row(slot_of(sbase + ky + R), cur, ky + R, q);
+          fill_w(par ^ 1, q, ky + 1);
+        } else if (next_sweep) {
+          fill_w(par ^ 1, lastq ? 0 : q + 1, 0);
+        }
+        if (ky >= K - R && next_sweep) {
+          const int p2 = ky - (K - R);
+          if (lastq) fill_row(slot_of(sbase + SWEEP + p2), nxt, p2, 0);
+          else fill_row(slot_of(sbase + SWEEP + p2), cur, p2, q + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        int abase[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          int t = sbase + ky + jrow[i];                     // < 3 * NSLOT
+          t -= t >= NSLOT ? NSLOT : 0;
+          t -= t >= NSLOT ? NSLOT : 0;
+          abase[i] = t * ROWB + cb[i];
+        }
+        const char* wb = wbuf + par * WB + lane * 16;
+        f32x4 Bc[NTC], Bn[NTC], Ac, An = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) Bn[nt] = Bc[nt] = *(const f32x4*)(wb + nt * 1024);
+        Ac = *(const f32x4*)(ring + abase[0]);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          if (kx + 1 < K) {
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) Bn[nt] = *(const f32x4*)(wb + ((kx + 1) * NTC + nt) * 1024);
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (i + 1 < NTW) An = *(const f32x4*)(ring + abase[i + 1] + kx * (D * 32));
+            else if (kx + 1 < K) An = *(const f32x4*)(ring + abase[0] + (kx + 1) * (D * 32));
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nact) {
+#pragma unroll
+              for (int nt = 0; nt < NTC; ++nt) {
+                acc[i][nt] = DD_MFMA(Ac.x, Bc[nt].x, acc[i][nt]);
+                acc[i][nt] = DD_MFMA(Ac.y, Bc[nt].y, acc[i][nt]);
+                acc[i][nt] = DD_MFMA(Ac.z, Bc[nt].z, acc[i][nt]);
+                acc[i][nt] = DD_MFMA(Ac.w, Bc[nt].w, acc[i][nt]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Ac = An;
+          }
+#pragma unroll
+          for (int nt = 0; nt < NTC; ++nt) Bc[nt] = Bn[nt];
+        }
+        mf_barrier();
+        par ^= 1;
+      }
+      sbase = (sbase + SWEEP) % NSLOT;
+    }
+
+    // ---- write-out: a request / retire pair per tile (all offsets and mask values of a 32 x 32 tile before the first is used)
+    {
+      const int fl = dd_fresh_lane();
+      const int n = fl & 31;
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const __amdgpu_buffer_rsrc_t ms = dd_rsrc(msk ? msk + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore : y, msk ? out_bytes : 0);
+      const bool masked = epi == DD_EPI_RELU_MASK;
+      const int row0 = cur.res + D * cur.a0 + d.ooff_h;
+#pragma unroll
+      for (int blk = 0; blk < NTW * NTC; ++blk) {
+        const int i = blk / NTC, nt = blk % NTC;
+        const int ch = nt * 32 + n;
+        const bool pass = d.out_coff + ch >= d.mask_pass_lo && d.out_coff + ch < d.mask_pass_hi;
+        int off[16];
+        float mv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * (wave + 8 * i) + dd_acc_row(r, fl);
+          const int jr = (j >= W) + (j >= 2 * W);
+          const bool ok = i < nact && j < npix && ch < d.cout;
+          off[r] = ok ? (((row0 + D * jr) * d.omem_w + d.ooff_w + (j - jr * W)) * d.out_cstore + d.out_coff + ch) * 4 : -16;
+          mv[r] = 1.f;
+        }
+        if (masked) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float m = dd_bload1(ms, pass ? -16 : off[r]);
+            mv[r] = pass ? 1.f : m;
+          }
+        }
+        float bvn = 0.f;
+        if ((epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) && ch < d.cout) bvn = bias[ch];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][nt][r] + bvn;
+          if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          v = mv[r] > 0.f ? v : 0.f;
+          dd_bstore1(ys, off[r], v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    cur = nxt;
+    u = un;
+  }
+}
+
 }  // namespace
 
 // Launches the multi-row gather kernel if the layer is one it is built for; false = nothing launched.
@@ -324,6 +554,18 @@ bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias
                        0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes);                                                     \
     return true;                                                                                                                     \
   } while (0)
+  static const bool window = !(getenv("DD_DCONV_MWIN_OFF") && atoi(getenv("DD_DCONV_MWIN_OFF")) != 0);
+#define DD_MW(NTC_, IWP_)                                                                                                            \
+  do {                                                                                                                               \
+    if (d->in_w <= IWP_ && 3 * d->out_w <= 1024 && d->out_w + halo <= IWP_ && d->out_h >= 7) {                                        \
+      hipLaunchKernelGGL((dconv_mwin_kernel<7, 7, NTC_, 4, 3, IWP_>), dim3(grid), dim3(512), 0, st, x, packed, bias, mask, y, *d,    \
+                         epilogue, wp_bytes);                                                                                        \
+      return true;                                                                                                                   \
+    }                                                                                                                                \
+  } while (0)
+  if (!padded && window && ntc == 2) DD_MW(2, 384);        // up_conv_2 data gradient: phase rows, one new input row per step
+  if (!padded && window && ntc == 1) DD_MW(1, 384);        // up_conv_3 data gradient
+#undef DD_MW
   if (!padded && ntc == 2) DD_MF(2, 4, 3, 1024, false, 8);      // up_conv_2 data gradient: 3 x 340 = 1020 pixels
   if (!padded && ntc == 1) DD_MF(1, 4, 3, 1152, false, 8);      // up_conv_3 data gradient: 3 x 382 = 1146 (6-row tasks, 8 tiles per wave: 1.58 against 1.52 ms)
   if (padded && ntc == 1) DD_MF(1, 4, 3, 1152, true, 8);        // up_conv_2 forward: 3 x (340 + 42) = 1146

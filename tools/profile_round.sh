@@ -31,7 +31,7 @@ python3 tools/pmc_traffic.py $O/fetch $O/write gpurun_out/${R}_c2_dgrad_w1_traff
 python3 tools/pmc_traffic_any.py $O/up_fetch $O/up_write gpurun_out/${R}_upconv_traffic.json \
   'dconv_tfwd_kernel<7, 7, 7, 0=1532755968:up_conv_1 forward' 'dconv_gfwd_kernel<7, 7, 3=2338062336:up_conv_1 data gradient' \
   'dconv_wgrad_kernel<7, 7, 96, 64=1532755968:up_conv_1 weight gradient' \
-  'dconv_tfwd_kernel<7, 7, 9, 1=1200947200:up_conv_2 forward' 'dconv_mfwd_kernel<7, 7, 2=1928396800:up_conv_2 data gradient' \
+  'dconv_tfwd_kernel<7, 7, 9, 1=1200947200:up_conv_2 forward' 'dconv_mwin_kernel<7, 7, 2=1928396800:up_conv_2 data gradient' \
   'dconv_wgrad_kernel<7, 7, 64, 32=1200947200:up_conv_2 weight gradient' > $O/traffic_up.log 2>&1
 cp profiles/${R}_*_kernel_stats.csv gpurun_out/ 2>/dev/null
 for f in $O/*_sum.log $O/traffic_*.log; do tail -n 2 $f; done
