@@ -71,6 +71,10 @@ def parse_args():
                     help="N > 1: reduce-scatter + Adam on the owned 1/N + all-gather under the next forward (on) instead of all-reduce + "
                     "replicated Adam (off).  auto = on for the configs with a big gradient message (2, 4, 5: 0.65 / 0.65 / 2.09 GB -- the budget "
                     "of DESIGN.md section 6 favours it at every N and link speed), off for 3 (2 MB of head gradients)")
+    ap.add_argument("--factor-linear", choices=("auto", "on", "off"), default="auto",
+                    help="data parallel: the big Linear layers all-gather their factors (input, output gradient: 202 MB per rank) instead "
+                         "of reducing their weight gradients (648 MB); every rank forms the global-batch gradient itself.  auto = on at "
+                         "N = 2 (one xGMI link carries the whole message), where it replaces the sharded optimizer")
     ap.add_argument("--simulate-shard", type=int, default=0, metavar="N",
                     help="one GPU, timing only: the COMPUTE side of an N-GPU sharded step (Adam on rank 0's 1/N of every big tensor, no "
                     "collectives; the parameters it leaves are meaningless) -- the per-GPU lower bound of the N-GPU step")
@@ -925,8 +929,12 @@ def run_rank(a):
     # The optimizer and the gradient synchronisation are built over the model AS CONSTRUCTED -- feature extractor still frozen
     # (roadmap_bce_v2.py:45-47, spatial_w_rm.py:45-48): the first training_step unfreezes it where the config says so, and
     # LightningModule.unfreeze() re-arms both (driving_dirty_amd.train.TrainStep = HipAdam + GradSync, the step of this benchmark).
+    # N = 2: the factors of the two big Linear layers instead of their gradients: replicated optimizer, no shards
+    factor = comm and {"on": True, "off": False, "auto": world == 2 and a.config in (2, 4, 5) and a.shard_optimizer != "on"}[a.factor_linear]
+    if factor:
+        shard = False
     ts = TrainStep(model, lr=1e-3, adam_overlap=overlap, shard_optimizer=shard, reserve_cus=reserve, force_collectives=rehearse,
-                   simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False)
+                   simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False, factor_linear=factor)
     if a.config == 2:
         timer = KernelTimer()
     else:
@@ -988,7 +996,9 @@ def run_rank(a):
                              "tensor, no collectives; a per-GPU lower bound, not a training step (parameters meaningless)"} if a.simulate_shard > 1 else {}),
             "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
-                       "adam_overlap": bool(overlap), "optimizer": "sharded (reduce-scatter, Adam on 1/N, all-gather)" if shard else "replicated"},
+                       "adam_overlap": bool(overlap), "optimizer": "sharded (reduce-scatter, Adam on 1/N, all-gather)" if shard else
+                       ("replicated; the big Linear layers all-gather their factors, every rank forms the global-batch gradient" if factor
+                        else "replicated")},
             # the step's algorithmic flops over its time, against the dense matrix peak of the dtype its convolutions run in
             ("step_algorithmic_frac_of_bf16_mfma_peak" if cfg["dtype"] == "bf16" else "step_algorithmic_frac_of_fp32_mfma_peak"):
                 round(cfg["flop_per_scene"] * per_gpu * world / (ms * 1e-3) / 1e12

@@ -44,6 +44,19 @@ tensor's device pointer).  Same bytes on the links per step (RS + AG = AR), but 
 the arithmetic is elementwise: the replicas hold bit-for-bit the parameters of the all-reduce path whenever the backend's
 reduce-scatter adds in the order of its all-reduce (gloo: always; tests/test_ddp_gloo.py, world sizes 2 and 4).  In shard mode
 ``p.grad`` of a sharded tensor keeps THIS rank's local gradient; the reduced gradient exists only as ``shards(p)``.
+Factor gather (``factor_linear=True``; round 4, for 2 <= world <= 4).  The weight gradient of a Linear layer over an m-row batch is a
+rank-m product, dW = dY^T X, and for the two tensors that ARE the message here the factors are far smaller than the product: the
+encoder's ``fc1.fc1`` has 120 MB of pooled activations X (32 x 940032) and 16 KB of dY against a 481 MB gradient, the head 8 KB of X
+and 82 MB of dlogits against 164 MB.  ``ops.Linear.backward`` hands X and dY to ``linear_factors`` instead of forming its local dW;
+both are ALL-GATHERED over the batch dimension (asynchronously, under the rest of the backward) and every rank forms the
+global-batch gradient itself (``HipAdam``: the weight-gradient kernel over world x m rows, then the replicated Adam pass, on its side
+stream behind the gathers).  Bytes received per rank: (world - 1) x 202 MB instead of 2 x (world - 1) / world x 648 MB -- 202 against
+648 MB at world 2, where ONE xGMI link carries everything and no schedule hides 648 MB under a 7.6 ms step; 606 against 972 at 4;
+1414 against 1134 at 8, where the reduce-scatter wins.  Same products as the all-reduce path, summed in a
+different order (one GEMM over the global batch instead of a sum of per-rank GEMMs); every rank computes from identical gathered
+factors with a deterministic kernel, so the replicas stay bit-identical to EACH OTHER.  The bias gradients and everything else travel
+as before.
+
 ``simulate_world=N`` (one process, no communicator) cuts the shards of rank 0 of an N-rank job out of the local gradient and skips
 the gather: the COMPUTE side of an N-GPU sharded step on one GPU -- a timing aid (`bench.py --simulate-shard N`), the parameters
 it leaves are meaningless.
@@ -66,6 +79,19 @@ def param_ready(t):
             wait()
 
 
+# data_ptr of a Linear weight -> GradSync in factor mode: ops.Linear.backward hands its factors over instead of forming dW
+FACTOR_SYNC = {}
+
+
+class Factors:
+    """The gathered factors of one Linear weight gradient: dW = dy_all^T x_all over ``rows`` = world x m rows, valid once every
+    handle in ``works`` has been waited for."""
+    __slots__ = ("works", "x_all", "dy_all", "rows")
+
+    def __init__(self, works, x_all, dy_all, rows):
+        self.works, self.x_all, self.dy_all, self.rows = works, x_all, dy_all, rows
+
+
 class Shard:
     """One piece's slice owned by this rank: ``param`` = flat view of p.data[lo:hi] (updated in place by the optimizer),
     ``grad`` = the summed gradient of exactly those elements, valid once ``work`` (None: already there) has been waited for."""
@@ -78,7 +104,7 @@ class Shard:
 
 class GradSync:
     def __init__(self, module, process_group=None, big_numel=1 << 20, chunk_numel=1 << 25, reserve_cus=0, force_collectives=False,
-                 shard_optimizer=False, simulate_world=0):
+                 shard_optimizer=False, simulate_world=0, factor_linear=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -90,6 +116,13 @@ class GradSync:
         self.shard = bool(shard_optimizer) and (self.active or self.simulate_world > 0)
         self.shard_world = self.simulate_world if self.simulate_world else self.world
         self.big_numel = big_numel
+        # factor mode: big Linear weights send their factors (all-gather over the batch) instead of their gradients; not with shards
+        self.factor = bool(factor_linear) and self.active and not self.shard
+        self._factors = {}         # p -> Factors of the latest backward, until the optimizer takes them
+        self._fbuf = {}            # p -> (x_all, dy_all): persistent gather targets
+        self._fkeys = {}           # data_ptr -> p
+        self._xwork = {}           # p -> (work, data_ptr, rows) of an input gather started in the forward
+        self.on_factors = None     # callback(p): the optimizer queues its early update (HipAdam.attach)
         self.chunk_numel = max(4, chunk_numel - chunk_numel % 4)      # pieces start on 16-byte boundaries
         if self.shard:      # every piece splits into shard_world slices of whole 16-byte groups
             q = 4 * self.shard_world
@@ -127,6 +160,66 @@ class GradSync:
             if p.requires_grad and p not in self._hooked:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 self._hooked.add(p)
+                if self.factor and p.dim() == 2 and p.numel() >= self.big_numel and p.data.is_contiguous():
+                    FACTOR_SYNC[p.data_ptr()] = self
+                    self._fkeys[p.data_ptr()] = p
+
+    # ---- factor mode ------------------------------------------------------------------------------------------------------
+    def _factor_bufs(self, p, m, k, n, like):
+        w = self.world
+        bufs = self._fbuf.get(p)
+        if bufs is None or bufs[0].shape != (w * m, k) or bufs[1].shape != (w * m, n) or bufs[0].device != like.device:
+            bufs = self._fbuf[p] = (torch.empty((w * m, k), device=like.device, dtype=like.dtype),
+                                    torch.empty((w * m, n), device=like.device, dtype=like.dtype))
+        return bufs
+
+    def linear_input(self, weight, x):
+        """Called by ``ops.Linear.forward`` (training, factor mode): an input of >= big_numel elements starts its all-gather right
+        away -- it is known a forward-tail and a backward-head earlier than the layer's output gradient."""
+        p = self._fkeys.get(weight.data_ptr())
+        if p is None or not self.factor or x.numel() < self.big_numel or not x.is_contiguous():
+            return
+        bufs = self._factor_bufs(p, x.shape[0], x.shape[1], weight.shape[0], x)
+        if self.reserve_cus and not self._reserved:
+            self._set_budget(256 - self.reserve_cus)
+            self._reserved = True
+        work = self._all_gather(bufs[0], x)
+        self._handles.append(work)
+        self._xwork[p] = (work, x.data_ptr(), x.shape[0])
+
+    def linear_factors(self, weight, x, dy):
+        """Called by ``ops.Linear.backward`` (on the backward's stream) for a weight registered in FACTOR_SYNC: start the all-gathers
+        of the layer's input ``x`` [m, k] and output gradient ``dy`` [m, n] over the batch dimension and return True -- the caller
+        then forms NO local weight gradient (``weight.grad`` stays None; the optimizer computes the global-batch gradient from
+        ``take_factors``).  False: not in factor mode for this tensor, the caller proceeds as usual."""
+        p = self._fkeys.get(weight.data_ptr())
+        if p is None or not self.factor:
+            return False
+        m, w = x.shape[0], self.world
+        x, dy = x.contiguous(), dy.contiguous()
+        bufs = self._factor_bufs(p, m, x.shape[1], dy.shape[1], x)
+        if self.reserve_cus and not self._reserved:
+            self._set_budget(256 - self.reserve_cus)
+            self._reserved = True
+        early = self._xwork.pop(p, None)
+        if early is not None and early[1] == x.data_ptr() and early[2] == m:      # this x is already on the links (linear_input)
+            works = [early[0], self._all_gather(bufs[1], dy)]
+            self._handles.append(works[1])
+        else:
+            works = [self._all_gather(bufs[0], x), self._all_gather(bufs[1], dy)]
+            self._handles.extend(works)
+        self._factors[p] = Factors(works, bufs[0], bufs[1], w * m)
+        if self.on_factors is not None:
+            self.on_factors(p)
+        return True
+
+    def has_factors(self, p):
+        return p in self._factors
+
+    def take_factors(self, p):
+        """The gathered factors of ``p`` from the latest backward (None: p did not travel as factors); the caller waits for
+        ``works`` on the stream that will read them."""
+        return self._factors.pop(p, None)
 
     @property
     def grad_scale(self):
@@ -301,5 +394,10 @@ class GradSync:
         self._hooked = set()
         self._pre_hooked = set()
         self._shards, self._gshard = {}, {}
+        for key in list(self._fkeys):
+            if FACTOR_SYNC.get(key) is self:
+                del FACTOR_SYNC[key]
+        self._fkeys, self._factors, self._fbuf, self._xwork = {}, {}, {}, {}
+        self.factor = False
         self.active = False
         self.shard = False

@@ -556,6 +556,10 @@ def pool4_relu_bwd(dpooled, feat):
 # at bs = 32 that use a third of the HBM bandwidth): the place to start bandwidth-bound side work such as the
 # optimizer pass of already-finished gradients (optim.HipAdam.overlap_with_backward).
 MFMA_PHASE_HOOKS = []
+# ... and fired again between c2's weight gradient and its data gradient, ~1.2 ms later: the place for work that has to WAIT for
+# something started at the top of the backward (factor mode of ddp.GradSync: the gathered factors of the two big Linear layers).
+MFMA_PHASE2_HOOKS = []
+C2_DGRAD_FIRST = False      # c2's data gradient before its weight gradient (same results; see EncoderConvStack.backward)
 
 # c1's weight gradient taken from c2's data gradient inside conv_wino2_fwd<EPI_RELU_BITS_W1> (2-D Winograd path only)
 FUSE_C1_WGRAD = os.environ.get("DD_FUSE_C1_WGRAD", "1") != "0"
@@ -683,25 +687,45 @@ class EncoderConvStack(torch.autograd.Function):
             for hook in MFMA_PHASE_HOOKS:
                 hook()
             reduced = None
-            if need[3] or need[4]:
-                if wino2:      # the reduce of the partials runs on the side stream, beside c2's data gradient
-                    dw2, db2, reduced = conv_wino2_wgrad(a1, g2, d2, finish_stream=_pack_stream(g2.device))
-                elif wino:
-                    dw2, db2 = conv_wino_wgrad(a1, g2, d2)
-                else:
-                    dw2, db2 = conv_wgrad(a1, g2, d2)
-            if (need[1] or need[2]) and wino2 and FUSE_C1_WGRAD:
-                dw1, db1 = conv_wino2_dgrad_w1(g2, p2d, s1, x4, d2)      # g1 never leaves the registers
-                del g2
-            elif need[1] or need[2]:
-                if wino2:
-                    g1 = conv_wino2_dgrad_bits(g2, p2d, s1, d2)
-                elif wino:
-                    g1 = conv_wino_dgrad_bits(g2, p2d, s1, d2)
-                else:
-                    g1 = conv_dgrad_bits(g2, p2d, s1, d2)
-                del g2
-                dw1, db1 = conv_wgrad(x4, g1, d1)
+
+            def c2_weight_gradient():
+                nonlocal dw2, db2, reduced
+                if need[3] or need[4]:
+                    if wino2:      # the reduce of the partials runs on the side stream, beside c2's data gradient
+                        dw2, db2, reduced = conv_wino2_wgrad(a1, g2, d2, finish_stream=_pack_stream(g2.device))
+                    elif wino:
+                        dw2, db2 = conv_wino_wgrad(a1, g2, d2)
+                    else:
+                        dw2, db2 = conv_wgrad(a1, g2, d2)
+
+            def c2_data_gradient():
+                nonlocal dw1, db1
+                if (need[1] or need[2]) and wino2 and FUSE_C1_WGRAD:
+                    dw1, db1 = conv_wino2_dgrad_w1(g2, p2d, s1, x4, d2)      # g1 never leaves the registers
+                elif need[1] or need[2]:
+                    if wino2:
+                        g1 = conv_wino2_dgrad_bits(g2, p2d, s1, d2)
+                    elif wino:
+                        g1 = conv_wino_dgrad_bits(g2, p2d, s1, d2)
+                    else:
+                        g1 = conv_dgrad_bits(g2, p2d, s1, d2)
+                    dw1, db1 = conv_wgrad(x4, g1, d1)
+
+            # C2_DGRAD_FIRST (optim.HipAdam, factor mode of ddp.GradSync): the optimizer passes of the two big Linear layers can only
+            # start once their gathered factors have arrived, ~3 ms into the backward, and they can only run BESIDE c2's weight gradient
+            # (440 registers per SIMD: one 48-register Adam wave fits; the data-gradient kernel's 475 leave no room) -- so that kernel
+            # goes last and the second hook sits in front of it
+            if C2_DGRAD_FIRST:
+                c2_data_gradient()
+                for hook in MFMA_PHASE2_HOOKS:
+                    hook()
+                c2_weight_gradient()
+            else:
+                c2_weight_gradient()
+                for hook in MFMA_PHASE2_HOOKS:
+                    hook()
+                c2_data_gradient()
+            del g2
             if reduced is not None:
                 torch.cuda.current_stream().wait_event(reduced)
         return None, dw1, db1, dw2, db2, dw3, db3, None, None
@@ -735,6 +759,10 @@ class Linear(torch.autograd.Function):
         check(_lib.lib().dd_linear_fwd(_p(x), _p(weight), _p(bias), _p(y), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_fwd")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if _ddp.FACTOR_SYNC and weight.requires_grad and torch.is_grad_enabled():
+            sync = _ddp.FACTOR_SYNC.get(weight.data_ptr())
+            if sync is not None:      # factor mode: a big input (fc1's 120 MB of pooled activations) starts its gather now, not in the backward
+                sync.linear_input(weight, x)
         return y
 
     @staticmethod
@@ -748,7 +776,12 @@ class Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             ws, nbytes = _linear_ws(m, n, k, x.device)
             check(_lib.lib().dd_linear_dgrad(_p(dy), _p(weight), _p(dx), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_dgrad")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        sync = _ddp.FACTOR_SYNC.get(weight.data_ptr()) if _ddp.FACTOR_SYNC else None
+        if sync is not None and ctx.needs_input_grad[1] and sync.linear_factors(weight, x, dy):
+            # data parallel, factor mode (ddp.GradSync): x and dy travel instead of dW; the optimizer forms the global-batch gradient
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = dy.sum(0)
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(n, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             check(_lib.lib().dd_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), m, n, k, _stream()), "dd_linear_wgrad")
@@ -757,6 +790,17 @@ class Linear(torch.autograd.Function):
 
 def linear(x, weight, bias):
     return Linear.apply(x.contiguous(), weight, bias)
+
+
+def linear_wgrad(dy, x, dw):
+    """dw [n, k] = dy^T x for dy [m, n], x [m, k] (dd_linear_wgrad without the bias sum): the optimizer's global-batch weight gradient
+    from gathered factors (ddp.GradSync, factor mode)."""
+    m, n = dy.shape
+    k = x.shape[1]
+    _dev(dy, "dy")
+    _dev(x, "x", (m, k))
+    _dev(dw, "dw", (n, k))
+    check(_lib.lib().dd_linear_wgrad(_p(dy), _p(x), _p(dw), None, m, n, k, _stream()), "dd_linear_wgrad")
 
 
 # ------------------------------------------------------------------------------------------------ dense block tail

@@ -28,6 +28,8 @@ class HipAdam(torch.optim.Optimizer):
         self._big_numel = 1 << 20
         self._scale = 1.0
         self._sync = None
+        self._factored = []        # parameters whose factors are on the links (ddp.GradSync, factor mode)
+        self._fgrad = {}           # p -> persistent buffer of the global-batch gradient formed from gathered factors
 
     SMALL_NUMEL = int(os.environ.get("DD_ADAM_MULTI_NUMEL", 1 << 16))      # tensors up to this size go into one multi-tensor launch (0: never)
 
@@ -47,6 +49,52 @@ class HipAdam(torch.optim.Optimizer):
     def attach(self, grad_sync):
         """Use ``grad_sync`` (ddp.GradSync) for per-piece waits and, in shard mode, for the shards and their all-gathers."""
         self._sync = grad_sync
+        if getattr(grad_sync, "factor", False):
+            grad_sync.on_factors = self._factored.append
+
+    def _group_of(self, p):
+        for group in self.param_groups:
+            if any(q is p for q in group["params"]):
+                return group
+        raise RuntimeError("HipAdam: factors arrived for a tensor this optimizer does not own")
+
+    def _form_factored(self, p):
+        """Factor mode: wait (on the CURRENT stream) for the gathers of the layer's input and output gradient and form the
+        global-batch weight gradient dy_all^T x_all into ``p.grad``."""
+        fac = self._sync.take_factors(p)
+        if fac is None:
+            return False
+        for work in fac.works:
+            work.wait()
+        g = self._fgrad.get(p)
+        if g is None or g.shape != p.shape or g.device != p.device:
+            g = self._fgrad[p] = torch.empty_like(p, memory_format=torch.contiguous_format)
+        ops.linear_wgrad(fac.dy_all, fac.x_all, g)
+        p.grad = g
+        return True
+
+    def _update_factored(self, p, group, grad_scale):
+        if not self._form_factored(p):
+            return False
+        self._update(p, group, grad_scale)
+        return True
+
+    @torch.no_grad()
+    def _flush_factored(self):
+        """Between c2's weight and data gradient (ops.MFMA_PHASE2_HOOKS): the factors gathered since the top of the backward have
+        arrived (N = 2: 202 MB over one link in ~3 ms).  The weight-gradient kernels run HERE, on the backward's stream -- on the side
+        stream, beside conv kernels that fill every CU with 440-register waves, they starve (measured on a one-rank communicator:
+        81 us -> 1.2 ms) -- and the Adam passes, built to run beside those kernels, go to the side stream behind them."""
+        if not self._factored:
+            return
+        done = [p for p in self._factored if self._form_factored(p)]
+        self._factored.clear()
+        ev = torch.cuda.current_stream().record_event()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            for p in done:
+                self._update(p, self._group_of(p), self._scale)
+                self._early.add(p)
 
     def _update_shards(self, p, group, grad_scale, shards):
         """The update of the slices of ``p`` this rank owns: wait (on the current stream) for piece k's reduce-scatter, update the
@@ -111,6 +159,9 @@ class HipAdam(torch.optim.Optimizer):
         self._big_numel = big_numel
         self._hooked = set()
         ops.MFMA_PHASE_HOOKS.append(self._flush_pending)
+        ops.MFMA_PHASE2_HOOKS.append(self._flush_factored)
+        if getattr(self._sync, "factor", False):
+            ops.C2_DGRAD_FIRST = True             # the Adam passes behind the gathered factors run beside c2's weight gradient: it goes last
         self.refresh()
         lightning.on_unfreeze(self)
 
@@ -135,6 +186,10 @@ class HipAdam(torch.optim.Optimizer):
         self._hooked = set()
         if self._flush_pending in ops.MFMA_PHASE_HOOKS:
             ops.MFMA_PHASE_HOOKS.remove(self._flush_pending)
+        if self._flush_factored in ops.MFMA_PHASE2_HOOKS:
+            ops.MFMA_PHASE2_HOOKS.remove(self._flush_factored)
+            if getattr(self._sync, "factor", False):
+                ops.C2_DGRAD_FIRST = False
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._side = None
@@ -167,9 +222,13 @@ class HipAdam(torch.optim.Optimizer):
     def step(self, grad_scale=1.0):
         if self._side is not None:
             self._flush_pending()                 # backward never reached an MFMA phase hook (other models)
+        self._factored.clear()
         for group in self.param_groups:
             small = {}                            # step count -> [(p, g, m, v)]: one launch for all the small tensors
             for p in group["params"]:
+                if p not in self._early and self._sync is not None and getattr(self._sync, "factor", False) and self._sync.has_factors(p):
+                    self._update_factored(p, group, grad_scale)      # no side stream: here, after the backward
+                    continue
                 if p.grad is None or p in self._early:
                     continue
                 shards = self._sync.shards(p) if self._sync is not None else None

@@ -10,7 +10,9 @@ exactly that (torch.optim.Adam): a caller with its own loop keeps working.  This
   * ``optim.HipAdam`` (one fused pass per tensor, torch.optim.Adam's arithmetic) with the pass of the big tensors on a side stream
     beside the MFMA-bound stretch of the backward (``overlap_with_backward``);
   * ``ddp.GradSync`` when ``torch.distributed`` is initialised: per-tensor asynchronous all-reduce from autograd hooks, or -- with
-    ``shard_optimizer=True`` -- reduce-scatter, Adam on the owned 1/N, in-place all-gather under the next forward;
+    ``shard_optimizer=True`` -- reduce-scatter, Adam on the owned 1/N, in-place all-gather under the next forward; or -- with
+    ``factor_linear=True``, for 2-4 ranks -- the big Linear layers send their factors (input, output gradient) instead of their
+    weight gradients and every rank forms the global-batch gradient itself (ddp.py);
   * frozen feature extractors (``self.ae.freeze()`` in the fine-tuning modules) are handled: both objects are built over the model
     as constructed and re-arm when ``training_step`` unfreezes it (lightning.on_unfreeze);
   * ``validation_epoch_end(val_loss)`` steps ``ReduceLROnPlateau`` the way Lightning does for a scheduler returned beside the
@@ -27,7 +29,7 @@ from .optim import HipAdam
 
 class TrainStep:
     def __init__(self, model, lr=None, adam_overlap=True, shard_optimizer=False, reserve_cus=None, process_group=None,
-                 force_collectives=False, simulate_world=0, scheduler="auto", big_numel=1 << 20, chunk_numel=1 << 25):
+                 force_collectives=False, simulate_world=0, scheduler="auto", big_numel=1 << 20, chunk_numel=1 << 25, factor_linear=False):
         self.model = model
         hp = getattr(model, "hparams", None)
         if lr is None:
@@ -43,7 +45,8 @@ class TrainStep:
         # the reference's Adam(self.parameters()); a parameter without a gradient is skipped until it has one
         self.optimizer = self._make_optimizer(model.parameters(), lr)
         self.sync = GradSync(model, process_group=process_group, big_numel=big_numel, chunk_numel=chunk_numel, reserve_cus=reserve_cus,
-                             force_collectives=force_collectives, shard_optimizer=shard_optimizer, simulate_world=simulate_world)
+                             force_collectives=force_collectives, shard_optimizer=shard_optimizer, simulate_world=simulate_world,
+                             factor_linear=factor_linear)
         self.optimizer.attach(self.sync)
         self.overlap = bool(adam_overlap)
         if self.overlap:

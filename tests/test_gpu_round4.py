@@ -101,6 +101,60 @@ def test_sharded_hipadam_is_bit_identical_to_the_all_reduce_path(tmp_path, dev, 
                 assert torch.equal(plain[k], ref[k]), f"rank {rank}: parameter {k} differs from rank 0's"
 
 
+def _factor_worker(rank, world, port, out, factor, overlap):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from driving_dirty_amd import ddp
+    from driving_dirty_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    model = _tiny_model(dev, frozen_epochs=1)
+    ts = TrainStep(model, lr=1e-2, adam_overlap=overlap, factor_linear=factor, big_numel=4096, chunk_numel=1 << 20, scheduler=False)
+    assert ts.sync.factor == factor and bool(ddp.FACTOR_SYNC) == factor
+    big = {"fc1.weight": model.fc1.weight, "ae.encoder.fc1.fc1.weight": model.ae.encoder.fc1.fc1.weight}
+    grads, losses = {}, []
+    for step in range(3):
+        if step == 1:
+            model.current_epoch = 1                           # the extractor (and its fc1) joins: its weight is registered at the unfreeze
+        losses.append(float(ts(_tiny_batch(dev, step, rank), step)["loss"]))
+        for name, q in big.items():
+            if q.grad is not None:
+                grads[f"{name}.{step}"] = q.grad.detach().cpu().clone()      # the SUM over ranks in both modes (1 / world is folded into Adam)
+    if factor:
+        assert set(ddp.FACTOR_SYNC) == {q.data_ptr() for q in big.values()}
+    torch.cuda.synchronize()
+    torch.save({"state": {k: v.cpu() for k, v in model.state_dict().items()}, "grads": grads, "losses": losses}, f"{out}.{int(factor)}.{rank}")
+    ts.close()
+    assert not ddp.FACTOR_SYNC
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, True), (3, False)])
+def test_factor_gather_forms_the_global_batch_gradient_on_every_rank(tmp_path, dev, world, overlap):
+    """ddp.GradSync(factor_linear=True): the two big Linear layers all-gather (input, output gradient) instead of all-reducing their
+    weight gradients, HipAdam forms dY_all^T X_all on every rank (beside the backward or after it).  The gradient equals the
+    all-reduce path's sum to rounding (one GEMM over the global batch against a sum of per-rank GEMMs), the replicas are bit-identical
+    to each other, the losses of three steps agree."""
+    out = str(tmp_path / "f.pt")
+    for factor in (False, True):
+        mp.spawn(_factor_worker, args=(world, free_port(), out, factor, overlap), nprocs=world, join=True)
+    plain = [torch.load(f"{out}.0.{r}") for r in range(world)]
+    fact = [torch.load(f"{out}.1.{r}") for r in range(world)]
+    assert set(fact[0]["grads"]) == set(plain[0]["grads"]) and len(fact[0]["grads"]) == 5      # head: 3 steps, encoder fc1: after the unfreeze
+    for key, g in fact[0]["grads"].items():      # step 0: same parameters in both runs; later the two runs have taken Adam steps apart
+        ref = plain[0]["grads"][key].double()
+        tol = 2e-6 if key.endswith(".0") else 1e-3
+        assert (g.double() - ref).abs().max().item() <= tol * ref.abs().max().item(), key
+    buffers = {k for k in fact[0]["state"] if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    for r in range(1, world):
+        for k, v in fact[0]["state"].items():
+            if k not in buffers:
+                assert torch.equal(fact[r]["state"][k], v), f"rank {r}: parameter {k} differs from rank 0's"
+    for a, b in zip(fact[0]["losses"], plain[0]["losses"]):
+        assert abs(a - b) <= 1e-4 * abs(b)
+
+
 # ------------------------------------------------------------------------------------------------ TrainStep == the reference's loop
 def test_trainstep_matches_configure_optimizers_loop(dev):
     """Two steps through train.TrainStep (HipAdam beside the backward, ReduceLROnPlateau attached) leave the parameters that two steps
@@ -179,13 +233,25 @@ def test_bench_sharded_step_over_a_one_rank_rccl_communicator(dev):
     assert abs(line["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-6 * abs(plain["config"]["final_loss"])
 
 
+def test_bench_factor_gather_over_a_one_rank_rccl_communicator(dev):
+    """The factor gather's call pattern on the real backend: RCCL all-gathers of the two Linear layers' inputs and output gradients from
+    inside the backward, the weight-gradient kernel and the Adam pass behind them on the side stream (a 1-rank gather is a copy and the
+    gradient formed from the gathered factors is the local one: the loss must equal the plain step's)."""
+    line, _ = _bench({"DD_REHEARSE_RCCL": "1", "MASTER_PORT": str(free_port())}, "--steps", "3", "--warmup", "2", "--factor-linear", "on")
+    assert line["n_ranks_seen"] == 1 and "rehearsal" in line and line["config"]["optimizer"].startswith("replicated; the big Linear layers all-gather")
+    plain, _ = _bench({}, "--steps", "3", "--warmup", "2")
+    assert abs(line["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-6 * abs(plain["config"]["final_loss"])
+
+
 @pytest.mark.parametrize("config", [3, 4, 5])
 def test_bench_two_ranks_over_gloo_on_one_card(dev, config):
     """`bench.py --gpus 2 --config C` starting its own ranks, both on this card, gradients over gloo (DD_DIST_BACKEND=gloo): the N > 1
-    control flow of every BASELINE configuration that exists only on several GPUs -- configs 4 and 5 on the sharded optimizer (auto)."""
-    line, err = _bench({"DD_DIST_BACKEND": "gloo", "DD_RESERVED_CUS": "0"}, "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1")
+    control flow of every BASELINE configuration that exists only on several GPUs -- config 4 on the sharded optimizer, config 5 on the
+    factor gather (the N = 2 default)."""
+    extra = ("--factor-linear", "off") if config == 4 else ()      # N = 2 defaults to the factor gather (config 5 here); config 4: the sharded optimizer
+    line, err = _bench({"DD_DIST_BACKEND": "gloo", "DD_RESERVED_CUS": "0"}, "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1", *extra)
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["baseline_config"] == config
-    assert line["config"]["optimizer"].startswith("sharded" if config in (2, 4, 5) else "replicated")
+    assert line["config"]["optimizer"].startswith({3: "replicated", 4: "sharded", 5: "replicated; the big Linear layers all-gather"}[config])
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0
     assert "[rank 0] bench.py preflight:" in err

@@ -69,9 +69,15 @@ def curve():
     w_fwd = min(v for k, v in m.items() if k.startswith("first_read"))
     t1 = min(sim["sim_c2_s0"]["ms_per_step"], sim["sim2_c2_s0"]["ms_per_step"])
     t_shard8 = min(sim["sim_c2_s8"]["ms_per_step"], sim["sim2_c2_s8"]["ms_per_step"])
+    # factor gather (ddp.GradSync(factor_linear=True)): every rank receives (N - 1) x 202 MB -- fc1's 120 MB of pooled activations, on the
+    # links from the end of the forward's conv part, and the head's 82 MB of dlogits from the top of the backward -- and needs them in
+    # front of c2's weight gradient, which goes LAST in this mode (ops.C2_DGRAD_FIRST).  Compute side measured on a one-rank RCCL
+    # communicator: +0.2 ms over the plain step (the two weight-gradient launches over N x 32 rows, the reordered backward).
+    f_gb = 0.202
+    w_fac = m["backward_end"] - 1.4 - m["forward_end"] + 0.5      # forward tail (0.5 ms) + the backward up to c2's weight gradient (its last ~1.4 ms)
     print()
-    print("| N | busbw at 70 % of (N-1) links | all-reduce: exposed / step / speed-up | sharded: exposed / step / speed-up |")
-    print("|---|---|---|---|")
+    print("| N | busbw at 70 % of (N-1) links | all-reduce: exposed / step / speed-up | sharded: exposed / step / speed-up | factor gather: exposed / step / speed-up |")
+    print("|---|---|---|---|---|")
     for n in (2, 4, 8):
         bw = 0.7 * (n - 1) * 76.8
         t_ar = 2.0 * (n - 1) / n * s_gb / bw * 1e3
@@ -80,7 +86,11 @@ def curve():
         comp = t1 - (t1 - t_shard8) * (1.0 - 1.0 / n) / (1.0 - 1.0 / 8)      # the Adam saving scales with the share given away
         e_sh = max(0.0, t_ar - (w_bwd + w_fwd))
         step_sh = comp + e_sh + FIXED_MS
-        print(f"| {n} | {bw:.0f} GB/s | {e_ar:.1f} / {step_ar:.1f} ms / {n * t1 / step_ar:.2f}x | {e_sh:.1f} / {step_sh:.1f} ms / {n * t1 / step_sh:.2f}x |")
+        t_fac = (n - 1) * f_gb / bw * 1e3
+        e_fac = max(0.0, t_fac - w_fac)
+        step_fac = t1 + 0.2 + 0.08 * (n - 2) + e_fac + FIXED_MS                # the weight-gradient launches grow with the gathered batch
+        print(f"| {n} | {bw:.0f} GB/s | {e_ar:.1f} / {step_ar:.1f} ms / {n * t1 / step_ar:.2f}x | {e_sh:.1f} / {step_sh:.1f} ms / {n * t1 / step_sh:.2f}x | "
+              f"{e_fac:.1f} / {step_fac:.1f} ms / {n * t1 / step_fac:.2f}x |")
 
 
 if __name__ == "__main__":
