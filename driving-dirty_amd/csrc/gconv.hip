@@ -841,6 +841,114 @@ __global__ __launch_bounds__(256) void channel_sum_stream_final(const float* __r
   if (threadIdx.x == 0) out[c] = accumulate ? out[c] + red[0] : red[0];
 }
 
+
+// ---------------------------------------------------------------------------------------------- ConvTranspose2d(32, 32, k2, s2): weight gradient
+// dW[ci][co][a][b] = sum over input pixels p = (r, c) of x[p][ci] * g[2r + a][2c + b][co]; db[co] = sum of g.  Four GEMMs (one per output
+// phase) with M = ci, N = co, K = pixels that share their A operand.  As four launches of the generic weight-gradient kernel each phase
+// cost a 27 us launch plus two reduce launches of 25-30 us (0.33 ms for ss_deconv at bs 32).  Here: one launch, a wave walks a contiguous
+// range of pixel pairs with four accumulator tiles (lane (h, m) supplies x[pixel h][ci = m] and the four g values of that pixel's 2 x 2
+// output block at co = m: five 128-byte-coalesced loads per four MFMAs, requested a group of four pixel pairs ahead), one partial per
+// wave, then a fixed-order fp64 second stage that also lays the result out as the layer's [ci][co][2][2] weight.
+constexpr int D2W_WAVES = 1024;      // partials (256 workgroups of 4 waves)
+constexpr int D2W_U = 4;             // pixel pairs per pipeline group
+
+__global__ __launch_bounds__(256) void deconv2x2_c32_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                  float* __restrict__ part, long npix, int w, int gcs, int gcoff) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  const int h = lane >> 5, m = lane & 31;
+  const long npairs = (npix + 1) / 2;
+  const long per = (npairs + D2W_WAVES - 1) / D2W_WAVES;
+  const long p0 = min((long)gw * per, npairs), p1 = min(p0 + per, npairs);
+  const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x, (int)(npix * 128));
+  const __amdgpu_buffer_rsrc_t gs = dd_rsrc(g, (int)(npix * 4 * gcs * 4));
+  f32x16 acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+  float bsum = 0.f;
+  // this lane's pixel: 2 * pair + h, as (row of the [batch * h] row list, column)
+  long pix = 2 * p0 + h;
+  long row = pix / w;
+  int col = (int)(pix - row * w);
+  auto offsets = [&](int& xo, int (&go)[4]) {
+    const bool ok = pix < npix;
+    xo = ok ? (int)(pix * 32 + m) * 4 : -16;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      go[p] = ok ? (int)((((2 * row + (p >> 1)) * (2L * w) + 2 * col + (p & 1)) * gcs + gcoff + m) * 4) : -16;
+    pix += 2;
+    col += 2;
+    if (col >= w) { col -= w; row += 1; }
+  };
+  float av[D2W_U], gv[D2W_U][4];
+  auto request = [&](int n) {      // the operands of the next n pixel pairs (n <= D2W_U; the others read zeros)
+#pragma unroll
+    for (int u = 0; u < D2W_U; ++u) {
+      int xo, go[4];
+      if (u < n) {
+        offsets(xo, go);
+      } else {
+        xo = -16;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) go[p] = -16;
+      }
+      av[u] = dd_bload1(xs, xo);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) gv[u][p] = dd_bload1(gs, go[p]);
+    }
+  };
+  long left = p1 - p0;
+  if (left > 0) request((int)min(left, (long)D2W_U));
+  while (left > 0) {
+    float ac[D2W_U], gc[D2W_U][4];
+#pragma unroll
+    for (int u = 0; u < D2W_U; ++u) {
+      ac[u] = av[u];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) gc[u][p] = gv[u][p];
+    }
+    left -= D2W_U;
+    if (left > 0) request((int)min(left, (long)D2W_U));      // the next group is on its way while this one is multiplied
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < D2W_U; ++u)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        acc[p] = DD_MFMA(ac[u], gc[u][p], acc[p]);
+        bsum += gc[u][p];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* out = part + (long)gw * (4 * 1024 + 64);
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[(p * 16 + e) * 64 + lane] = acc[p][e];
+  out[4096 + lane] = bsum;
+}
+
+__global__ __launch_bounds__(256) void deconv2x2_c32_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < 4096) {      // t = (p * 16 + e) * 64 + lane: element (ci = row of accumulator register e, co = lane & 31) of phase p = 2a + b
+    double s = 0.0;
+    for (int k = 0; k < D2W_WAVES; ++k) s += (double)part[(long)k * (4 * 1024 + 64) + t];
+    const int lane = t & 63, e = (t >> 6) & 15, p = t >> 10;
+    const int ci = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), co = lane & 31;
+    dw[(ci * 32 + co) * 4 + p] = (float)s;
+  } else if (t < 4096 + 32 && db) {
+    const int co = t - 4096;
+    double s = 0.0;
+    for (int k = 0; k < D2W_WAVES; ++k) {
+      const float* q = part + (long)k * (4 * 1024 + 64) + 4096;
+      s += (double)q[co] + (double)q[32 + co];
+    }
+    db[co] = (float)s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -975,6 +1083,24 @@ int dd_deconv2x2_c32_fwd_slice(const float* x, const float* wt, const float* bia
   hipLaunchKernelGGL(deconv2x2_c32_fwd_kernel, dim3((unsigned)min((ntile + 3) / 4, (long)DD_NUM_CU * 8)), dim3(256), 0, (hipStream_t)stream, x, wt,
                      bias, out, npix, w, relu, out_cstore, out_coff);
   DD_LAUNCH_CHECK("deconv2x2_c32_fwd");
+  return 0;
+}
+
+int64_t dd_deconv2x2_c32_wgrad_workspace_bytes(void) { return (int64_t)D2W_WAVES * (4 * 1024 + 64) * 4; }
+
+int dd_deconv2x2_c32_wgrad(const float* x, const float* g, float* dw, float* db, int32_t batch, int32_t h, int32_t w, int32_t g_cstore,
+                           int32_t g_coff, void* workspace, int64_t workspace_bytes, void* stream) {
+  DD_REQUIRE(x && g && dw && workspace && batch > 0 && h > 0 && w >= 2, DD_ERR_BAD_ARG, "deconv2x2_c32_wgrad: bad argument");
+  DD_REQUIRE(g_cstore >= 32 && g_coff >= 0 && g_coff + 32 <= g_cstore, DD_ERR_BAD_ARG, "deconv2x2_c32_wgrad: gradient channel slice");
+  DD_REQUIRE(workspace_bytes >= dd_deconv2x2_c32_wgrad_workspace_bytes(), DD_ERR_BAD_ARG, "deconv2x2_c32_wgrad: workspace too small");
+  const long npix = (long)batch * h * w;
+  DD_REQUIRE(npix * 128 < (1L << 31) && npix * 16 * g_cstore < (1L << 31), DD_ERR_UNSUPPORTED, "deconv2x2_c32_wgrad: a tensor exceeds 2 GB");
+  hipLaunchKernelGGL(deconv2x2_c32_wgrad_kernel, dim3(D2W_WAVES / 4), dim3(256), 0, (hipStream_t)stream, x, g, (float*)workspace, npix, w,
+                     g_cstore, g_coff);
+  DD_LAUNCH_CHECK("deconv2x2_c32_wgrad");
+  hipLaunchKernelGGL(deconv2x2_c32_wgrad_reduce, dim3((4096 + 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                     db);
+  DD_LAUNCH_CHECK("deconv2x2_c32_wgrad reduce");
   return 0;
 }
 

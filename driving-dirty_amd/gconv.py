@@ -121,6 +121,7 @@ def split_rows(view):
     return xs
 
 
+K2S2_WGRAD = os.environ.get("DD_K2S2_WGRAD", "1") != "0"      # A/B knob: 0 = the k2 s2 32->32 weight gradient by four phase launches
 SSCONV_DGRAD = os.environ.get("DD_SSCONV_DGRAD", "1") != "0"      # A/B knob: 0 = ss_conv's data gradient by seven phase launches
 
 
@@ -311,6 +312,16 @@ class Layer:
         if not self.transposed:
             d = _desc(b, src, ddst, cs, self.cout, self.k, self.stride, self.dil, self.pad)
             _wgrad(src.buf, ddst.buf, dw, db, d, 0, self.cin * self.T, self.T, False, self.cout, self.cin, 0)
+        elif (self.k2s2 and K2S2_WGRAD and self.cin == 32 and self.cout == 32 and _whole(src) and _whole(ddst) and src.coff == 0
+              and src.buf.shape[3] == 32 and src.buf.is_contiguous() and ddst.buf.is_contiguous() and src.buf.shape[2] >= 2
+              and ddst.buf.shape[1] == 2 * src.buf.shape[1] and ddst.buf.shape[2] == 2 * src.buf.shape[2]):
+            # ss_deconv / the decoder's dc3: the four phases in one launch (csrc/gconv.hip, deconv2x2_c32_wgrad_kernel)
+            lib = _lib.lib()
+            nbytes = lib.dd_deconv2x2_c32_wgrad_workspace_bytes()
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            _, ih, iw, _ = src.buf.shape
+            check(lib.dd_deconv2x2_c32_wgrad(_p(src.buf), _p(ddst.buf), _p(dw), _p(db) if db is not None else None, b, ih, iw,
+                                             ddst.buf.shape[3], ddst.coff, _p(ws), nbytes, _stream()), "dd_deconv2x2_c32_wgrad")
         elif self.k2s2:
             ih, iw = src.buf.shape[1:3]
             for ph in range(4):

@@ -402,6 +402,13 @@ int dd_deconv2x2_c32_fwd(const float* x, const float* wt, const float* bias, flo
 int dd_deconv2x2_c32_fwd_slice(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w, int32_t relu,
                                int32_t out_cstore, int32_t out_coff, void* stream);
 
+/* Weight (and bias) gradient of ConvTranspose2d(32, 32, k2, s2) -- ss_deconv (spatial_bb/components.py:89,130), the decoder's dc3
+ * (components.py:72,91) -- in one launch + a fixed-order second stage: x [batch, h, w, 32] dense, g = channels [g_coff, g_coff + 32) of a
+ * [batch, 2h, 2w, g_cstore] NHWC buffer, dw [32, 32, 2, 2] (the layer's weight layout), db [32] or NULL. */
+int64_t dd_deconv2x2_c32_wgrad_workspace_bytes(void);
+int dd_deconv2x2_c32_wgrad(const float* x, const float* g, float* dw, float* db, int32_t batch, int32_t h, int32_t w, int32_t g_cstore,
+                           int32_t g_coff, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Data gradient of ss_conv -- Conv2d(32, 32, (1, 24), stride (1, 7)), spatial_bb/components.py:88,129 (what autograd computes for
  * F.conv2d's input there) -- in one launch: g [batch, h, gw, 32], w [32, 32, 1, 24] (the layer's weight as it is), dx [batch, h, xw, 32],
  * all dense NHWC fp32, gw = (xw - 24) / 7 + 1 <= 128.  Every element of dx is written (pixels no tap reaches get 0). */

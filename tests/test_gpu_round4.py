@@ -745,3 +745,29 @@ def test_ss_conv_data_gradient_in_one_launch(dev, b, h, xw):
     for dx in outs:
         assert (dx.double() - ref).abs().max().item() / scale < 2e-6
     assert (outs[0] - outs[1]).abs().max().item() / scale < 2e-6
+
+
+@pytest.mark.parametrize("b,h,w,gcs,coff", [(2, 5, 7, 32, 0), (3, 16, 16, 96, 0), (1, 9, 3, 40, 8)])
+def test_k2s2_weight_gradient_in_one_launch(dev, b, h, w, gcs, coff):
+    """ConvTranspose2d(32, 32, k2, s2)'s weight / bias gradient (ss_deconv, the decoder's dc3) by `dd_deconv2x2_c32_wgrad` against torch
+    fp64 autograd and against the four phase launches of the generic engine; an odd pixel count, a channel slice of a wider buffer."""
+    import torch.nn.functional as F
+    from driving_dirty_amd import gconv, synth
+    layer = gconv.Layer(32, 32, 2, stride=2, transposed=True)
+    x = synth.hash_uniform((b, h, w, 32), synth.key_salt("k2x"), -1.0, 1.0).to(dev)
+    gbuf = synth.hash_uniform((b, 2 * h, 2 * w, gcs), synth.key_salt("k2g"), -1.0, 1.0).to(dev)
+    wt = torch.zeros(32, 32, 2, 2, dtype=torch.float64, device=dev, requires_grad=True)
+    bias = torch.zeros(32, dtype=torch.float64, device=dev, requires_grad=True)
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt, bias, stride=2)
+    (y * gbuf[..., coff:coff + 32].permute(0, 3, 1, 2).double()).sum().backward()
+    outs = []
+    old = gconv.K2S2_WGRAD
+    try:
+        for on in (True, False):
+            gconv.K2S2_WGRAD = on
+            outs.append(layer.backward_weight(gconv.View(x), gconv.View(gbuf, coff, 32)))
+    finally:
+        gconv.K2S2_WGRAD = old
+    for dw, db in outs:
+        assert (dw.double() - wt.grad).abs().max().item() <= 2e-6 * wt.grad.abs().max().item()
+        assert (db.double() - bias.grad).abs().max().item() <= 2e-6 * bias.grad.abs().max().item()
