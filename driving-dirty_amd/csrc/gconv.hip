@@ -354,14 +354,13 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restric
 // dw[w_off + o*sn + c*sc + tap'] (+)= sum over ranges.  One block = 256 consecutive accumulator elements (four register
 // rows of one tile) x 16 groups of ranges; a lane reads 16 bytes, so every wave-load is 1 KB of contiguous partials
 // (the partials of one range are `per` floats apart: 256-byte pieces ran at a quarter of the bandwidth).
-__global__ __launch_bounds__(1024) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int nranges, int njobs, int no, int nb, int njg, int T, int cin,
-                                                           long w_off, long sn, long sc, int flip, int n_real, int c_real,
-                                                           int accumulate) {
-  __shared__ f32x4 red[16][64];
+__device__ __forceinline__ void gconv_wgrad_reduce_block(f32x4 (*red)[64], int block, const float* __restrict__ part, float* __restrict__ dw,
+                                                         int nranges, int njobs, int no, int nb, int njg, int T, int cin,
+                                                         long w_off, long sn, long sc, int flip, int n_real, int c_real,
+                                                         int accumulate) {
   const long per = (long)njobs * no * nb * 1024;
   const int l64 = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long e0 = (long)blockIdx.x * 256 + 4 * l64;
+  const long e0 = (long)block * 256 + 4 * l64;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 s0 = z, s1 = z, s2 = z, s3 = z;
   int r = g;
@@ -396,10 +395,9 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_reduce(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(1024) void gconv_bias_reduce(const float* __restrict__ bpart, float* __restrict__ db,
-                                                          int nranges, int nto, int n_real, int accumulate) {
-  __shared__ float red[16][64];
-  const int ot = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+__device__ __forceinline__ void gconv_bias_reduce_block(float (*red)[64], int ot, const float* __restrict__ bpart, float* __restrict__ db,
+                                                        int nranges, int nto, int n_real, int accumulate) {
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   float s = 0.f;
   for (int r = g; r < nranges; r += 16) s += bpart[((long)r * nto + ot) * 64 + lane];
   red[g][lane] = s;
@@ -411,6 +409,20 @@ __global__ __launch_bounds__(1024) void gconv_bias_reduce(const float* __restric
   s += __shfl_xor(s, 32);
   const int o = ot * 32 + lane;
   if (lane < 32 && o < n_real) db[o] = accumulate ? db[o] + s : s;
+}
+
+// Both second stages in ONE launch: blocks [0, wblocks) sum the weight partials, the nto blocks behind them the bias partials (two
+// launches of 16-30 us per weight gradient before: 13 pairs per step of the box-head model).
+__global__ __launch_bounds__(1024) void gconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int wblocks,
+                                                           const float* __restrict__ bpart, float* __restrict__ db, int nto, int baccumulate,
+                                                           int nranges, int njobs, int no, int nb, int njg, int T, int cin,
+                                                           long w_off, long sn, long sc, int flip, int n_real, int c_real,
+                                                           int accumulate) {
+  __shared__ f32x4 red[16][64];
+  if ((int)blockIdx.x < wblocks)
+    gconv_wgrad_reduce_block(red, blockIdx.x, part, dw, nranges, njobs, no, nb, njg, T, cin, w_off, sn, sc, flip, n_real, c_real, accumulate);
+  else
+    gconv_bias_reduce_block((float (*)[64])red, blockIdx.x - wblocks, bpart, db, nranges, nto, n_real, baccumulate);
 }
 
 // ---------------------------------------------------------------------------------------------- small helpers
@@ -1035,13 +1047,11 @@ int dd_gconv_wgrad(const float* x, const float* dy, float* dw, float* dbias, con
 #undef DD_GW
   DD_LAUNCH_CHECK("gconv_wgrad");
   const long per = (long)p.njobs * p.no * p.nb * 1024;
-  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)(per / 256)), dim3(1024), 0, st, part, dw, p.nranges, p.njobs, p.no,
-                     p.nb, p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn, (long)sc, flip, n_real, c_real, accumulate & 1);
+  const int wblocks = (int)(per / 256), bblocks = dbias ? p.nto : 0;
+  hipLaunchKernelGGL(gconv_wgrad_reduce, dim3((unsigned)(wblocks + bblocks)), dim3(1024), 0, st, part, dw, wblocks, bpart, dbias,
+                     p.nog * p.no, accumulate & 2, p.nranges, p.njobs, p.no, p.nb, p.njg, d->kh * d->kw, d->cin, (long)w_off, (long)sn,
+                     (long)sc, flip, n_real, c_real, accumulate & 1);
   DD_LAUNCH_CHECK("gconv_wgrad_reduce");
-  if (dbias) {
-    hipLaunchKernelGGL(gconv_bias_reduce, dim3(p.nto), dim3(1024), 0, st, bpart, dbias, p.nranges, p.nog * p.no, n_real, accumulate & 2);
-    DD_LAUNCH_CHECK("gconv_bias_reduce");
-  }
   return 0;
 }
 
