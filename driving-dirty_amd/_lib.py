@@ -112,6 +112,9 @@ SIGNATURES = {
     "dd_dconv_packed_floats": (_i64, [_GP]),
     "dd_dconv_pack": (_i32, [_p, _p, _GP, _i64, _i64, _i64, _i32, _i32, _i32, _p]),
     "dd_dconv_fwd": (_i32, [_p, _p, _p, _p, _p, _GP, _i32, _p]),
+    "dd_dconv_colsum_supported": (_i32, [_p, _i32, _i32]),
+    "dd_dconv_colsum_workspace_bytes": (_i64, []),
+    "dd_dconv_fwd_colsum": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "dd_dconv_split_supported": (_i32, [_GP]),
     "dd_dconv_split_input_bytes": (_i64, [_GP]),
     "dd_dconv_split_packed_bytes": (_i64, [_GP]),

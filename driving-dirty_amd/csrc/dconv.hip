@@ -597,6 +597,34 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
   return 0;
 }
 
+// The same launch that ALSO leaves the per-channel sums of what it wrote (after the epilogue) in colsum[0 .. cout): the data gradient
+// of up_conv_(k+1) is dL/dy of up_conv_k, and its channel sums are up_conv_k's bias gradient -- without this a separate pass re-reads
+// the whole tensor.  Only the windowed multi-row kernel (csrc/dconv_m.hip) does it: ask dd_dconv_colsum_supported first.
+int32_t dd_dconv_colsum_supported(const dd_gconv_desc* d, int32_t epilogue, int32_t has_mask) {
+  return d && dd_dconv_mwin_takes(d, epilogue, has_mask != 0, false) ? 1 : 0;
+}
+
+int64_t dd_dconv_colsum_workspace_bytes(void) { return (int64_t)DD_NUM_CU * 3 * 64 * 4; }
+
+int dd_dconv_fwd_colsum(const float* x, const float* packed, const float* mask, float* y, float* colsum, const dd_gconv_desc* d,
+                        int32_t epilogue, void* workspace, int64_t workspace_bytes, void* stream) {
+  DD_REQUIRE(dc_supported(d), DD_ERR_UNSUPPORTED, "dconv_fwd_colsum: unsupported layer");
+  DD_REQUIRE(x && packed && y && colsum && workspace, DD_ERR_BAD_ARG, "dconv_fwd_colsum: NULL pointer");
+  DD_REQUIRE(epilogue == DD_EPI_NONE || epilogue == DD_EPI_RELU_MASK, DD_ERR_BAD_ARG, "dconv_fwd_colsum: epilogue %d", epilogue);
+  DD_REQUIRE(workspace_bytes >= dd_dconv_colsum_workspace_bytes(), DD_ERR_WORKSPACE, "dconv_fwd_colsum: workspace too small");
+  DD_REQUIRE(dd_dconv_mwin_takes(d, epilogue, mask != nullptr, false), DD_ERR_UNSUPPORTED,
+             "dconv_fwd_colsum: not a layer of the windowed multi-row kernel (dd_dconv_colsum_supported)");
+  hipStream_t st = (hipStream_t)stream;
+  const int wp_bytes = (int)(dd_dconv_packed_floats(d) * 4);
+  const int grid = dd_cu_budget_internal();
+  DD_REQUIRE(dd_dconv_mfwd_launch_colsum(x, packed, nullptr, mask, y, d, epilogue, wp_bytes, st, (float*)workspace), DD_ERR_UNSUPPORTED,
+             "dconv_fwd_colsum: the launcher refused the layer");
+  DD_LAUNCH_CHECK("dconv_fwd_colsum");
+  dd_dconv_colsum_reduce_launch((const float*)workspace, colsum, grid, d->cout, st);
+  DD_LAUNCH_CHECK("dconv_colsum_reduce");
+  return 0;
+}
+
 }  // extern "C"
 
 // =====================================================================================================================

@@ -306,10 +306,11 @@ struct MwTask {
   int b, res, a0, rows;
 };
 
-template <int K, int D, int NTC, int NTW, int R, int IWP>
+template <int K, int D, int NTC, int NTW, int R, int IWP, bool COLSUM>
 __global__ __launch_bounds__(512, 2) void dconv_mwin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, const float* __restrict__ msk,
-                                                            float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes) {
+                                                            float* __restrict__ y, const dd_gconv_desc d, int epi, int wp_bytes,
+                                                            float* __restrict__ cpart) {
   constexpr int T = K * K;
   constexpr int NSLOT = 2 * R, SWEEP = K - 1 + R;
   constexpr int ROWB = IWP * 32;                          // bytes of a row image (IWP pixels x one 8-channel chunk)
@@ -385,7 +386,15 @@ __global__ __launch_bounds__(512, 2) void dconv_mwin_kernel(const float* __restr
   };
   auto slot_of = [&](int idx) { return idx % NSLOT; };
 
-  if (u0 >= u1) return;
+  // COLSUM: per-channel sums of everything this workgroup writes (after the mask) -- the bias gradient of the layer whose output
+  // gradient this launch produces, which otherwise re-reads the whole tensor (channel_sum: 0.14 ms for up_conv_1's 727 MB)
+  float bs[NTC];
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) bs[nt] = 0.f;
+  if (u0 >= u1) {
+    if (COLSUM && threadIdx.x < NTC * 64) cpart[(long)blockIdx.x * (NTC * 64) + threadIdx.x] = 0.f;
+    return;
+  }
   MwTask cur, nxt;
   decode(u0, cur);
   int sbase = 0;                                            // ring slot of sweep row 0 of the current sweep
@@ -513,6 +522,10 @@ __global__ __launch_bounds__(512, 2) void dconv_mwin_kernel(const float* __restr
           if (epi == DD_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
           v = mv[r] > 0.f ? v : 0.f;
           dd_bstore1(ys, off[r], v);
+          if (COLSUM) {      // an opaque add: left to the compiler the 16 sums became a tree that kept 50 more registers alive (spills at NTC = 2)
+            const float t = off[r] >= 0 ? v : 0.f;
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs[nt]) : "v"(t));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -520,13 +533,52 @@ __global__ __launch_bounds__(512, 2) void dconv_mwin_kernel(const float* __restr
     cur = nxt;
     u = un;
   }
+  if (COLSUM) {      // the eight waves' sums in a fixed order (deterministic), one partial per workgroup; the second stage adds the halves
+    float* red = (float*)lds;                               // the ring is idle: the last step's barrier is behind every wave
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) red[(wave * NTC + nt) * 64 + lane] = bs[nt];
+    __syncthreads();
+    if (threadIdx.x < NTC * 64) {
+      float sum = 0.f;
+      for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * NTC * 64 + threadIdx.x];
+      cpart[(long)blockIdx.x * (NTC * 64) + threadIdx.x] = sum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void dconv_colsum_reduce(const float* __restrict__ cpart, float* __restrict__ out, int nblocks, int ntc, int cout) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= cout) return;
+  const int nt = c >> 5, n = c & 31;
+  double sum = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    const float* q = cpart + (long)b * (ntc * 64) + nt * 64;
+    sum += (double)q[n] + (double)q[32 + n];
+  }
+  out[c] = (float)sum;
 }
 
 }  // namespace
 
+// Whether the windowed kernel (the only one that can also sum its output per channel) takes this layer: the launcher's own conditions.
+bool dd_dconv_mwin_takes(const dd_gconv_desc* d, int epilogue, bool has_mask, bool has_bias) {
+  static const bool off = (getenv("DD_DCONV_MFWD_OFF") && atoi(getenv("DD_DCONV_MFWD_OFF")) != 0) ||
+                          (getenv("DD_DCONV_MWIN_OFF") && atoi(getenv("DD_DCONV_MWIN_OFF")) != 0);
+  if (off || !dd_dconv_desc_ok(d)) return false;
+  if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU && epilogue != DD_EPI_RELU_MASK) return false;
+  if ((epilogue == DD_EPI_RELU_MASK && !has_mask) || ((epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) && !has_bias)) return false;
+  if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7 || d->cout <= 16 || d->cout > 64 || d->cin % 8) return false;
+  if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30) || d->pad_h != 0 || d->pad_w != 0) return false;
+  if (d->out_h > d->in_h - 42 || d->out_w > d->in_w - 42) return false;
+  return d->in_w <= 384 && 3 * d->out_w <= 1024 && d->out_w + 42 <= 384 && d->out_h >= 7 && dd_cu_budget_internal() >= 1;
+}
+
 // Launches the multi-row gather kernel if the layer is one it is built for; false = nothing launched.
-bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
-                          int epilogue, int wp_bytes, hipStream_t st) {
+// ``colsum_part`` (NULL: none): one partial of (cout + 31) / 32 x 64 floats per workgroup of per-channel sums of the output; only the
+// windowed kernel fills it -- false is returned, nothing launched, when the layer would go elsewhere.
+bool dd_dconv_mfwd_launch_colsum(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                                 int epilogue, int wp_bytes, hipStream_t st, float* colsum_part) {
   static const bool off = getenv("DD_DCONV_MFWD_OFF") && atoi(getenv("DD_DCONV_MFWD_OFF")) != 0;
   // the padded (transposed-forward) form is correct but slower than the input-aligned forward of dconv_t.hip (up_conv_2: 6.04 against
   // 5.36 ms -- tiles that straddle a row need nearly every tap column): an experiment knob, off by default
@@ -558,17 +610,31 @@ bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias
 #define DD_MW(NTC_, IWP_)                                                                                                            \
   do {                                                                                                                               \
     if (d->in_w <= IWP_ && 3 * d->out_w <= 1024 && d->out_w + halo <= IWP_ && d->out_h >= 7) {                                        \
-      hipLaunchKernelGGL((dconv_mwin_kernel<7, 7, NTC_, 4, 3, IWP_>), dim3(grid), dim3(512), 0, st, x, packed, bias, mask, y, *d,    \
-                         epilogue, wp_bytes);                                                                                        \
+      if (colsum_part)                                                                                                               \
+        hipLaunchKernelGGL((dconv_mwin_kernel<7, 7, NTC_, 4, 3, IWP_, true>), dim3(grid), dim3(512), 0, st, x, packed, bias, mask,    \
+                           y, *d, epilogue, wp_bytes, colsum_part);                                                                  \
+      else                                                                                                                           \
+        hipLaunchKernelGGL((dconv_mwin_kernel<7, 7, NTC_, 4, 3, IWP_, false>), dim3(grid), dim3(512), 0, st, x, packed, bias, mask,   \
+                           y, *d, epilogue, wp_bytes, (float*)nullptr);                                                              \
       return true;                                                                                                                   \
     }                                                                                                                                \
   } while (0)
   if (!padded && window && ntc == 2) DD_MW(2, 384);        // up_conv_2 data gradient: phase rows, one new input row per step
   if (!padded && window && ntc == 1) DD_MW(1, 384);        // up_conv_3 data gradient
 #undef DD_MW
+  if (colsum_part) return false;                           // only the windowed kernel sums its output
   if (!padded && ntc == 2) DD_MF(2, 4, 3, 1024, false, 8);      // up_conv_2 data gradient: 3 x 340 = 1020 pixels
   if (!padded && ntc == 1) DD_MF(1, 4, 3, 1152, false, 8);      // up_conv_3 data gradient: 3 x 382 = 1146 (6-row tasks, 8 tiles per wave: 1.58 against 1.52 ms)
   if (padded && ntc == 1) DD_MF(1, 4, 3, 1152, true, 8);        // up_conv_2 forward: 3 x (340 + 42) = 1146
 #undef DD_MF
   return false;
+}
+
+bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                          int epilogue, int wp_bytes, hipStream_t st) {
+  return dd_dconv_mfwd_launch_colsum(x, packed, bias, mask, y, d, epilogue, wp_bytes, st, nullptr);
+}
+
+void dd_dconv_colsum_reduce_launch(const float* part, float* out, int nblocks, int cout, hipStream_t st) {
+  hipLaunchKernelGGL(dconv_colsum_reduce, dim3((cout + 63) / 64), dim3(64), 0, st, part, out, nblocks, (cout + 31) / 32, cout);
 }

@@ -76,3 +76,7 @@ bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias
 // dconv_m.hip: gather form with several output rows per workgroup (rows that are not a whole number of 8 m-tiles); false = not one of its layers.
 bool dd_dconv_mfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
                           int epilogue, int wp_bytes, hipStream_t st);
+bool dd_dconv_mfwd_launch_colsum(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
+                                 int epilogue, int wp_bytes, hipStream_t st, float* colsum_part);
+void dd_dconv_colsum_reduce_launch(const float* part, float* out, int nblocks, int cout, hipStream_t st);
+bool dd_dconv_mwin_takes(const dd_gconv_desc* d, int epilogue, bool has_mask, bool has_bias);

@@ -121,6 +121,7 @@ def split_rows(view):
     return xs
 
 
+COLSUM = os.environ.get("DD_DCONV_COLSUM", "1") != "0"      # A/B knob: 0 = bias gradients of the up-convs by their own pass over dL/dy
 K2S2_WGRAD = os.environ.get("DD_K2S2_WGRAD", "1") != "0"      # A/B knob: 0 = the k2 s2 32->32 weight gradient by four phase launches
 SSCONV_DGRAD = os.environ.get("DD_SSCONV_DGRAD", "1") != "0"      # A/B knob: 0 = ss_conv's data gradient by seven phase launches
 
@@ -143,7 +144,7 @@ def _dconv_ok(d):
     return DCONV and bool(_lib.lib().dd_dconv_supported(C.byref(d)))
 
 
-def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real, xs=None, emit=None):
+def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real, xs=None, emit=None, colsum=None):
     """pack + launch on the dilated kernel when the descriptor qualifies, on the generic one otherwise.  Returns the split image of
     x when the split-product path ran (``xs``: one a caller already holds), None otherwise.  ``emit`` (a dict): on the split path the
     kernel also writes the split image of its OUTPUT from its epilogue (``emit['ys']``: the next layer's operand, no split pass)."""
@@ -165,6 +166,14 @@ def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real,
         n = lib.dd_dconv_packed_floats(C.byref(d))
         packed = torch.empty(n, device=weight.device, dtype=torch.float32)
         check(lib.dd_dconv_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_pack")
+        if (colsum is not None and COLSUM and bias is None and epi in (EPI_NONE, EPI_RELU_MASK)
+                and lib.dd_dconv_colsum_supported(C.byref(d), epi, int(mask is not None))):
+            # the launch also leaves the per-channel sums of its output: the bias gradient of the layer below (csrc/dconv_m.hip)
+            nbytes = lib.dd_dconv_colsum_workspace_bytes()
+            ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+            check(lib.dd_dconv_fwd_colsum(_p(x), _p(packed), _p(mask), _p(y), _p(colsum), C.byref(d), epi, _p(ws), nbytes, _stream()),
+                  "dd_dconv_fwd_colsum")
+            return "colsum"
         check(lib.dd_dconv_fwd(_p(x), _p(packed), _p(bias), _p(mask), _p(y), C.byref(d), epi, _stream()), "dd_dconv_fwd")
     else:
         _fwd(x, _pack(weight, d, w_off, sn, sc, flip, n_real, c_real), bias, mask, y, d, epi)
@@ -227,9 +236,11 @@ class Layer:
                 keep["xs"] = xs
 
     # ---- data gradient: dsrc (View with the input's geometry, >= 4-aligned channels) from ddst (View of dy)
-    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0), gs=None, emit=None):
+    def backward_data(self, weight, ddst, dsrc, relu_src=None, mask_pass=(0, 0), gs=None, emit=None, colsum=None):
         """dsrc.buf[..., dsrc.coff : +cin] = dL/dx (x masked by ``relu_src > 0`` when given; channels
-        [mask_pass[0], mask_pass[1]) of the dsrc buffer are exempt: a concat slice that is not a ReLU output)."""
+        [mask_pass[0], mask_pass[1]) of the dsrc buffer are exempt: a concat slice that is not a ReLU output).
+        ``colsum`` (a [cin] float tensor): where the kernel can, it also receives the per-channel sums of what was written -- the bias
+        gradient of the layer that produced x; returns True when it was filled."""
         b = ddst.buf.shape[0]
         epi = EPI_RELU_MASK if relu_src is not None else EPI_NONE
         cin_out = self.cin
@@ -238,8 +249,9 @@ class Layer:
             # the dilated kernel takes up to 96 output channels in one launch (three column tiles per wave)
             d = _desc(b, ddst, dsrc, cos, cin_out, self.k, (1, 1), self.dil, self.pad, mask_pass=mask_pass)
             if _dconv_ok(d):
-                _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout, xs=gs, emit=emit)
-                return
+                r = _conv(ddst.buf, weight, None, relu_src, dsrc.buf, d, epi, 0, self.cout * self.T, self.T, False, cin_out, self.cout, xs=gs,
+                          emit=emit, colsum=colsum)
+                return isinstance(r, str) and r == "colsum"
         if (not self.transposed and self.k == (1, 24) and self.stride == (1, 7) and self.dil == (1, 1) and self.pad == (0, 0)
                 and self.cin == 32 and self.cout == 32 and relu_src is None and SSCONV_DGRAD and _whole(ddst) and _whole(dsrc)
                 and ddst.coff == 0 and dsrc.coff == 0 and _ops().ssconv_dgrad_ok(ddst.buf, dsrc.buf)):

@@ -279,6 +279,7 @@ class MergeFn(torch.autograd.Function):
                                              b, u.shape[1], u.shape[2], 8, _p(ws), _stream()), "dd_deconv2x2_c1_bwd")
         g = gu
         g_planes = None                              # split-product experiment: the bf16 planes of g, when the kernel that produced g wrote them
+        db_from_above = None                         # this layer's bias gradient, when the data gradient above already summed dL/dy
         g_up = []
         for i in range(nup - 1, -1, -1):
             layer, src = ups[i], acts[i]
@@ -288,12 +289,18 @@ class MergeFn(torch.autograd.Function):
             if gs is None and layer.split_wgrad_ok(View(src), View(g)):
                 gs = gconv_split_rows(View(g))
             use_w = gs is not None and layer.split_wgrad_ok(View(src), View(g))
-            g_up.append(layer.backward_weight(View(src), View(g), xs=ctx.split_x[i] if use_w else None, gs=gs if use_w else None))
+            dw_i, db_i = layer.backward_weight(View(src), View(g), xs=ctx.split_x[i] if use_w else None, gs=gs if use_w else None,
+                                               want_bias=db_from_above is None)
+            g_up.append((dw_i, db_i if db_from_above is None else db_from_above))
             gsrc = _empty(src.shape, dev)
             emit = {} if i > 0 else None             # the concat buffer's gradient (i == 0) goes to layers outside the experiment
             # masks with the producer's ReLU output; in the concat buffer (i == 0) only the slices this node's own ReLUs
             # wrote (ss_deconv 0:32, rm_conv_2 64:96): the spatial-map slice 32:64 is an external input
-            layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0), gs=gs, emit=emit)
+            # the per-channel sums of gsrc are the bias gradient of the up-conv below: the kernel that writes gsrc leaves them where it can
+            csum = _empty((ups[i - 1].cout,), dev) if i > 0 and gsrc.shape[3] == ups[i - 1].cout else None
+            took = layer.backward_data(w_up[i], View(g), View(gsrc), relu_src=src, mask_pass=(32, 64) if i == 0 else (0, 0), gs=gs, emit=emit,
+                                       colsum=csum)
+            db_from_above = csum if took else None
             g, g_planes = gsrc, (emit or {}).get("ys")
         g_up.reverse()
         gcat = g                                                                 # [B,256,256,64|96]; slices 0:32 / 64:96 ReLU-masked

@@ -333,6 +333,15 @@ int dd_dconv_pack(const float* w, float* packed, const dd_gconv_desc* d, int64_t
 int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const float* mask, float* y,
                  const dd_gconv_desc* d, int32_t epilogue, void* stream);
 
+/* dd_dconv_fwd that ALSO leaves in colsum[0 .. cout) the per-channel sums of what it wrote: the data gradient of up_conv_(k+1) is the
+ * output gradient of up_conv_k, whose bias gradient (autograd's sum over batch and pixels, spatial_bb/components.py:135-137) is exactly
+ * those sums -- a separate pass over the tensor otherwise.  Epilogues NONE / RELU_MASK; only layers dd_dconv_colsum_supported accepts
+ * (the data gradients of the k7 d7 up-convs with 17-64 output channels). */
+int32_t dd_dconv_colsum_supported(const dd_gconv_desc* d, int32_t epilogue, int32_t has_mask);
+int64_t dd_dconv_colsum_workspace_bytes(void);
+int dd_dconv_fwd_colsum(const float* x, const float* packed, const float* mask, float* y, float* colsum, const dd_gconv_desc* d,
+                        int32_t epilogue, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* EXPERIMENT, off by default (csrc/dconv_split.hip): the forward of the k7 d7 dilated ConvTranspose2d layers with Cout > 16
  * (up_conv_1 / up_conv_2, spatial_bb/components.py:135-136) with fp32-equivalent products on the bf16 matrix pipe: every fp32
  * operand is split exactly into three bf16 pieces (hi + mid + lo, truncation: 24 significant bits) and the six cross products

@@ -708,7 +708,12 @@ def test_multi_row_data_gradient_against_fp64_and_the_one_row_kernels(dev, cin, 
         src = torch.zeros_like(buf)
         src[..., 4:4 + cin] = x
         lo, hi = 4 + cin // 2, 4 + cin                                             # the upper half of the slice is exempt from the mask
-        layer.backward_data(wd, gconv.View(g), gconv.View(buf, 4, cin), relu_src=src if masked else None, mask_pass=(lo, hi) if masked else (0, 0))
+        csum = torch.full((cin,), float("nan"), device=dev)
+        took = layer.backward_data(wd, gconv.View(g), gconv.View(buf, 4, cin), relu_src=src if masked else None,
+                                   mask_pass=(lo, hi) if masked else (0, 0), colsum=csum)
+        assert took                                                                # these layers run on the windowed kernel, which sums its output
+        sums = buf[..., 4:4 + cin].double().sum(dim=(0, 1, 2))
+        assert (csum.double() - sums).abs().max().item() <= 1e-5 * max(sums.abs().max().item(), 1.0), "per-channel sums of the written gradient"
         want = ref.clone()
         if masked:
             keep = (x > 0).double()
