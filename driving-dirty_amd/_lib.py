@@ -60,6 +60,7 @@ SIGNATURES = {
     "dd_deconv2x2_c32_wgrad": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "dd_ssconv_dgrad_supported": (_i32, [_i32, _i32, _i32]),
     "dd_ssconv_dgrad": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_ssconv_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_conv1x1_c32_c3_nchw": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_conv1ch_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_conv1ch_wgrad_workspace_bytes": (_i64, []),

@@ -123,6 +123,7 @@ def split_rows(view):
 
 COLSUM = os.environ.get("DD_DCONV_COLSUM", "1") != "0"      # A/B knob: 0 = bias gradients of the up-convs by their own pass over dL/dy
 K2S2_WGRAD = os.environ.get("DD_K2S2_WGRAD", "1") != "0"      # A/B knob: 0 = the k2 s2 32->32 weight gradient by four phase launches
+SSCONV_FWD = os.environ.get("DD_SSCONV_FWD", "1") != "0"      # A/B knob: 0 = ss_conv's forward on the generic engine
 SSCONV_DGRAD = os.environ.get("DD_SSCONV_DGRAD", "1") != "0"      # A/B knob: 0 = ss_conv's data gradient by seven phase launches
 
 
@@ -220,7 +221,11 @@ class Layer:
         b = src.buf.shape[0]
         cs = src.chans if src.chans % 4 == 0 else self.cin_store
         _chk(weight, "weight")
-        if not self.transposed:
+        if (not self.transposed and self.k == (1, 24) and self.stride == (1, 7) and self.dil == (1, 1) and self.pad == (0, 0)
+                and self.cin == 32 and self.cout == 32 and mask is None and epilogue in (EPI_BIAS, EPI_BIAS_RELU) and SSCONV_FWD
+                and _whole(src) and _whole(dst) and src.coff == 0 and dst.coff == 0 and _ops().ssconv_dgrad_ok(dst.buf, src.buf)):
+            _ops().ssconv_fwd(src.buf, _p_weight(weight), bias, dst.buf, relu=epilogue == EPI_BIAS_RELU)      # ss_conv (csrc/ssconv.hip)
+        elif not self.transposed:
             d = _desc(b, src, dst, cs, self.cout, self.k, self.stride, self.dil, self.pad)
             _conv(src.buf, weight, bias, mask, dst.buf, d, epilogue, 0, self.cin * self.T, self.T, False, self.cout, self.cin)
         elif self.k2s2:

@@ -254,6 +254,13 @@ def ssconv_dgrad(g, wt, dx):
     check(_lib.lib().dd_ssconv_dgrad(_p(g), _p(wt), _p(dx), b, h, gw, dx.shape[2], _stream()), "dd_ssconv_dgrad")
 
 
+def ssconv_fwd(x, wt, bias, y, relu=True):
+    """x [B,h,xw,32], wt [32,32,1,24], bias [32] or None -> y [B,h,gw,32] = (relu)(Conv2d(32,32,(1,24),stride (1,7))(x)), one launch."""
+    assert tuple(wt.shape) == (32, 32, 1, 24) and wt.is_contiguous() and ssconv_dgrad_ok(y, x)
+    b, h, xw, _ = x.shape
+    check(_lib.lib().dd_ssconv_fwd(_p(x), _p(wt), _p(bias), _p(y), b, h, xw, y.shape[2], int(relu), _stream()), "dd_ssconv_fwd")
+
+
 def conv1x1_c32_c3_nchw(x, wt, bias):
     """x [B,h,w,32] NHWC, wt [32,3,1,1] -> ConvTranspose2d k1 [B,3,h,w] NCHW."""
     b, h, w, c = x.shape

@@ -423,6 +423,10 @@ int dd_deconv2x2_c32_wgrad(const float* x, const float* g, float* dw, float* db,
  * all dense NHWC fp32, gw = (xw - 24) / 7 + 1 <= 128.  Every element of dx is written (pixels no tap reaches get 0). */
 int32_t dd_ssconv_dgrad_supported(int32_t h, int32_t gw, int32_t xw);
 int dd_ssconv_dgrad(const float* g, const float* w, float* dx, int32_t batch, int32_t h, int32_t gw, int32_t xw, void* stream);
+/* The layer's forward (F.conv2d(x, w, b, stride=(1, 7)) [+ ReLU], spatial_bb/components.py:129,147): x [batch, h, xw, 32], y [batch, h, gw, 32]
+ * dense NHWC fp32, gw = (xw - 24) / 7 + 1; bias may be NULL. */
+int dd_ssconv_fwd(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t h, int32_t xw, int32_t gw, int32_t relu,
+                  void* stream);
 int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
                            void* stream);
 

@@ -776,3 +776,30 @@ def test_k2s2_weight_gradient_in_one_launch(dev, b, h, w, gcs, coff):
     for dw, db in outs:
         assert (dw.double() - wt.grad).abs().max().item() <= 2e-6 * wt.grad.abs().max().item()
         assert (db.double() - bias.grad).abs().max().item() <= 2e-6 * bias.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("b,h,xw", [(2, 5, 918), (3, 7, 311), (1, 4, 24), (2, 3, 919)])
+def test_ss_conv_forward_in_one_launch(dev, b, h, xw):
+    """csrc/ssconv.hip's forward against torch fp64 and the generic engine: full width, a narrow image (a ragged last m-tile), a single
+    output pixel, trailing input pixels no tap reaches."""
+    import torch.nn.functional as F
+    from driving_dirty_amd import gconv, synth
+    layer = gconv.Layer(32, 32, (1, 24), stride=(1, 7))
+    gw = (xw - 24) // 7 + 1
+    wt = synth.hash_uniform((32, 32, 1, 24), synth.key_salt("sfw"), -0.1, 0.1).to(dev)
+    bias = synth.hash_uniform((32,), synth.key_salt("sfb"), -0.5, 0.5).to(dev)
+    x = synth.hash_uniform((b, h, xw, 32), synth.key_salt("sfx"), -1.0, 1.0).to(dev)
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=(1, 7))).permute(0, 2, 3, 1)
+    outs = []
+    old = gconv.SSCONV_FWD
+    try:
+        for on in (True, False):
+            gconv.SSCONV_FWD = on
+            y = torch.full((b, h, gw, 32), float("nan"), device=dev)
+            layer.forward(wt, bias, gconv.View(x), gconv.View(y), gconv.EPI_BIAS_RELU)
+            outs.append(y)
+    finally:
+        gconv.SSCONV_FWD = old
+    scale = ref.abs().max().item()
+    for y in outs:
+        assert (y.double() - ref).abs().max().item() / scale < 2e-6
