@@ -257,6 +257,25 @@ def test_bench_two_ranks_over_gloo_on_one_card(dev, config):
     assert "[rank 0] bench.py preflight:" in err
 
 
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it(dev):
+    """The driver's N > 1 command line, verbatim, for the headline configuration: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W` -- both ranks on this card,
+    gradients over gloo.  One JSON line on stdout (rank 0's), the N = 2 default (factor gather) in it, a roofline and a preflight."""
+    env = dict(os.environ, DD_DIST_BACKEND="gloo", DD_RESERVED_CUS="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, [ln[:80] for ln in r.stdout.splitlines()]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 3 and line["warmup"] == 2
+    assert line["config"]["baseline_config"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 64
+    assert line["config"]["optimizer"].startswith("replicated; the big Linear layers all-gather")
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
+    assert "preflight" in line and "cpu_baseline" not in line          # the CPU baseline is timed at N = 1 only
+
+
 def test_simulated_shard_step_runs(dev):
     """`--simulate-shard 8`: the compute side of an 8-GPU sharded step on this one GPU (a timing aid; labelled as such)."""
     line, _ = _bench({}, "--steps", "3", "--warmup", "2", "--simulate-shard", "8")
