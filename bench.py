@@ -75,6 +75,9 @@ def parse_args():
                     help="data parallel: the big Linear layers all-gather their factors (input, output gradient: 202 MB per rank) instead "
                          "of reducing their weight gradients (648 MB); every rank forms the global-batch gradient itself.  auto = on at "
                          "N = 2 (one xGMI link carries the whole message), where it replaces the sharded optimizer")
+    ap.add_argument("--fuse-linear-wgrad", choices=("on", "off"), default="on",
+                    help="rank-B optimizer pass: the weight gradients of the big Linear layers are formed inside their Adam pass, never written "
+                         "(off: dd_linear_wgrad + dd_adam_step, the round-4 arrangement; A/B)")
     ap.add_argument("--simulate-shard", type=int, default=0, metavar="N",
                     help="one GPU, timing only: the COMPUTE side of an N-GPU sharded step (Adam on rank 0's 1/N of every big tensor, no "
                     "collectives; the parameters it leaves are meaningless) -- the per-GPU lower bound of the N-GPU step")
@@ -393,7 +396,7 @@ def other_configs(a, dev, steps=10, warmup=3):
     res = {}
 
     def run(name, model, batch, nbatch, extra=None, watch=None, cfg=None):
-        ts = TrainStep(model, lr=1e-3, scheduler=False)
+        ts = TrainStep(model, lr=1e-3, scheduler=False, fuse_linear_wgrad=getattr(a, "fuse_linear_wgrad", "on") == "on")
         timer = AbiTimer(watch) if watch else None
         if timer:
             timer.install()
@@ -570,6 +573,7 @@ def setup_config(a, dev, rank):
     flop = 136.448e9 + 6.0 * (pooled2 * HIDDEN + HIDDEN * HIDDEN + HIDDEN * LATENT + LATENT * 640000)
     is_c2 = lambda d: d.cin_real == 32 and d.stride == 1      # noqa: E731
     watch = {"adam_fc1": ("dd_adam_step", lambda *x: x[4] >= 100_000_000),
+             "adam_fc1_rankb": ("dd_adam_step_rankb", lambda *x: x[6] * x[7] >= 100_000_000),
              "c2_fwd_bf16": ("dd_conv_bf16_fwd", lambda *x: is_c2(_desc(x[5]))),
              "c2_dgrad_bf16": ("dd_conv_bf16_dgrad", lambda *x: is_c2(_desc(x[4]))),
              "c2_wgrad_bf16": ("dd_conv_bf16_wgrad", lambda *x: is_c2(_desc(x[4])))}
@@ -638,7 +642,7 @@ def refresh_traffic(roof, pmc):
         roof["traffic_live"] = how
 
 
-def config5_step_bytes(per_gpu_batch, shard_world=1):
+def config5_step_bytes(per_gpu_batch, shard_world=1, rankb=True):
     """Algorithmic HBM bytes of one config-5 step (bf16 activations, fp32 parameters): every activation
     written once and read once per consumer, the two big weights read twice and their gradients written once, Adam's seven
     passes over the parameters it owns.  P = full-resolution pixels of the batch (512 x 3672 per scene), q = P / 4."""
@@ -656,6 +660,8 @@ def config5_step_bytes(per_gpu_batch, shard_world=1):
                  + 72)   # c1 weight gradient: 8 + 64
     fc1 = (32 * 256 * 1836 // 4) * HIDDEN * 4.0
     head = LATENT * 640000 * 4.0
+    if rankb and shard_world == 1:      # rank-B optimizer pass: no dW written or read back (weights read twice; p, m, v read + written)
+        return P * float(per_pixel) + 2.0 * (fc1 + head) + 6.0 * (fc1 + head)
     return P * float(per_pixel) + 3.0 * (fc1 + head) + 7.0 * (fc1 + head) / shard_world
 
 
@@ -693,15 +699,18 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
                          frac=round(flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4))
         else:
             px = 512 * 3672 * per_gpu_batch
-            nbytes = {"adam_fc1": 28.0 * (32 * 256 * 1836 // 4) * HIDDEN,      # p, g, m, v read; p, m, v written: 7 x 4 B per element
+            pooled2 = 32 * 256 * 1836 // 4
+            nbytes = {"adam_fc1": 28.0 * pooled2 * HIDDEN,      # p, g, m, v read; p, m, v written: 7 x 4 B per element
+                      "adam_fc1_rankb": 24.0 * pooled2 * HIDDEN + 4.0 * per_gpu_batch * (pooled2 + HIDDEN),      # p, m, v read + written; the factors read
                       "c2_fwd_bf16": px * (64 + 64 + 4.0),                    # bf16 NHWC in + out, one sign word per pixel
                       "c2_dgrad_bf16": px * (64 + 64 + 4.0),
                       "c2_wgrad_bf16": px * (64 + 64.0)}[key]
-            flop = 0.0 if key == "adam_fc1" else 2.0 * px * 32 * 288
+            flop = 0.0 if key.startswith("adam_fc1") else 2.0 * px * 32 * 288
             t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), flop / (PEAK_BF16_MFMA_TF * 1e12)
             hbm_frac = round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
             mfma_frac = round(flop / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF, 4)
-            name = {"adam_fc1": "adam_kernel (fc1.fc1.weight, 481 M elements, side stream)", "c2_fwd_bf16": "conv_bf16_fwd (c2)",
+            name = {"adam_fc1": "adam_kernel (fc1.fc1.weight, 481 M elements, side stream)",
+                    "adam_fc1_rankb": "adam_rankb_lds_kernel (fc1.fc1.weight, 481 M elements: gradient formed in the pass, side stream)", "c2_fwd_bf16": "conv_bf16_fwd (c2)",
                     "c2_dgrad_bf16": "conv_bf16_dgrad (c2)", "c2_wgrad_bf16": "conv_bf16_wgrad (c2)"}[key]
             if t_hbm >= t_mfma:
                 entry.update(kernel=name, bound="hbm", achieved=round(nbytes / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
@@ -716,10 +725,11 @@ def watched_roofline(cfg, timer, per_gpu_batch, step_ms=None):
     roof = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
             "launch_ms": k["launch_ms"], "launches_timed": k["launches_timed"], "traffic": None, "kernels": kernels}
     if cfg == 5 and step_ms:
-        nbytes = config5_step_bytes(per_gpu_batch)
+        rankb = "adam_fc1_rankb" in kernels
+        nbytes = config5_step_bytes(per_gpu_batch, rankb=rankb)
         roof["step"] = {"algorithmic_bytes": nbytes, "TBps": round(nbytes / (step_ms * 1e-3) / 1e12, 3),
                         "hbm_frac": round(nbytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                        "of_which_adam_bytes": 7.0 * ((32 * 256 * 1836 // 4) * HIDDEN + LATENT * 640000) * 4.0}
+                        "of_which_adam_bytes": (6.0 if rankb else 7.0) * ((32 * 256 * 1836 // 4) * HIDDEN + LATENT * 640000) * 4.0}
     return roof
 
 
@@ -934,7 +944,8 @@ def run_rank(a):
     if factor:
         shard = False
     ts = TrainStep(model, lr=1e-3, adam_overlap=overlap, shard_optimizer=shard, reserve_cus=reserve, force_collectives=rehearse,
-                   simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False, factor_linear=factor)
+                   simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False, factor_linear=factor,
+                   fuse_linear_wgrad=a.fuse_linear_wgrad == "on")
     if a.config == 2:
         timer = KernelTimer()
     else:
@@ -996,7 +1007,11 @@ def run_rank(a):
                              "tensor, no collectives; a per-GPU lower bound, not a training step (parameters meaningless)"} if a.simulate_shard > 1 else {}),
             "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
-                       "adam_overlap": bool(overlap), "optimizer": "sharded (reduce-scatter, Adam on 1/N, all-gather)" if shard else
+                       "adam_overlap": bool(overlap),
+                       "linear_wgrad": ("formed inside the Adam pass (rank-B): " + ", ".join(sorted(n for n, p in model.named_parameters()
+                                                                                                      if any(p is w for w in ts.fused))))
+                       if ts.fused and not (shard or (comm and not factor)) else "materialised (dd_linear_wgrad + dd_adam_step)",
+                       "optimizer": "sharded (reduce-scatter, Adam on 1/N, all-gather)" if shard else
                        ("replicated; the big Linear layers all-gather their factors, every rank forms the global-batch gradient" if factor
                         else "replicated")},
             # the step's algorithmic flops over its time, against the dense matrix peak of the dtype its convolutions run in

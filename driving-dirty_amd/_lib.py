@@ -175,6 +175,8 @@ SIGNATURES = {
     "dd_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
     "dd_bf16_to_f32": (_i32, [_p, _p, _i64, _p]),
     "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
+    "dd_adam_step_rankb": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
+    "dd_column_sum": (_i32, [_p, _p, _i32, _i32, _p]),
     "dd_adam_step_multi": (_i32, [C.POINTER(AdamTensor), _i32, _f32, _f32, _f32, _f32, _i32, _f32, _p]),
 }
 

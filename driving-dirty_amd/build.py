@@ -16,9 +16,12 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdd_hotpath.so")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["runtime.hip", "conv3x3.hip", "layout_pool.hip", "dense.hip", "linear.hip", "gconv.hip", "dconv.hip", "dconv_t.hip", "dconv_m.hip", "dconv_split.hip", "conv1ch.hip", "ssconv.hip", "bn2d.hip", "raster.hip",
-           "conv3x3_bf16.hip", "mlp_tail.hip"]
+           "conv3x3_bf16.hip", "mlp_tail.hip", "adam_rankb.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-HEADERS = [os.path.join(CSRC, "dd_common.h"), os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "dd_hotpath.h")]
+# per-file additions.  adam_rankb.hip: MFMA accumulators in ordinary vector registers (the kernel's whole budget is 72 registers, and the
+# default form keeps a second copy of the accumulators in the accumulation registers)
+EXTRA_FLAGS = {"adam_rankb.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+HEADERS = [os.path.join(CSRC, "dd_common.h"), os.path.join(CSRC, "dd_adam.h"), os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "dd_hotpath.h")]
 
 
 def _obj(src):
@@ -46,7 +49,7 @@ def build_diag(verbose=True):
     def one(src):
         obj = os.path.join(out, os.path.splitext(src)[0] + ".o")
         if _stale(obj, [os.path.join(CSRC, src)] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-DDD_TIMING_DIAG", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-DDD_TIMING_DIAG", "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -66,7 +69,7 @@ def build(force=False, verbose=True):
     todo = [s for s in SOURCES if force or _stale(_obj(s), [os.path.join(CSRC, s)] + HEADERS)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

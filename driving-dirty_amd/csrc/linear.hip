@@ -359,6 +359,24 @@ __global__ __launch_bounds__(256) void linear_wgrad_wide_kernel(const float* __r
   }
 }
 
+// db[n] = sum_m dY[m][n]: the bias gradient alone, for a layer whose weight gradient is formed elsewhere (dd_adam_step_rankb without a
+// registered bias, ddp factor mode without rank-B).  One thread per 4 columns, rows in order: deterministic.
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ dY, float* __restrict__ db, int M, int N) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;
+  if (c + 4 <= N && N % 4 == 0) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < M; ++m) s += *(const f32x4*)(dY + (long)m * N + c);
+    *(f32x4*)(db + c) = s;
+  } else {
+    for (int j = c; j < min(c + 4, N); ++j) {
+      float s = 0.f;
+      for (int m = 0; m < M; ++m) s += dY[(long)m * N + j];
+      db[j] = s;
+    }
+  }
+}
+
 int pick_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 0); }   // 64 KB of static LDS caps the batch tile at 64 rows
 
 int pick_split(int blocks_other, int ntiles) {
@@ -436,6 +454,14 @@ int dd_linear_dgrad(const float* dy, const float* w, float* dx, int32_t m, int32
     launch_splits_reduce(part, nullptr, dx, elems, nsplit, k, st);
     DD_LAUNCH_CHECK("linear_dgrad reduce");
   }
+  return 0;
+}
+
+int dd_column_sum(const float* dy, float* dbias, int32_t m, int32_t n, void* stream) {
+  DD_REQUIRE(dy && dbias && m > 0 && n > 0, DD_ERR_BAD_ARG, "column_sum: bad argument");
+  DD_REQUIRE(n % 4 != 0 || ((uintptr_t)dy | (uintptr_t)dbias) % 16 == 0, DD_ERR_BAD_ARG, "column_sum: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(column_sum_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dy, dbias, m, n);
+  DD_LAUNCH_CHECK("column_sum");
   return 0;
 }
 

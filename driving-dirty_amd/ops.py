@@ -748,6 +748,10 @@ def _linear_ws(m, n, k, device):
     return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
 
 
+# data_ptr of an nn.Linear weight -> optim.HipAdam in rank-B mode: Linear.backward hands (x, dy) over instead of forming dW
+RANKB = {}
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T + b with nn.Linear's [out, in] weight, all three passes on the fp32 matrix cores
     (dd_linear_fwd / dgrad / wgrad).  Reference call sites: components.py:105 (DenseBlock.fc1),
@@ -766,7 +770,8 @@ class Linear(torch.autograd.Function):
         check(_lib.lib().dd_linear_fwd(_p(x), _p(weight), _p(bias), _p(y), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_fwd")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        if _ddp.FACTOR_SYNC and weight.requires_grad and torch.is_grad_enabled():
+        # (grad mode is always off inside Function.forward: whether this call will be differentiated is ctx.needs_input_grad)
+        if _ddp.FACTOR_SYNC and ctx.needs_input_grad[1]:
             sync = _ddp.FACTOR_SYNC.get(weight.data_ptr())
             if sync is not None:      # factor mode: a big input (fc1's 120 MB of pooled activations) starts its gather now, not in the backward
                 sync.linear_input(weight, x)
@@ -784,10 +789,17 @@ class Linear(torch.autograd.Function):
             ws, nbytes = _linear_ws(m, n, k, x.device)
             check(_lib.lib().dd_linear_dgrad(_p(dy), _p(weight), _p(dx), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_dgrad")
         sync = _ddp.FACTOR_SYNC.get(weight.data_ptr()) if _ddp.FACTOR_SYNC else None
+        fused = RANKB.get(weight.data_ptr()) if RANKB else None
+        taken = 0
         if sync is not None and ctx.needs_input_grad[1] and sync.linear_factors(weight, x, dy):
             # data parallel, factor mode (ddp.GradSync): x and dy travel instead of dW; the optimizer forms the global-batch gradient
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = dy.sum(0)
+            # (rank-B mode of the optimizer: inside its Adam pass, the bias from the gathered dy as well)
+            if ctx.has_bias and ctx.needs_input_grad[2] and not (fused is not None and fused.factor_bias(weight)):
+                db = column_sum(dy)
+        elif fused is not None and ctx.needs_input_grad[1] and (taken := fused.linear_factors(weight, x, dy)):
+            # rank-B mode (optim.HipAdam): no dW at all, dd_adam_step_rankb forms it from (x, dy) inside the optimizer pass
+            if taken == 1 and ctx.has_bias and ctx.needs_input_grad[2]:
+                db = column_sum(dy)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(n, device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -797,6 +809,16 @@ class Linear(torch.autograd.Function):
 
 def linear(x, weight, bias):
     return Linear.apply(x.contiguous(), weight, bias)
+
+
+def column_sum(dy):
+    """db [n] = sum over the rows of dy [m, n] on the hot path's own kernel (dd_column_sum): the bias gradient of a Linear layer whose
+    weight gradient is not formed by dd_linear_wgrad."""
+    m, n = dy.shape
+    _dev(dy, "dy")
+    db = torch.empty(n, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().dd_column_sum(_p(dy), _p(db), m, n, _stream()), "dd_column_sum")
+    return db
 
 
 def linear_wgrad(dy, x, dw):
@@ -1105,6 +1127,23 @@ def adam_step_multi(tensors, lr, beta1, beta2, eps, step, grad_scale=1.0):
         table[i] = _lib.AdamTensor(_p(quad[0]), _p(quad[1]), _p(quad[2]), _p(quad[3]), quad[0].numel())
     check(_lib.lib().dd_adam_step_multi(table, len(tensors), lr, beta1, beta2, eps, int(step), grad_scale, _stream()),
           "dd_adam_step_multi")
+
+
+def adam_step_rankb(p, m, v, dy, x, bias, bias_m, bias_v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """Adam on the Linear weight ``p`` [n, k] (moments ``m``, ``v``) with its gradient dy^T x formed inside the pass from the layer's
+    output gradient ``dy`` [rows, n] and input ``x`` [rows, k]; ``bias`` (optional, with its moments) is updated from dy's column sums
+    in the same launch (dd_adam_step_rankb)."""
+    rows, n = dy.shape
+    k = x.shape[1]
+    _dev(dy, "dy")
+    _dev(x, "x", (rows, k))
+    for name, t in (("p", p), ("m", m), ("v", v)):
+        _dev(t, name, (n, k))
+    if bias is not None:
+        for name, t in (("bias", bias), ("bias_m", bias_m), ("bias_v", bias_v)):
+            _dev(t, name, (n,))
+    check(_lib.lib().dd_adam_step_rankb(_p(p), _p(m), _p(v), _p(dy), _p(x), rows, n, k, _p(bias), _p(bias_m), _p(bias_v),
+                                        lr, beta1, beta2, eps, int(step), grad_scale, _stream()), "dd_adam_step_rankb")
 
 
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):

@@ -4,6 +4,14 @@ executed by ``dd_adam_step``, one fused read-modify-write pass per parameter ten
 ``grad_scale`` folds the 1/world_size of data-parallel gradient averaging into the same pass, so the
 all-reduced SUM never needs a separate divide kernel.
 
+Rank-B mode (``fuse_linear_wgrad(module)``; round 5): the weight gradient of a big ``nn.Linear`` is never written.  ``ops.Linear.backward``
+hands its factors -- the layer's input X [rows, in] and output gradient dY [rows, out] -- to ``linear_factors`` instead of launching
+``dd_linear_wgrad``, ``weight.grad`` stays None, and ``dd_adam_step_rankb`` forms every gradient element dW[o][i] = sum_b dY[b][o] X[b][i]
+in MFMA accumulators inside the optimizer pass (bias: the column sum of dY, updated by the same launch): six passes over the tensor
+instead of eight (reference call sites: components.py:105, roadmap_bce_v2.py:75,154-157).  Used when the gradient does not have to
+travel as a tensor: one GPU, or ``GradSync`` factor mode (the gathered factors feed the same kernel).  With an all-reduce or a sharded
+``GradSync`` the layer keeps its materialised gradient.
+
 Shard mode (``attach(grad_sync)`` / ``overlap_with_backward(grad_sync=...)`` with ``GradSync(shard_optimizer=True)``): a tensor
 that travels as reduce-scatter + all-gather is updated only in the slices this rank owns (``grad_sync.shards(p)``), its moments
 exist only for those slices (``state[p]["shards"][piece] = (exp_avg, exp_avg_sq)``), and each updated slice is handed straight
@@ -30,6 +38,11 @@ class HipAdam(torch.optim.Optimizer):
         self._sync = None
         self._factored = []        # parameters whose factors are on the links (ddp.GradSync, factor mode)
         self._fgrad = {}           # p -> persistent buffer of the global-batch gradient formed from gathered factors
+        self._rankb = {}           # weight -> bias (or None): Linear layers whose gradient is formed inside the Adam pass
+        self._rankb_keys = {}      # data_ptr -> weight
+        self._rankb_now = {}       # weight -> (x, dy) of this step's backward, until the pass has been launched
+        self._held = []            # factors read by launches on the side stream: kept until step() has joined it
+        self._fac_now = {}         # weight -> gathered Factors that have arrived (factor mode of ddp.GradSync + rank-B)
 
     SMALL_NUMEL = int(os.environ.get("DD_ADAM_MULTI_NUMEL", 1 << 16))      # tensors up to this size go into one multi-tensor launch (0: never)
 
@@ -45,6 +58,93 @@ class HipAdam(torch.optim.Optimizer):
         """The one place the elementwise kernel is called (flat fp32 device tensors of equal length)."""
         b1, b2 = group["betas"]
         ops.adam_step_flat(p, g, m, v, group["lr"], b1, b2, group["eps"], step, grad_scale)
+
+    # ---- rank-B mode -----------------------------------------------------------------------------------------------------------
+    def fuse_linear_wgrad(self, module, min_numel=None):
+        """Register every ``nn.Linear`` of ``module`` whose weight has >= ``min_numel`` elements (default: the big-tensor threshold)
+        and belongs to this optimizer: from now on its weight gradient is formed inside its Adam pass (``dd_adam_step_rankb``) and
+        ``weight.grad`` / ``bias.grad`` stay None after a backward.  Returns the registered weights."""
+        owned = {id(p) for group in self.param_groups for p in group["params"]}
+        limit = self._big_numel if min_numel is None else min_numel
+        done = []
+        for mod in module.modules():
+            w = getattr(mod, "weight", None)
+            if not isinstance(mod, torch.nn.Linear) or w is None or id(w) not in owned or w.numel() < limit:
+                continue
+            if not (w.is_cuda and w.dtype == torch.float32 and w.data.is_contiguous() and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0):
+                continue
+            b = mod.bias if (mod.bias is not None and id(mod.bias) in owned and mod.bias.dtype == torch.float32) else None
+            self._rankb[w] = b
+            self._rankb_keys[w.data_ptr()] = w
+            ops.RANKB[w.data_ptr()] = self
+            done.append(w)
+        return done
+
+    def _sync_blocks_rankb(self):
+        """A gradient that has to travel as a tensor (all-reduce or reduce-scatter) must exist as one."""
+        s = self._sync
+        return s is not None and (getattr(s, "active", False) or getattr(s, "shard", False)) and not getattr(s, "factor", False)
+
+    def linear_factors(self, weight, x, dy):
+        """Called by ``ops.Linear.backward`` (on the backward's stream) for a weight registered in ``ops.RANKB``.  Returns 0: declined,
+        the caller forms dW and db as usual; 1: the weight's gradient will be formed from (x, dy) inside its Adam pass, the caller
+        still owes db; 2: the bias is updated by that pass too."""
+        p = self._rankb_keys.get(weight.data_ptr())
+        if p is None or not p.requires_grad or p.grad is not None or self._sync_blocks_rankb():
+            return 0
+        if not (x.is_contiguous() and dy.is_contiguous() and x.dtype == torch.float32 and dy.dtype == torch.float32):
+            return 0
+        bias = self._rankb[p]
+        if bias is not None and (not bias.requires_grad or bias.grad is not None):
+            bias = None
+        if p in self._early:
+            raise RuntimeError("HipAdam (rank-B mode): a Linear layer ran a second backward after its optimizer pass of this step was "
+                               "launched; call step() between the backwards or build TrainStep(fuse_linear_wgrad=False)")
+        prev = self._rankb_now.get(p)
+        if prev is not None:      # a second backward through the layer before the step (shared weight, retained graph): the gradients add
+            x, dy = torch.cat([prev[0], x]), torch.cat([prev[1], dy])
+        else:
+            self._queue_rankb(p)
+        self._rankb_now[p] = (x, dy, bias)
+        return 2 if bias is not None else 1
+
+    def factor_bias(self, weight):
+        """Factor mode of ddp.GradSync: whether the pass over the gathered factors will update this layer's bias too (then the caller
+        owes no bias gradient)."""
+        p = self._rankb_keys.get(weight.data_ptr())
+        bias = self._rankb.get(p) if p is not None else None
+        return bias is not None and bias.requires_grad and bias.grad is None and not self._sync_blocks_rankb()
+
+    def _queue_rankb(self, p):
+        if self._side is not None and p.numel() >= self._big_numel:
+            self._pending.append((p, self._group_of(p)))      # launched on the side stream when backward reaches its MFMA-bound stretch
+
+    def _update_rankb(self, p, group, grad_scale, x, dy, bias):
+        """The one place ``dd_adam_step_rankb`` is called: Adam on ``p`` (and ``bias``) with the gradient dy^T x formed on the fly."""
+        st = self._state_of(p)
+        if "shards" in st:
+            raise RuntimeError("HipAdam: a sharded tensor cannot take a rank-B update")
+        st["step"] += 1
+        bst = None
+        if bias is not None:
+            bst = self._state_of(bias)
+            bst["step"] += 1
+            if bst["step"] != st["step"]:
+                raise RuntimeError("HipAdam: a Linear layer's weight and bias have taken different numbers of steps")
+            self._early.add(bias)
+        b1, b2 = group["betas"]
+        ops.adam_step_rankb(p.data, st["exp_avg"], st["exp_avg_sq"], dy, x, None if bias is None else bias.data,
+                            None if bst is None else bst["exp_avg"], None if bst is None else bst["exp_avg_sq"],
+                            group["lr"], b1, b2, group["eps"], st["step"], grad_scale)
+        self._held.append((x, dy))
+        self._early.add(p)
+
+    def _take_rankb(self, p, group, grad_scale):
+        now = self._rankb_now.pop(p, None)
+        if now is None:
+            return False
+        self._update_rankb(p, group, grad_scale, *now)
+        return True
 
     def attach(self, grad_sync):
         """Use ``grad_sync`` (ddp.GradSync) for per-piece waits and, in shard mode, for the shards and their all-gathers."""
@@ -66,6 +166,9 @@ class HipAdam(torch.optim.Optimizer):
             return False
         for work in fac.works:
             work.wait()
+        if p in self._rankb:      # rank-B mode: no gradient tensor at all, the gathered factors go straight into the Adam pass
+            self._fac_now[p] = fac
+            return True
         g = self._fgrad.get(p)
         if g is None or g.shape != p.shape or g.device != p.device:
             g = self._fgrad[p] = torch.empty_like(p, memory_format=torch.contiguous_format)
@@ -73,10 +176,20 @@ class HipAdam(torch.optim.Optimizer):
         p.grad = g
         return True
 
+    def _update_formed(self, p, group, grad_scale):
+        """The Adam pass behind ``_form_factored``: from ``p.grad``, or -- rank-B mode -- straight from the gathered factors."""
+        fac = self._fac_now.pop(p, None)
+        if fac is None:
+            return self._update(p, group, grad_scale)
+        bias = self._rankb[p]
+        if bias is not None and (not bias.requires_grad or bias.grad is not None):
+            bias = None
+        self._update_rankb(p, group, grad_scale, fac.x_all, fac.dy_all, bias)
+
     def _update_factored(self, p, group, grad_scale):
         if not self._form_factored(p):
             return False
-        self._update(p, group, grad_scale)
+        self._update_formed(p, group, grad_scale)
         return True
 
     @torch.no_grad()
@@ -93,7 +206,7 @@ class HipAdam(torch.optim.Optimizer):
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
             for p in done:
-                self._update(p, self._group_of(p), self._scale)
+                self._update_formed(p, self._group_of(p), self._scale)
                 self._early.add(p)
 
     def _update_shards(self, p, group, grad_scale, shards):
@@ -158,7 +271,11 @@ class HipAdam(torch.optim.Optimizer):
         self._pending = []
         self._big_numel = big_numel
         self._hooked = set()
-        ops.MFMA_PHASE_HOOKS.append(self._flush_pending)
+        if os.environ.get("DD_ADAM_LATE") == "1":      # EXPERIMENT: c2's data gradient first (alone), the passes beside its weight gradient, last
+            ops.MFMA_PHASE2_HOOKS.append(self._flush_pending)
+            ops.C2_DGRAD_FIRST = True
+        else:
+            ops.MFMA_PHASE_HOOKS.append(self._flush_pending)
         ops.MFMA_PHASE2_HOOKS.append(self._flush_factored)
         if getattr(self._sync, "factor", False):
             ops.C2_DGRAD_FIRST = True             # the Adam passes behind the gathered factors run beside c2's weight gradient: it goes last
@@ -184,6 +301,10 @@ class HipAdam(torch.optim.Optimizer):
             h.remove()
         self._hooks = []
         self._hooked = set()
+        for key in list(self._rankb_keys):
+            if ops.RANKB.get(key) is self:
+                del ops.RANKB[key]
+        self._rankb, self._rankb_keys, self._rankb_now, self._fac_now = {}, {}, {}, {}
         if self._flush_pending in ops.MFMA_PHASE_HOOKS:
             ops.MFMA_PHASE_HOOKS.remove(self._flush_pending)
         if self._flush_factored in ops.MFMA_PHASE2_HOOKS:
@@ -207,6 +328,8 @@ class HipAdam(torch.optim.Optimizer):
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
             for p, group in self._pending:
+                if self._take_rankb(p, group, self._scale):
+                    continue
                 shards = self._sync.shards(p) if self._sync is not None else None
                 pieces = self._sync.pieces(p) if self._sync is not None else None
                 if shards:                        # sharded optimizer: this rank's slices only, each all-gathered behind its update
@@ -226,6 +349,9 @@ class HipAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             small = {}                            # step count -> [(p, g, m, v)]: one launch for all the small tensors
             for p in group["params"]:
+                if p in self._rankb_now and p not in self._early:      # rank-B mode without the side stream: here, after the backward
+                    self._take_rankb(p, group, grad_scale)
+                    continue
                 if p not in self._early and self._sync is not None and getattr(self._sync, "factor", False) and self._sync.has_factors(p):
                     self._update_factored(p, group, grad_scale)      # no side stream: here, after the backward
                     continue
@@ -248,3 +374,6 @@ class HipAdam(torch.optim.Optimizer):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._early.clear()
+        self._held.clear()
+        self._rankb_now.clear()
+        self._fac_now.clear()

@@ -8,7 +8,9 @@ validation loss for the road-map modules (roadmap_bce_v2.py:154-157) -- and, und
 exactly that (torch.optim.Adam): a caller with its own loop keeps working.  This helper is the SAME step arranged for the MI355X:
 
   * ``optim.HipAdam`` (one fused pass per tensor, torch.optim.Adam's arithmetic) with the pass of the big tensors on a side stream
-    beside the MFMA-bound stretch of the backward (``overlap_with_backward``);
+    beside the MFMA-bound stretch of the backward (``overlap_with_backward``); the big ``nn.Linear`` weights (encoder fc1, head,
+    decoder fc2) take a rank-B update: their gradient is formed inside the Adam pass from the layer's input and output gradient and
+    never written (``fuse_linear_wgrad``; ``weight.grad`` of those layers stays None -- pass ``fuse_linear_wgrad=False`` to keep it);
   * ``ddp.GradSync`` when ``torch.distributed`` is initialised: per-tensor asynchronous all-reduce from autograd hooks, or -- with
     ``shard_optimizer=True`` -- reduce-scatter, Adam on the owned 1/N, in-place all-gather under the next forward; or -- with
     ``factor_linear=True``, for 2-4 ranks -- the big Linear layers send their factors (input, output gradient) instead of their
@@ -29,7 +31,8 @@ from .optim import HipAdam
 
 class TrainStep:
     def __init__(self, model, lr=None, adam_overlap=True, shard_optimizer=False, reserve_cus=None, process_group=None,
-                 force_collectives=False, simulate_world=0, scheduler="auto", big_numel=1 << 20, chunk_numel=1 << 25, factor_linear=False):
+                 force_collectives=False, simulate_world=0, scheduler="auto", big_numel=1 << 20, chunk_numel=1 << 25, factor_linear=False,
+                 fuse_linear_wgrad=True):
         self.model = model
         hp = getattr(model, "hparams", None)
         if lr is None:
@@ -52,6 +55,9 @@ class TrainStep:
         if self.overlap:
             self.optimizer.overlap_with_backward(big_numel=big_numel, grad_scale=self.sync.grad_scale,
                                                  grad_sync=self.sync if (self.sync.active or self.sync.shard) else None)
+        # rank-B mode: the weight gradient of the big Linear layers is formed inside their Adam pass, never written (optim.py); the
+        # optimizer declines by itself where the gradient has to travel as a tensor (all-reduce / sharded GradSync)
+        self.fused = self.optimizer.fuse_linear_wgrad(model, min_numel=big_numel) if fuse_linear_wgrad else []
         if scheduler == "auto":      # the modules that return ([optimizer], [scheduler]) from configure_optimizers
             scheduler = self._reference_has_scheduler(model)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, patience=10) if scheduler else None

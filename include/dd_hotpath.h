@@ -489,6 +489,9 @@ int dd_linear_dgrad(const float* dy, const float* w, float* dx, int32_t m, int32
                     int64_t workspace_bytes, void* stream);
 int dd_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int32_t m, int32_t n, int32_t k,
                     void* stream);
+/* dbias[N] = sum_m dy[m,:] alone: the bias gradient of a layer whose weight gradient is formed inside its optimizer pass
+ * (dd_adam_step_rankb) while its bias is updated the ordinary way (components.py:105, roadmap_bce_v2.py:75). */
+int dd_column_sum(const float* dy, float* dbias, int32_t m, int32_t n, void* stream);
 
 /* Threat score tp / (sum a + sum b - tp), tp = sum a*b (reference src/utils/helper.py:74-77); round_b != 0 scores
  * round(b) (roadmap_bce_v2.py:140).  One pass, deterministic. */
@@ -514,6 +517,17 @@ typedef struct dd_adam_tensor {
 } dd_adam_tensor;
 int dd_adam_step_multi(const dd_adam_tensor* tensors, int32_t count, float lr, float beta1, float beta2, float eps,
                        int32_t step, float grad_scale, void* stream);
+
+/* Rank-B form of the same update for an nn.Linear weight p [n][k] (reference: DenseBlock.fc1 components.py:27,70,105; the road-map head
+ * roadmap_bce_v2.py:50,75; optimizer autoencoder.py:119-120, roadmap_bce_v2.py:154-157): the gradient is NOT an input.  It is formed
+ * inside the pass, dW[o][i] = sum_b dy[b][o] x[b][i], from the layer's output gradient dy [rows][n] and input x [rows][k] (rows = the
+ * batch, or world x batch for all-gathered factors) on the fp32 matrix cores, and consumed by the update of the same lane: p, m, v are
+ * read and written once each, no dW tensor exists (dd_linear_wgrad + dd_adam_step: two more passes over the tensor).  bias_p / bias_m /
+ * bias_v (all three or none): the layer's bias [n] and its moments, updated in the same launch from the column sums of dy.
+ * k % 4 == 0; p, m, v, x 16-byte aligned; same arithmetic per element as dd_adam_step (gradient: fp32 MFMA accumulation over rows). */
+int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const float* x, int32_t rows, int32_t n, int32_t k,
+                       float* bias_p, float* bias_m, float* bias_v, float lr, float beta1, float beta2, float eps, int32_t step,
+                       float grad_scale, void* stream);
 
 /* ---- Winograd F(2,3) along x for the 32 -> 32 stride-1 layer (c2, components.py:20): the same outputs as
  * dd_conv_fwd_relu_bits / dd_conv_dgrad_relu_bits from 2/3 of the multiplies (4 per output-pixel pair and tap row

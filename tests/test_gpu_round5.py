@@ -1,0 +1,153 @@
+"""GPU tests, fifth set: the rank-B optimizer pass (``dd_adam_step_rankb``: the weight gradient of a big Linear layer formed inside its
+Adam pass, reference components.py:105 / roadmap_bce_v2.py:75,154-157) against fp64, and ``TrainStep`` with it against the materialised
+gradient path."""
+import os
+import sys
+from argparse import Namespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_round4 import _tiny_batch, _tiny_model  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from driving_dirty_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _adam64(p, m, v, g, lr, b1, b2, eps, step):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+
+
+# n x k (multiples of 4, as every Linear kernel of the path asks): whole tiles, ragged last n-tile (52 = 3 x 16 + 4) and n-group, ragged
+# last k-tile (132 = 2 x 64 + 4), one k-tile (the head's shape class), less than one tile, more group-tiles than workgroups (350 > 256)
+RANKB_SHAPES = [(128, 1024), (52, 132), (640, 64), (20, 4), (16 * 70, 64 * 20)]
+
+
+@pytest.mark.parametrize("n,k", RANKB_SHAPES)
+@pytest.mark.parametrize("rows,with_bias,scale", [(32, True, 1.0), (7, False, 1.0), (64, True, 0.5), (1, True, 1.0)])
+@pytest.mark.parametrize("signed", [True, False])
+def test_adam_rankb_matches_fp64(dev, n, k, rows, with_bias, scale, signed):
+    """Three steps of dd_adam_step_rankb against torch.optim.Adam's arithmetic in fp64 on the fp64 gradient dy^T x (and dy's column sums
+    for the bias): m, v to fp32 rounding of the gradient, p within the Adam kernel's own 1e-6.  Signed factors: the gradient elements
+    that cancel to nearly zero carry the fp32 sum's ABSOLUTE rounding as a large RELATIVE error, and Adam's m / sqrt(v) turns that into
+    the same fraction of a full-size update (any fp32 gradient does, torch's included): there p is held to a fifth of one update (the worst of 1.4 M elements measured 4 %), and the
+    1e-6 is checked on the unsigned run, where every gradient element is well conditioned."""
+    from driving_dirty_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + k + rows)
+    p0 = (torch.rand(n, k, generator=g) - 0.5)
+    b0 = (torch.rand(n, generator=g) - 0.5)
+    p, m, v = p0.clone().to(dev), torch.zeros(n, k, device=dev), torch.zeros(n, k, device=dev)
+    b, bm, bv = b0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pr, mr, vr = p0.double(), torch.zeros(n, k, dtype=torch.float64), torch.zeros(n, k, dtype=torch.float64)
+    br, bmr, bvr = b0.double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    # the kernels take beta1 / beta2 as fp32 arguments: 1 - fp32(0.999) is 1.3e-5 off 1 - 0.999, in v itself but not in v_hat (the bias
+    # correction is computed from the same fp32 value), so the reference uses the rounded betas to judge m and v at rounding level
+    b1, b2 = float(torch.tensor(0.9, dtype=torch.float32)), float(torch.tensor(0.999, dtype=torch.float32))
+    for step in range(1, 4):
+        x = torch.rand(rows, k, generator=g) - (0.5 if signed else 0.0)
+        dy = (torch.rand(rows, n, generator=g) - (0.5 if signed else 0.0)) * 0.1 * step
+        gw = dy.double().t() @ x.double() * scale
+        _adam64(pr, mr, vr, gw, 1e-3, b1, b2, 1e-8, step)
+        _adam64(br, bmr, bvr, dy.double().sum(0) * scale, 1e-3, b1, b2, 1e-8, step)
+        ops.adam_step_rankb(p, m, v, dy.to(dev), x.to(dev), b if with_bias else None, bm if with_bias else None,
+                            bv if with_bias else None, 1e-3, 0.9, 0.999, 1e-8, step, scale)
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+    assert rel(m, mr) < 2e-6 and rel(v, vr) < 2e-6
+    if signed:
+        assert float((p.double().cpu() - pr).abs().max()) < 0.2 * 1e-3
+    else:
+        assert rel(p, pr) < 1e-6
+    if with_bias:
+        assert rel(bm, bmr) < 2e-6 and (signed or rel(b, br) < 1e-6)
+    else:
+        assert torch.equal(b.cpu(), b0) and float(bm.abs().max()) == 0.0
+
+
+def test_adam_rankb_refuses_bad_arguments(dev):
+    from driving_dirty_amd import _lib, ops
+    p = torch.zeros(16, 6, device=dev)
+    with pytest.raises(_lib.HotpathError):      # K % 4 != 0
+        ops.adam_step_rankb(p, p.clone(), p.clone(), torch.zeros(4, 16, device=dev), torch.zeros(4, 6, device=dev), None, None, None,
+                            1e-3, 0.9, 0.999, 1e-8, 1)
+    p = torch.zeros(16, 8, device=dev)
+    with pytest.raises(_lib.HotpathError):      # factor shapes disagree with the weight
+        ops.adam_step_rankb(p, p.clone(), p.clone(), torch.zeros(4, 16, device=dev), torch.zeros(5, 8, device=dev), None, None, None,
+                            1e-3, 0.9, 0.999, 1e-8, 1)
+
+
+def test_column_sum_matches_fp64(dev):
+    from driving_dirty_amd import ops
+    for m, n in ((32, 640), (7, 50), (3, 1027)):
+        dy = torch.rand(m, n, device=dev) - 0.5
+        got = ops.column_sum(dy)
+        ref = dy.double().sum(0)
+        assert float((got.double() - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_trainstep_rankb_matches_the_materialised_gradient_path(dev, overlap):
+    """TrainStep(fuse_linear_wgrad=True): the two big Linear layers (head 640000 x 8, encoder fc1 16 x 1056) never get a ``.grad``; their
+    Adam pass forms it.  After every step the parameters equal those of the materialised path (same gradient products, summed four
+    batch rows per matrix instruction instead of two) within the Adam kernel's 1e-6; both start each step from the same parameters."""
+    from driving_dirty_amd.train import TrainStep
+    a, b = _tiny_model(dev), _tiny_model(dev)
+    ta = TrainStep(a, lr=1e-2, adam_overlap=overlap, big_numel=4096, scheduler=False, fuse_linear_wgrad=False)
+    tb = TrainStep(b, lr=1e-2, adam_overlap=overlap, big_numel=4096, scheduler=False)
+    assert not ta.fused and {id(w) for w in tb.fused} == {id(b.fc1.weight), id(b.ae.encoder.fc1.fc1.weight)}
+    for step in range(3):
+        if step:
+            with torch.no_grad():
+                for p, q in zip(a.parameters(), b.parameters()):
+                    p.copy_(q)
+            for (_, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+                u.copy_(v)
+        batch = _tiny_batch(dev, step, 0)
+        la, lb = ta(batch, step)["loss"], tb(batch, step)["loss"]
+        assert float(la.detach()) == float(lb.detach())
+        assert a.fc1.weight.grad is not None and a.fc1.bias.grad is not None
+        assert b.fc1.weight.grad is None and b.fc1.bias.grad is None and b.ae.encoder.fc1.fc1.weight.grad is None
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            if k.endswith("fc1.fc1.bias"):      # a Linear bias in front of a train-mode BatchNorm: its gradient is exactly zero, in fp32 it is
+                continue                        # the rounding noise of the column sum, and Adam steps +-lr on the SIGN of that noise (either path)
+            d = float((p.detach() - q.detach()).abs().max() / p.detach().abs().max().clamp_min(1e-30))
+            assert d <= 1e-6, (step, k, d)
+        sa, sb = ta.optimizer.state[a.fc1.weight], tb.optimizer.state[b.fc1.weight]
+        assert sa["step"] == sb["step"] == step + 1
+        assert tb.optimizer.state[b.fc1.bias]["step"] == step + 1
+    ta.close()
+    tb.close()
+    from driving_dirty_amd import ops
+    assert not ops.RANKB
+
+
+def test_rankb_two_backwards_before_the_step_add_up(dev):
+    """Two backwards through a registered layer before one optimizer step (gradient accumulation): the factors are concatenated, the
+    update equals the materialised path's on the summed gradient."""
+    from driving_dirty_amd import ops
+    from driving_dirty_amd.optim import HipAdam
+    torch.manual_seed(5)
+    lin_a, lin_b = torch.nn.Linear(64, 4096).to(dev), torch.nn.Linear(64, 4096).to(dev)
+    lin_b.load_state_dict(lin_a.state_dict())
+    oa, ob = HipAdam(lin_a.parameters(), lr=1e-2), HipAdam(lin_b.parameters(), lr=1e-2)
+    assert len(ob.fuse_linear_wgrad(lin_b, min_numel=1024)) == 1
+    xs = [torch.rand(8, 64, device=dev), torch.rand(5, 64, device=dev)]
+    for lin, opt in ((lin_a, oa), (lin_b, ob)):
+        for x in xs:
+            ops.linear(x, lin.weight, lin.bias).square().sum().backward()
+        opt.step()
+    assert lin_b.weight.grad is None and lin_a.weight.grad is not None
+    for p, q in zip(lin_a.parameters(), lin_b.parameters()):
+        assert float((p - q).abs().max() / p.abs().max()) <= 1e-6
+    ob.close()

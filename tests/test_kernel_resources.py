@@ -27,3 +27,21 @@ def test_no_kernel_spills_registers():
                  "dconv_fwd_kernelILi8ELi8ELi2"):
         hit = [k for n, k in by.items() if frag in n]
         assert hit and all(k[".private_segment_fixed_size"] == 0 for k in hit), frag
+
+
+def test_rankb_optimizer_kernels_fit_beside_the_c2_weight_gradient():
+    """dd_adam_step_rankb runs on the optimizer's side stream beside conv_wino2_wgrad<4> (440 registers, 133 KB of LDS per workgroup, one
+    wave per SIMD on every CU): what is left of a SIMD's 512 registers is 72, of a CU's 160 KB of LDS 27 KB.  A variant that needs more
+    does not become resident until the conv kernel has drained (measured: +1.6 ms on a 7.6 ms step with a 76-register build)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    ks = [k for k in kernel_resources.kernels() if "adam_rankb" in k[".name"]]
+    assert len(ks) == 4, [k[".name"] for k in ks]
+    wgrad = [k for k in kernel_resources.kernels() if "conv_wino2_wgradILi4" in k[".name"]]
+    assert wgrad and all(k[".vgpr_count"] <= 440 for k in wgrad)
+    for k in ks:
+        assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 72, (k[".name"], k[".vgpr_count"], k.get(".agpr_count"))
+        assert k[".group_segment_fixed_size"] <= 24 * 1024, (k[".name"], k[".group_segment_fixed_size"])
