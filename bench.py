@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--fuse-linear-wgrad", choices=("on", "off"), default="on",
                     help="rank-B optimizer pass: the weight gradients of the big Linear layers are formed inside their Adam pass, never written "
                          "(off: dd_linear_wgrad + dd_adam_step, the round-4 arrangement; A/B)")
+    ap.add_argument("--alt-all-reduce", choices=("on", "off"), default="on",
+                    help="N > 1 with a sharded / factor-gather default: time the plain all-reduce step first and carry it in the line (on)")
     ap.add_argument("--simulate-shard", type=int, default=0, metavar="N",
                     help="one GPU, timing only: the COMPUTE side of an N-GPU sharded step (Adam on rank 0's 1/N of every big tensor, no "
                     "collectives; the parameters it leaves are meaningless) -- the per-GPU lower bound of the N-GPU step")
@@ -766,6 +768,7 @@ class Watchdog:
         self.rank, self.limit = rank, float(limit)
         self.phase, self.last = "start", time.monotonic()
         self.done = False
+        self.fallback = None      # callable: what this rank still owes its caller when the watchdog fires (rank 0: the line already measured)
         if self.limit > 0:
             threading.Thread(target=self._run, name="dd-watchdog", daemon=True).start()
 
@@ -784,6 +787,8 @@ class Watchdog:
                 sys.stderr.write(f"bench.py watchdog: rank {self.rank} made no progress for {idle:.0f} s in phase '{self.phase}' "
                                  f"(limit {self.limit:.0f} s, DD_WATCHDOG_S); exiting with status 3\n")
                 try:
+                    if self.fallback is not None:
+                        self.fallback()
                     faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                     sys.stderr.flush()
                 finally:
@@ -844,12 +849,46 @@ def init_distributed(world, rank, dev, backend, dog):
     return info
 
 
-def fault_injection(rank, i):
-    """DD_BENCH_FAULT="<rank>:<step>[:hang]": that rank dies (or hangs) at that step -- the failure-path tests' lever."""
+def collective_probe(model, world, dev, backend, dog):
+    """Measured bus bandwidth of the job's communicator: one all-reduce (SUM, fp32) over a buffer of the model's gradient size (648 MB
+    for config 2; 16 MB over gloo, which is a rehearsal), 2 warm-up + 5 timed, max over ranks.  busbw = 2 (N - 1) / N x bytes / time,
+    the figure RCCL's own tests quote; the step's collectives run with the same channel cap (NCCL_MAX_NCHANNELS) as this one."""
+    import torch
+    import torch.distributed as dist
+    numel = sum(p.numel() for p in model.parameters())
+    if backend != "nccl":
+        numel = min(numel, 4 << 20)
+    buf = torch.zeros(numel, device=dev if backend == "nccl" else "cpu", dtype=torch.float32)
+    dog.beat("collective probe")
+    for _ in range(2):
+        dist.all_reduce(buf)
+    if backend == "nccl":
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dist.all_reduce(buf)
+    if backend == "nccl":
+        torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / 5], dtype=torch.float64, device=buf.device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ms = float(dt.item()) * 1e3
+    nbytes = numel * 4
+    del buf
+    return {"collective": "all_reduce fp32 sum", "message_bytes": nbytes, "ms": round(ms, 3),
+            "algbw_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "busbw_GBps": round(2.0 * (world - 1) / max(world, 1) * nbytes / (ms * 1e-3) / 1e9, 1)}
+
+
+def fault_injection(rank, i, phase=""):
+    """DD_BENCH_FAULT="<rank>:<step>[:hang[:default]]": that rank dies (or hangs) at that step -- the failure-path tests' lever.  With
+    the fourth field only in the DEFAULT mode's steps (not in the all-reduce steps timed before them at N > 1)."""
     spec = os.environ.get("DD_BENCH_FAULT")
     if not spec:
         return
     parts = spec.split(":")
+    if len(parts) > 3 and parts[3] == "default" and phase:
+        return
     if int(parts[0]) == rank and int(parts[1]) == i:
         if len(parts) > 2 and parts[2] == "hang":
             sys.stderr.write(f"bench.py: injected hang on rank {rank} at step {i}\n")
@@ -895,7 +934,10 @@ def run_rank(a):
     # the first import of torch on a fresh box pages the image in (1-2 min): the watchdog's clock starts after it
     import torch
     import torch.distributed as dist
-    dog = Watchdog(rank, float(os.environ.get("DD_WATCHDOG_S", "150")) if world > 1 or os.environ.get("DD_WATCHDOG_S") else 0)
+    # rank 0's clock runs out first (x 0.8): when a job stalls, every rank's watchdog sees the same silence, and the launcher tears the
+    # others down the moment the first one exits -- rank 0 has to have printed its fallback line (the all-reduce figure) by then
+    dog = Watchdog(rank, float(os.environ.get("DD_WATCHDOG_S", "150")) * (0.8 if (rank == 0 and world > 1) else 1.0)
+                   if world > 1 or os.environ.get("DD_WATCHDOG_S") else 0)
     if os.environ.get("DD_BENCH_CONTROL_ONLY") == "1":
         return control_flow_rehearsal(a, world, rank, dog)
     if world > 1:
@@ -943,49 +985,100 @@ def run_rank(a):
     factor = comm and {"on": True, "off": False, "auto": world == 2 and a.config in (2, 4, 5) and a.shard_optimizer != "on"}[a.factor_linear]
     if factor:
         shard = False
-    ts = TrainStep(model, lr=1e-3, adam_overlap=overlap, shard_optimizer=shard, reserve_cus=reserve, force_collectives=rehearse,
-                   simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False, factor_linear=factor,
-                   fuse_linear_wgrad=a.fuse_linear_wgrad == "on")
+
+    def make_step(shard_, factor_):
+        return TrainStep(model, lr=1e-3, adam_overlap=overlap, shard_optimizer=shard_, reserve_cus=reserve, force_collectives=rehearse,
+                         simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False, factor_linear=factor_,
+                         fuse_linear_wgrad=a.fuse_linear_wgrad == "on")
+
+    def timed_region(ts, timer, tag):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over ranks of the wall time."""
+        def step(i):
+            dog.beat(f"{tag}step {i}")
+            fault_injection(rank, i, tag)
+            return ts(batch, i)["loss"]
+        for i in range(a.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if comm:
+            dog.beat(f"{tag}barrier before the timed region")
+            dist.barrier()
+        torch.cuda.synchronize()
+        if timer is not None:
+            timer.enabled = True
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            loss = step(a.warmup + i)
+        torch.cuda.synchronize()
+        if comm:
+            dog.beat(f"{tag}barrier after the timed region")
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if timer is not None:
+            timer.enabled = False
+        ts.sync_params()
+        seen = 1
+        if comm:
+            dog.beat(f"{tag}timing reductions")
+            cdev = dev if backend == "nccl" else "cpu"
+            t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            ones = torch.ones(1, device=cdev, dtype=torch.float64)
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # every rank that took part in the timed region counts itself
+            seen = int(round(float(ones.item())))
+        return dt, loss, seen
+
+    # N > 1, first of all: the bus bandwidth of this communicator, and the PLAIN ALL-REDUCE step (replicated optimizer: the arrangement
+    # every earlier round measured on one GPU) -- before the default mode, whose sharded optimizer / factor gather have met a multi-rank
+    # RCCL communicator only in rehearsals.  Its figure goes to stderr at once and into the line (config.alt_all_reduce_ms); should the
+    # default mode then stall, the watchdog prints a complete line for the all-reduce step before it exits, so the run is never empty.
+    probe, alt = None, None
+    if comm and not a.simulate_shard:
+        probe = collective_probe(model, world, dev, backend, dog)
+        if rank == 0:
+            sys.stderr.write("bench.py collective probe: " + json.dumps(probe) + "\n")
+            sys.stderr.flush()
+    if comm and (shard or factor) and not a.simulate_shard and a.alt_all_reduce == "on":
+        keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        rng = torch.cuda.get_rng_state(dev)
+        ts0 = make_step(False, False)
+        dt0, loss0, seen0 = timed_region(ts0, None, "all-reduce mode: ")
+        ts0.close()
+        del ts0
+        alt = {"ms_per_step": round(dt0 / a.steps * 1e3, 3), "value": round(world * per_gpu * a.steps / dt0, 2), "n_ranks_seen": seen0,
+               "final_loss": round(float(loss0.detach()), 6), "optimizer": "replicated (plain all-reduce of every gradient)"}
+        if rank == 0:
+            sys.stderr.write("bench.py alt_all_reduce: " + json.dumps(alt) + "\n")
+            sys.stderr.flush()
+
+            def fallback():      # the watchdog's last words on rank 0: a complete line for the mode that did run
+                print(json.dumps({"metric": cfg["metric"], "value": alt["value"], "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+                                  "warmup": a.warmup, "ms_per_step": alt["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                                  "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic", "n_ranks_seen": seen0,
+                                  "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
+                                             "parallelism": f"dp{world}", "final_loss": alt["final_loss"], "optimizer": alt["optimizer"],
+                                             "default_mode_failed": f"watchdog in phase '{dog.phase}'"},
+                                  "roofline": None, "collective_probe": probe}), flush=True)
+            dog.fallback = fallback
+        # back to the state the default mode would have started from: parameters, BatchNorm statistics, the dropout generator (the
+        # extractor stays unfrozen -- training_step switched it on in the all-reduce phase; the default mode hooks it from the start)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(keep[k])
+        del keep
+        torch.cuda.set_rng_state(rng, dev)
+        torch.cuda.empty_cache()
+
+    ts = make_step(shard, factor)
     if a.config == 2:
         timer = KernelTimer()
     else:
         timer = AbiTimer(cfg["watch"])
     timer.install()
-
-    def step(i):
-        dog.beat(f"step {i}")
-        fault_injection(rank, i)
-        return ts(batch, i)["loss"]
-
-    for i in range(a.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if comm:
-        dog.beat("barrier before the timed region")
-        dist.barrier()
-    torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = step(a.warmup + i)
-    torch.cuda.synchronize()
-    if comm:
-        dog.beat("barrier after the timed region")
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    ts.sync_params()
-    n_ranks_seen = 1
-    if comm:
-        dog.beat("timing reductions")
-        cdev = dev if backend == "nccl" else "cpu"
-        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        ones = torch.ones(1, device=cdev, dtype=torch.float64)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # every rank that took part in the timed region counts itself
-        n_ranks_seen = int(round(float(ones.item())))
+    dt, loss, n_ranks_seen = timed_region(ts, timer, "")
+    dog.fallback = None
     loss_val = float(loss.detach())
     dog.stop()                                            # what follows (rank 0's diagnostics, the CPU baseline) takes minutes by design
 
@@ -1020,6 +1113,13 @@ def run_rank(a):
                       / ((PEAK_BF16_MFMA_TF if cfg["dtype"] == "bf16" else PEAK_F32_MFMA_TF) * world), 4),
             "roofline": roof,
         }
+        if alt is not None:
+            line["config"]["alt_all_reduce_ms"] = alt["ms_per_step"]
+            line["config"]["alt_all_reduce"] = alt
+        elif comm:
+            line["config"]["alt_all_reduce_ms"] = round(ms, 3) if not (shard or factor) else None
+        if probe is not None:
+            line["collective_probe"] = probe
         if preflight is not None:
             line["preflight"] = preflight
         _phase("headline")

@@ -55,7 +55,8 @@ stream behind the gathers).  Bytes received per rank: (world - 1) x 202 MB inste
 1414 against 1134 at 8, where the reduce-scatter wins.  Same products as the all-reduce path, summed in a
 different order (one GEMM over the global batch instead of a sum of per-rank GEMMs); every rank computes from identical gathered
 factors with a deterministic kernel, so the replicas stay bit-identical to EACH OTHER.  The bias gradients and everything else travel
-as before.
+as before.  Every rank must bring the SAME number of rows (``all_gather_into_tensor``: use ``drop_last`` on the loader -- the all-reduce
+path has no such condition), and a registered layer runs ONE backward per optimizer step (a second one raises).
 
 ``simulate_world=N`` (one process, no communicator) cuts the shards of rank 0 of an N-rank job out of the local gradient and skips
 the gather: the COMPUTE side of an N-GPU sharded step on one GPU -- a timing aid (`bench.py --simulate-shard N`), the parameters
@@ -141,6 +142,7 @@ class GradSync:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=self.group)
+        self.early_input_gathers = 0      # factor mode: input gathers started from the forward and picked up by the backward (tests)
         self._handles = []
         self._by_param = {}
         self._shards = {}          # p -> [Shard]: kept until the next backward replaces them (the optimizer reads them after finish())
@@ -149,6 +151,10 @@ class GradSync:
         self._small = []
         self._hooks = []
         self._hooked = set()
+        if self.shard and self.active:
+            # shard mode leaves all-gathers writing into the parameters when a step returns: whoever reads the parameters as a whole --
+            # state_dict(), a checkpoint (LightningModule.save goes through state_dict), an EMA copy made from it -- first waits for them
+            self._hooks.append(module.register_state_dict_pre_hook(lambda _m, _prefix, _keep: self.wait_gathers()))
         self.refresh()
         lightning.on_unfreeze(self)
 
@@ -183,7 +189,8 @@ class GradSync:
         if self.reserve_cus and not self._reserved:
             self._set_budget(256 - self.reserve_cus)
             self._reserved = True
-        work = self._all_gather(bufs[0], x)
+        with torch.no_grad():      # called from the forward, in grad mode; the waits happen in the backward / optimizer (no grad): gloo splits
+            work = self._all_gather(bufs[0], x.detach())      # the output into views, which must be made and written in ONE grad mode
         self._handles.append(work)
         self._xwork[p] = (work, x.data_ptr(), x.shape[0])
 
@@ -195,6 +202,11 @@ class GradSync:
         p = self._fkeys.get(weight.data_ptr())
         if p is None or not self.factor:
             return False
+        if p in self._factors:
+            # the gather buffers of p are persistent and its earlier factors may still be on the links: a second backward through the
+            # layer before the optimizer has taken them (gradient accumulation, a shared weight, retain_graph) would overwrite them
+            raise RuntimeError("GradSync(factor_linear=True): a registered Linear layer ran a second backward before the optimizer step; "
+                               "step between the backwards, or use the all-reduce / sharded modes, which accumulate into .grad")
         m, w = x.shape[0], self.world
         x, dy = x.contiguous(), dy.contiguous()
         bufs = self._factor_bufs(p, m, x.shape[1], dy.shape[1], x)
@@ -203,6 +215,7 @@ class GradSync:
             self._reserved = True
         early = self._xwork.pop(p, None)
         if early is not None and early[1] == x.data_ptr() and early[2] == m:      # this x is already on the links (linear_input)
+            self.early_input_gathers += 1
             works = [early[0], self._all_gather(bufs[1], dy)]
             self._handles.append(works[1])
         else:
@@ -325,8 +338,15 @@ class GradSync:
 
     def wait_param_gather(self, p):
         PARAM_WAITS.pop(p.data_ptr(), None)
-        for work in self._gathers.pop(p, ()):
+        works = self._gathers.pop(p, ())
+        for work in works:
             work.wait()
+        if works and p.is_cuda:
+            # the wait above orders the CURRENT stream behind the gathers.  The first toucher may be a side stream (the weight-pack
+            # stream, the optimizer's); the entry is gone after this call, so the main stream has to be ordered here as well
+            cur, main = torch.cuda.current_stream(p.device), torch.cuda.default_stream(p.device)
+            if cur != main:
+                main.wait_event(cur.record_event())
         if self._reserved and not self._gathers and not self._handles:
             self._set_budget(256)                        # the last all-gather has been waited for: the whole GPU for the kernels behind it
             self._reserved = False

@@ -770,11 +770,6 @@ class Linear(torch.autograd.Function):
         check(_lib.lib().dd_linear_fwd(_p(x), _p(weight), _p(bias), _p(y), m, n, k, _p(ws), nbytes, _stream()), "dd_linear_fwd")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        # (grad mode is always off inside Function.forward: whether this call will be differentiated is ctx.needs_input_grad)
-        if _ddp.FACTOR_SYNC and ctx.needs_input_grad[1]:
-            sync = _ddp.FACTOR_SYNC.get(weight.data_ptr())
-            if sync is not None:      # factor mode: a big input (fc1's 120 MB of pooled activations) starts its gather now, not in the backward
-                sync.linear_input(weight, x)
         return y
 
     @staticmethod
@@ -808,7 +803,14 @@ class Linear(torch.autograd.Function):
 
 
 def linear(x, weight, bias):
-    return Linear.apply(x.contiguous(), weight, bias)
+    x = x.contiguous()
+    # factor mode of ddp.GradSync: a big input (fc1's 120 MB of pooled activations) starts its all-gather now, not in the backward.
+    # Decided HERE: inside Function.forward grad mode is always off and ctx.needs_input_grad ignores torch.no_grad()
+    if _ddp.FACTOR_SYNC and torch.is_grad_enabled() and weight.requires_grad:
+        sync = _ddp.FACTOR_SYNC.get(weight.data_ptr())
+        if sync is not None:
+            sync.linear_input(weight, x)
+    return Linear.apply(x, weight, bias)
 
 
 def column_sum(dy):

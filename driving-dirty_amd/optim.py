@@ -211,23 +211,85 @@ class HipAdam(torch.optim.Optimizer):
 
     def _update_shards(self, p, group, grad_scale, shards):
         """The update of the slices of ``p`` this rank owns: wait (on the current stream) for piece k's reduce-scatter, update the
-        slice, start its all-gather behind the update, go on."""
+        slice, start its all-gather behind the update, go on.  Whole moments found in the state (a checkpoint in torch.optim.Adam's
+        layout -- the reference's -- or steps taken in all-reduce mode before) are cut into this rank's slices on the way."""
         st = self.state[p]
         if not st:
             st["step"] = 0
             st["shards"] = {}
+        whole = None
         if "shards" not in st:
-            raise RuntimeError("HipAdam: a tensor that was updated whole is now sharded (GradSync(shard_optimizer=True) must be "
-                               "attached before the first step)")
+            whole = (st.pop("exp_avg").reshape(-1), st.pop("exp_avg_sq").reshape(-1))
+            st["shards"] = {}
         st["step"] += 1
         for sh in shards:
             if sh.work is not None:
                 sh.work.wait()
             mv = st["shards"].get(sh.index)
             if mv is None or mv[0].numel() != sh.param.numel():
-                mv = st["shards"][sh.index] = (torch.zeros_like(sh.param), torch.zeros_like(sh.param))
+                if whole is not None:
+                    mv = (whole[0][sh.lo:sh.hi].clone(), whole[1][sh.lo:sh.hi].clone())
+                else:
+                    mv = (torch.zeros_like(sh.param), torch.zeros_like(sh.param))
+                st["shards"][sh.index] = mv
             self._launch(sh.param, sh.grad, mv[0], mv[1], group, st["step"], grad_scale)
             self._sync.gather_shard(p, sh)
+
+    # ---- checkpoints of the optimizer ------------------------------------------------------------------------------------------
+    def _whole_moments(self, p, st):
+        """(exp_avg, exp_avg_sq) of ``p`` as whole tensors: the sharded moments all-gathered piece by piece (a COLLECTIVE when the
+        GradSync is live: every rank calls it, for the same tensors in the same order)."""
+        sync = self._sync
+        if sync is None or not getattr(sync, "shard", False):
+            raise RuntimeError("HipAdam: sharded moments but no sharded GradSync attached to put them together")
+        import torch.distributed as dist
+        m = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        v = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        mf, vf = m.view(-1), v.view(-1)
+        w, r = sync.shard_world, sync.rank
+        for k, (a, b) in enumerate(sync._pieces_of(p.numel())):
+            n = (b - a) // w
+            mv = st["shards"].get(k)
+            if mv is None:
+                mv = (torch.zeros(n, device=p.device, dtype=p.dtype), torch.zeros(n, device=p.device, dtype=p.dtype))
+            if sync.active:
+                dist.all_gather_into_tensor(mf[a:b], mv[0], group=sync.group)
+                dist.all_gather_into_tensor(vf[a:b], mv[1], group=sync.group)
+            else:                                 # simulate_world: one process holds rank 0's slices only
+                mf[a + r * n:a + (r + 1) * n].copy_(mv[0])
+                vf[a + r * n:a + (r + 1) * n].copy_(mv[1])
+        return m, v
+
+    def consolidated_state_dict(self):
+        """``state_dict()`` in torch.optim.Adam's layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter: what the reference's
+        ``configure_optimizers()`` optimizer writes, autoencoder.py:119-120 / roadmap_bce_v2.py:154-157) whatever mode the steps were
+        taken in.  In shard mode each rank holds 1 / world of the moments of a sharded tensor: they are all-gathered here, so EVERY rank
+        must call this (the result is the same on all of them; save rank 0's).  Loads into ``torch.optim.Adam`` and into a ``HipAdam``
+        of any mode (``_update_shards`` cuts whole moments into slices again)."""
+        if self._sync is not None and hasattr(self._sync, "wait_gathers"):
+            self._sync.wait_gathers()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        sd = super().state_dict()
+        flat = [p for group in self.param_groups for p in group["params"]]
+        for idx, p in enumerate(flat):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            st = dict(st)
+            if "shards" in st:
+                m, v = self._whole_moments(p, st)
+                del st["shards"]
+                st["exp_avg"], st["exp_avg_sq"] = m, v
+            sd["state"][idx] = st
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Takes torch.optim.Adam's state (whole moments; ``step`` possibly a tensor) as well as this class's own."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if "step" in st and isinstance(st["step"], torch.Tensor):
+                st["step"] = int(st["step"].item())
 
     def _update_pieces(self, p, group, grad_scale, pieces):
         """The update of a tensor whose all-reduce travels in pieces: wait (on the current stream) for piece k, update that
@@ -248,8 +310,12 @@ class HipAdam(torch.optim.Optimizer):
     def _update(self, p, group, grad_scale):
         st = self._state_of(p)
         if "shards" in st:
-            raise RuntimeError("HipAdam: a sharded tensor arrived without shards (GradSync.finish() of this step not reached, or the "
-                               "GradSync was removed while its optimizer lives on)")
+            if self._sync is None or not getattr(self._sync, "shard", False):
+                raise RuntimeError("HipAdam: a tensor with sharded moments is updated whole and no sharded GradSync is attached to put "
+                                   "them together (GradSync removed while its optimizer lives on?): save with consolidated_state_dict() "
+                                   "before leaving shard mode")
+            st["exp_avg"], st["exp_avg_sq"] = self._whole_moments(p, st)      # a collective: every rank is here for the same tensor
+            del st["shards"]
         st["step"] += 1
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
         self._launch(p.data.view(-1), g.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), group, st["step"], grad_scale)

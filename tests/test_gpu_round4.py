@@ -101,7 +101,7 @@ def test_sharded_hipadam_is_bit_identical_to_the_all_reduce_path(tmp_path, dev, 
                 assert torch.equal(plain[k], ref[k]), f"rank {rank}: parameter {k} differs from rank 0's"
 
 
-def _factor_worker(rank, world, port, out, factor, overlap):
+def _factor_worker(rank, world, port, out, factor, overlap, fuse=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -109,7 +109,9 @@ def _factor_worker(rank, world, port, out, factor, overlap):
     from driving_dirty_amd.train import TrainStep
     dev = torch.device("cuda:0")
     model = _tiny_model(dev, frozen_epochs=1)
-    ts = TrainStep(model, lr=1e-2, adam_overlap=overlap, factor_linear=factor, big_numel=4096, chunk_numel=1 << 20, scheduler=False)
+    # fuse: rank-B mode of the optimizer -- the gathered factors go straight into dd_adam_step_rankb, no gradient tensor is formed
+    ts = TrainStep(model, lr=1e-2, adam_overlap=overlap, factor_linear=factor, big_numel=4096, chunk_numel=1 << 20, scheduler=False,
+                   fuse_linear_wgrad=fuse)
     assert ts.sync.factor == factor and bool(ddp.FACTOR_SYNC) == factor
     big = {"fc1.weight": model.fc1.weight, "ae.encoder.fc1.fc1.weight": model.ae.encoder.fc1.fc1.weight}
     grads, losses = {}, []
@@ -128,6 +130,28 @@ def _factor_worker(rank, world, port, out, factor, overlap):
     assert not ddp.FACTOR_SYNC
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, True), (2, False)])
+def test_factor_gather_with_the_rankb_pass_keeps_the_replicas_identical(tmp_path, dev, world, overlap):
+    """Factor gather + rank-B optimizer pass (TrainStep's defaults at N = 2): the gathered factors feed dd_adam_step_rankb directly, no
+    gradient tensor exists for the two big Linear layers (``.grad`` stays None, bias included).  Replicas bit-identical to each other;
+    losses of three steps equal to the all-reduce path's to 1e-4."""
+    out = str(tmp_path / "f.pt")
+    mp.spawn(_factor_worker, args=(world, free_port(), out, False, overlap, False), nprocs=world, join=True)
+    mp.spawn(_factor_worker, args=(world, free_port(), out, True, overlap, True), nprocs=world, join=True)
+    plain = [torch.load(f"{out}.0.{r}") for r in range(world)]
+    fact = [torch.load(f"{out}.1.{r}") for r in range(world)]
+    assert len(plain[0]["grads"]) == 5 and not fact[0]["grads"]      # no .grad on the fused layers, ever
+    buffers = {k for k in fact[0]["state"] if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    for r in range(1, world):
+        for k, v in fact[0]["state"].items():
+            if k not in buffers:
+                assert torch.equal(fact[r]["state"][k], v), f"rank {r}: parameter {k} differs from rank 0's"
+    moved = float((fact[0]["state"]["fc1.weight"] - _tiny_model(dev, 1).state_dict()["fc1.weight"].cpu()).abs().max())
+    assert moved > 0
+    for a, b in zip(fact[0]["losses"], plain[0]["losses"]):
+        assert abs(a - b) <= 1e-4 * abs(b)
 
 
 @pytest.mark.parametrize("world,overlap", [(2, True), (3, False)])
@@ -274,6 +298,31 @@ def test_bench_under_torch_distributed_run_as_the_driver_launches_it(dev):
     assert line["config"]["optimizer"].startswith("replicated; the big Linear layers all-gather")
     assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
     assert "preflight" in line and "cpu_baseline" not in line          # the CPU baseline is timed at N = 1 only
+    # the un-losable part: the plain all-reduce step timed FIRST and carried in the line, its figure on stderr before the
+    # default mode starts, the communicator's measured bus bandwidth beside it; the default mode starts from the same parameters
+    alt = line["config"]["alt_all_reduce"]
+    assert line["config"]["alt_all_reduce_ms"] == alt["ms_per_step"] > 0 and alt["n_ranks_seen"] == 2 and alt["value"] > 0
+    assert alt["optimizer"].startswith("replicated (plain all-reduce")
+    assert "bench.py alt_all_reduce: " in r.stderr and "bench.py collective probe: " in r.stderr
+    probe = line["collective_probe"]
+    assert probe["message_bytes"] > 0 and probe["ms"] > 0 and probe["busbw_GBps"] > 0
+    assert abs(alt["final_loss"] - line["config"]["final_loss"]) <= 1e-3 * abs(alt["final_loss"])      # same start, same batches, same steps
+    assert line["config"]["linear_wgrad"].startswith("formed inside the Adam pass")      # factor gather + rank-B: gathered factors -> the pass
+
+
+def test_bench_watchdog_prints_the_all_reduce_line_when_the_default_mode_stalls(dev):
+    """A rank that hangs in the DEFAULT mode's timed region (fault injection at a step index only that phase reaches is not possible --
+    both phases count from 0 -- so the hang is injected by step AND phase): the watchdog fires, and rank 0's last words are a complete
+    JSON line for the all-reduce step that did run, marked `default_mode_failed`."""
+    env = dict(os.environ, DD_DIST_BACKEND="gloo", DD_RESERVED_CUS="0", PYTHONPATH=ROOT, DD_WATCHDOG_S="12", DD_BENCH_FAULT="1:3:hang:default")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-others", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout[-500:], r.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["config"]["default_mode_failed"].startswith("watchdog") and line["value"] > 0 and line["n_gpus"] == 2
+    assert line["config"]["optimizer"].startswith("replicated (plain all-reduce") and line["collective_probe"]["ms"] > 0
 
 
 def test_simulated_shard_step_runs(dev):

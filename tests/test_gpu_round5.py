@@ -151,3 +151,43 @@ def test_rankb_two_backwards_before_the_step_add_up(dev):
     for p, q in zip(lin_a.parameters(), lin_b.parameters()):
         assert float((p - q).abs().max() / p.abs().max()) <= 1e-6
     ob.close()
+
+
+def test_factor_mode_starts_the_input_gather_in_the_forward(dev):
+    """ddp.GradSync factor mode: ``ops.Linear.forward`` starts the all-gather of a big layer input right away -- decided in
+    ``ops.linear()``, outside the autograd Function (inside ``Function.forward`` grad mode is always off, so the earlier
+    ``torch.is_grad_enabled()`` test there never fired) -- and the backward picks that gather up instead of starting its own.  One-rank gloo communicator, force_collectives."""
+    import torch.distributed as dist
+    from _ports import free_port
+    from driving_dirty_amd import ddp, ops
+    from driving_dirty_amd.optim import HipAdam
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(4096, 16).to(dev)
+        ref = torch.nn.Linear(4096, 16).to(dev)
+        ref.load_state_dict(lin.state_dict())
+        sync = ddp.GradSync(lin, big_numel=4096, force_collectives=True, factor_linear=True)
+        opt = HipAdam(lin.parameters(), lr=1e-2)
+        opt.attach(sync)
+        assert sync.factor and lin.weight.data_ptr() in ddp.FACTOR_SYNC
+        x = torch.rand(2, 4096, device=dev)                  # 8192 elements >= big_numel: gathered from the forward
+        with torch.no_grad():
+            ops.linear(x, lin.weight, lin.bias)              # torch.no_grad(): validation starts no gather
+        assert not sync._xwork and sync.early_input_gathers == 0
+        ops.linear(x, lin.weight, lin.bias).square().sum().backward()
+        assert sync.early_input_gathers == 1 and not sync._xwork
+        sync.finish()
+        opt.step(grad_scale=sync.grad_scale)
+        ropt = HipAdam(ref.parameters(), lr=1e-2)
+        ops.linear(x, ref.weight, ref.bias).square().sum().backward()
+        ropt.step()
+        for p, q in zip(lin.parameters(), ref.parameters()):
+            assert float((p - q).abs().max() / q.abs().max()) <= 1e-6
+        with pytest.raises(RuntimeError, match="second backward"):      # ADVICE r4 (low): persistent gather buffers are not overwritten silently
+            ops.linear(x, lin.weight, lin.bias).square().sum().backward()
+            ops.linear(x, lin.weight, lin.bias).square().sum().backward()
+        sync.remove()
+    finally:
+        dist.destroy_process_group()

@@ -143,3 +143,124 @@ def test_simulated_shard_world_updates_only_rank0s_slices():
         want[a:a + (b - a) // 8] = True
     assert torch.equal(changed, want)
     assert not ddp.PARAM_WAITS
+
+
+def _ckpt_worker(rank, world, port, out):
+    """Two steps sharded -> consolidated_state_dict() -> (a) a fresh SHARDED optimizer loads it and takes two more steps, (b) a fresh
+    ALL-REDUCE optimizer loads it and takes the same two steps, (c) the uninterrupted sharded run takes them: all three must agree bit for
+    bit, and the consolidated moments must equal the all-reduce run's whole moments."""
+    torch.set_num_threads(1)
+    from driving_dirty_amd import ddp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Adam = _torch_adam_cls()
+
+    def make(shard):
+        net = _FineTune()
+        for p in net.ae.parameters():
+            p.requires_grad_(True)
+        net.ae.train()
+        sync = ddp.GradSync(net, big_numel=4096, chunk_numel=4992, shard_optimizer=shard)
+        opt = Adam(net.parameters(), lr=1e-2)
+        opt.attach(sync)
+        return net, sync, opt
+
+    def steps(net, sync, opt, which):
+        for step in which:
+            net.zero_grad(set_to_none=True)
+            _loss(net, step, rank).backward()
+            sync.finish()
+            opt.step(grad_scale=sync.grad_scale)
+        sync.wait_gathers()
+
+    ref_net, ref_sync, ref_opt = make(False)                 # all-reduce throughout
+    steps(ref_net, ref_sync, ref_opt, range(4))
+    net, sync, opt = make(True)                              # sharded throughout
+    steps(net, sync, opt, range(2))
+    import copy
+    sd = copy.deepcopy(opt.consolidated_state_dict())        # collective: every rank.  (Like torch's state_dict() it REFERENCES the live
+                                                             # moments of the tensors that were never sharded: copied before the run goes on)
+    weights = {k: v.clone() for k, v in net.state_dict().items()}      # through the state_dict pre-hook (waits for the gathers)
+    half_net, half_sync, half_opt = make(False)
+    steps(half_net, half_sync, half_opt, range(2))
+    want = half_opt.state_dict()
+    for idx, st in want["state"].items():
+        got = sd["state"][idx]
+        assert "shards" not in got and got["step"] == st["step"] == 2
+        assert torch.equal(got["exp_avg"], st["exp_avg"]) and torch.equal(got["exp_avg_sq"], st["exp_avg_sq"]), idx
+    steps(net, sync, opt, range(2, 4))
+    resumed = {}
+    for name, shard in (("sharded", True), ("all_reduce", False)):
+        n2, s2, o2 = make(shard)
+        n2.load_state_dict(weights)
+        o2.load_state_dict(copy.deepcopy(sd))                # (load_state_dict keeps the tensors it is given: each run gets its own)
+        steps(n2, s2, o2, range(2, 4))
+        resumed[name] = n2.state_dict()
+        if shard:
+            st = o2.state[n2.head.weight]
+            assert "exp_avg" not in st and st["step"] == 4 and len(st["shards"]) == 14
+    # torch.optim.Adam takes the consolidated state as it is (the reference's optimizer, roadmap_bce_v2.py:154-157)
+    n3, _, _ = make(False)
+    torch.optim.Adam(n3.parameters(), lr=1e-2).load_state_dict(copy.deepcopy(sd))
+    final = net.state_dict()
+    for k, v in ref_net.state_dict().items():
+        assert torch.equal(final[k], v), f"uninterrupted sharded run: {k}"
+        for name, got in resumed.items():
+            assert torch.equal(got[k], v), f"resumed {name} run: {k} (max diff {float((got[k] - v).abs().max())})"
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_consolidated_optimizer_state_resumes_in_either_mode(tmp_path):
+    out = str(tmp_path / "ok.pt")
+    mp.spawn(_ckpt_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    assert torch.load(out)["ok"]
+
+
+def _leave_shard_mode_worker(rank, world, port, out):
+    """Steps in shard mode, then the same optimizer goes on under an all-reduce GradSync... that needs the consolidation collective while
+    the sharded GradSync is still attached: HipAdam._update does it on the first whole update."""
+    torch.set_num_threads(1)
+    from driving_dirty_amd import ddp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = torch.nn.Linear(64, 128)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        net.weight.copy_(torch.randn(128, 64) * 0.1)
+    sync = ddp.GradSync(net, big_numel=4096, chunk_numel=4096, shard_optimizer=True)
+    opt = _torch_adam_cls()(net.parameters(), lr=1e-2)
+    opt.attach(sync)
+    g = torch.Generator().manual_seed(70 + rank)
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        net(torch.randn(4, 64, generator=g)).square().mean().backward()
+        sync.finish()
+        opt.step(grad_scale=sync.grad_scale)
+    assert ddp.PARAM_WAITS                                   # the last step's all-gathers are still writing into the weight ...
+    net.state_dict()                                         # ... and reading the parameters as a whole waits for them (state_dict pre-hook)
+    assert not ddp.PARAM_WAITS and not sync._gathers
+    assert "shards" in opt.state[net.weight]
+    m_whole, v_whole = opt._whole_moments(net.weight, opt.state[net.weight])
+    net.zero_grad(set_to_none=True)
+    net(torch.randn(4, 64, generator=g)).square().mean().backward()
+    dist.all_reduce(net.weight.grad)                         # a whole gradient, outside the hooks' reach: the whole-tensor update
+    sync._shards.pop(net.weight, None)
+    before = {k: v.clone() for k, v in (("m", m_whole), ("v", v_whole))}
+    opt._update(net.weight, opt.param_groups[0], 0.5)
+    st = opt.state[net.weight]
+    assert "shards" not in st and st["step"] == 3
+    gsum = net.weight.grad * 0.5
+    assert torch.allclose(st["exp_avg"], before["m"] * 0.9 + gsum * (1.0 - 0.9), rtol=0, atol=1e-7)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_whole_update_after_shard_mode_consolidates_the_moments(tmp_path):
+    out = str(tmp_path / "ok.pt")
+    mp.spawn(_leave_shard_mode_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    assert torch.load(out)["ok"]
