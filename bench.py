@@ -313,21 +313,23 @@ def host_cores():
     return int(os.environ.get("DD_CPU_THREADS", min(n, 16)))
 
 
-def cpu_baseline(sample_batch=4, steps=5):
-    """The CPU oracle (oracle/: pure-torch restatement of the reference path) timed on this host's cores: the headline
-    config-2 step and the config-1 autoencoder step, each on a bounded sample (bs = 4, 1 warm-up + ``steps`` timed steps)."""
+def cpu_baseline(sample_batch=BATCH, steps=1, ae_batch=4, ae_steps=3):
+    """The CPU oracle (oracle/: pure-torch restatement of the reference path) timed on this host's cores: the headline config-2 step AT
+    THE METRIC'S BATCH (bs = 32: the same step the GPU line measures; 1 warm-up + 1 timed step -- 49 s per step on the 8
+    cores of the build container, 13.5 GB resident) and the config-1 autoencoder step at ITS batch (bs = 4: BASELINE.json configs[0]),
+    1 warm-up + 3 timed."""
     import numpy as np
     import torch
     from oracle import ae_parts, steps as osteps
     cores = host_cores()
     torch.set_num_threads(cores)
 
-    def timed(step):
+    def timed(step, n):
         step()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n):
             step()
-        return (time.perf_counter() - t0) / steps
+        return (time.perf_counter() - t0) / n
 
     torch.manual_seed(SEED)
     enc = ae_parts.EncoderNet(HIDDEN, LATENT, 3, H, 6 * W)
@@ -342,14 +344,15 @@ def cpu_baseline(sample_batch=4, steps=5):
         opt.zero_grad(set_to_none=True)
         osteps.roadmap_bce_loss(enc, head, batch)[0].backward()
         opt.step()
-    dt = timed(roadmap_step)
+    dt = timed(roadmap_step, steps)
     out = {"value": round(sample_batch / dt, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
            "port_of": "oracle/ (plain-torch CPU restatement of the reference path; the reference itself never travels to the GPU box): "
                       "held to the reference's own outputs by tests/golden/*.npz, which tests/golden/make_golden.py generates by "
                       "importing /root/reference (tests/test_oracle_golden.py: fp32 2e-6, fp64 1e-12)",
            "sample": f"oracle roadmap step (config 2) fwd+bwd+Adam, bs={sample_batch}, {steps} timed steps after 1 warm-up, "
                      f"{dt:.2f} s/step, torch {torch.__version__} CPU"}
-    del opt, head
+    del opt, head, batch, road
+    views = views[:ae_batch].clone()
     # config 1 (BASELINE.json configs[0]: the reference's own CPU-runnable case): masked-view autoencoder step, bs = 4
     dec = ae_parts.DecoderNet(HIDDEN, LATENT, 3, H, W)
     opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=1e-3)
@@ -359,10 +362,10 @@ def cpu_baseline(sample_batch=4, steps=5):
         opt.zero_grad(set_to_none=True)
         osteps.ae_loss(enc, dec, views, rng)[0].backward()
         opt.step()
-    dt1 = timed(ae_step)
-    out["config1_ae"] = {"value": round(sample_batch / dt1, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
-                         "sample": f"oracle BasicAE step (config 1: src/autoencoder/autoencoder.py, bs={sample_batch}) fwd+bwd+Adam, "
-                                   f"{steps} timed steps after 1 warm-up, {dt1:.2f} s/step"}
+    dt1 = timed(ae_step, ae_steps)
+    out["config1_ae"] = {"value": round(ae_batch / dt1, 3), "unit": "scenes/s", "cores": cores, "kind": "port",
+                         "sample": f"oracle BasicAE step (config 1: src/autoencoder/autoencoder.py, bs={ae_batch}) fwd+bwd+Adam, "
+                                   f"{ae_steps} timed steps after 1 warm-up, {dt1:.2f} s/step"}
     return out
 
 
@@ -436,9 +439,8 @@ def other_configs(a, dev, steps=10, warmup=3):
         res[names[c]].update(algorithmic_TFLOPs=round(algo / (ms * 1e-3) / 1e12, 1),
                              **{("frac_bf16_mfma_peak" if c == 5 else "frac_fp32_mfma_peak"): round(algo / (ms * 1e-3) / 1e12 / peak, 4)})
         if c in (3, 4):
-            # EXPERIMENT (csrc/dconv_split.hip; never the headline): the same step with up_conv_1 / up_conv_2 taking every fp32
+            # precision mode "fp32x3" (csrc/dconv_split.hip; never the headline): the same step with up_conv_1 / up_conv_2 taking every fp32
             # product as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulate) on the bf16 matrix pipe
-            from driving_dirty_amd import gconv
             watch = {"up_conv_1_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 96 and _desc(x[6]).pad_h > 0),
                      "up_conv_2_fwd_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 64 and _desc(x[6]).cout == 32 and _desc(x[6]).pad_h > 0),
                      "up_conv_1_dgrad_split": ("dd_dconv_fwd_split", lambda *x: _desc(x[6]).cin == 64 and _desc(x[6]).cout == 96 and _desc(x[6]).pad_h == 0),
@@ -447,13 +449,13 @@ def other_configs(a, dev, steps=10, warmup=3):
                      "up_conv_1_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 96),
                      "up_conv_2_wgrad_split": ("dd_dconv_wgrad_split", lambda *x: x[6] == 64),
                      "split_input_pass": ("dd_dconv_split_input", lambda *x: True), "split_rows_pass": ("dd_dconv_split_rows", lambda *x: True)}
-            gconv.SPLIT_BF16 = True
+            cfg["model"].box_merge.precision = "fp32x3"      # the documented mode switch (hparams.precision = "fp32x3" sets the same attribute)
             try:
                 run("config3_bbox_split_products_bs32" if c == 3 else "config4_joint_split_products_bs32_per_gpu", cfg["model"], cfg["batch"], cfg["per_gpu_batch"],
                     {"dtype": "f32 (bf16x6 split products, fp32 accumulate) in the forward, data gradient and weight gradient of up_conv_1 and "
                               "up_conv_2; everything else exact fp32"}, watch, "3s")
             finally:
-                gconv.SPLIT_BF16 = False
+                cfg["model"].box_merge.precision = "fp32"
         del cfg
         torch.cuda.empty_cache()
     # config 2 at the reference's DEFAULT width (autoencoder.py:33-34,164-166: hidden 256 / latent 128; SURVEY.md 8d "also report 256/128"):

@@ -103,10 +103,33 @@ DCONV = os.environ.get("DD_DCONV", "1") != "0"
 PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
 
 
-# EXPERIMENT (csrc/dconv_split.hip), off by default: the forward and the data gradient of up_conv_1 / up_conv_2 with every fp32 product taken as
-# six bf16 x bf16 products (exact 3-way operand split, fp32 accumulation) on the bf16 matrix pipe.  DD_DCONV_SPLIT=1 or
-# gconv.SPLIT_BF16 = True selects it; the default stays the exact-fp32 MFMA kernels.
+# Precision mode "fp32x3" (csrc/dconv_split.hip; off by default): the forward, data gradient and weight gradient of up_conv_1 / up_conv_2
+# with every fp32 product taken as six bf16 x bf16 products (exact 3-way operand split, fp32 accumulation) on the bf16 matrix pipe; error
+# bound: DESIGN.md 3.3d.  Selected per module -- ``hparams.precision = "fp32x3"`` on BBSpatialRoadMap / JointRoadMapBBox, or
+# ``box_merge.precision = "fp32x3"`` -- through ``split_products()`` below; ``gconv.SPLIT_BF16 = True`` is the process-wide default
+# (DD_DCONV_SPLIT=1 sets it at import: tools' A/B).  The default everywhere stays the exact-fp32 MFMA kernels.
 SPLIT_BF16 = os.environ.get("DD_DCONV_SPLIT", "0") == "1"
+
+
+class split_products:
+    """``with split_products(True):`` -- the layers run inside take the split-product kernels where those serve them (False: the exact
+    ones; None: whatever the process-wide default says).  heads.MergeFn records the mode of its forward and re-enters it in its
+    backward, so a module's choice holds for the whole step however the backward is started."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        global SPLIT_BF16
+        self.prev = SPLIT_BF16
+        if self.on is not None:
+            SPLIT_BF16 = bool(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        global SPLIT_BF16
+        SPLIT_BF16 = self.prev
+        return False
 # ... its kernels write the bf16 planes of their OUTPUT from the epilogue for the next layer (DD_SPLIT_EMIT=0: a split pass per operand again; A/B)
 SPLIT_EMIT = os.environ.get("DD_SPLIT_EMIT", "1") != "0"
 

@@ -16,6 +16,7 @@ import torch
 from . import _lib, ops
 from ._lib import check
 from .gconv import EPI_BIAS, EPI_BIAS_RELU, Layer, View, _p, _stream, add, copy_channels, view_to_nhwc4
+from . import gconv as gconv_mod
 from .gconv import split_rows as gconv_split_rows
 
 
@@ -249,6 +250,7 @@ class MergeFn(torch.autograd.Function):
             planes = (emit or {}).get("ys")
             acts.append(dst)
         ctx.split_x = split_x
+        ctx.split_mode = gconv_mod.SPLIT_BF16                # the backward runs in the precision mode of its forward (gconv.split_products)
         u = acts[-1]
         probs = _empty((b, 2 * u.shape[1], 2 * u.shape[2]), dev)
         check(_lib.lib().dd_deconv2x2_c1_fwd(_p(u), _p(p_last[0]), _p(p_last[1]), _p(probs), b, u.shape[1], u.shape[2], 8,
@@ -263,6 +265,11 @@ class MergeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gprobs):
+        with gconv_mod.split_products(ctx.split_mode):
+            return MergeFn._backward(ctx, gprobs)
+
+    @staticmethod
+    def _backward(ctx, gprobs):
         cls = MergeFn
         with_rm, nup = ctx.with_rm, ctx.nup
         ups = cls.UPS_RM if with_rm else cls.UPS_PLAIN

@@ -26,6 +26,11 @@ class JointRoadMapBBox(LightningModule):
         self.fc1 = nn.Linear(self.ae.latent_dim, 800 * 800)          # roadmap head, roadmap_bce_v2.py:50
         self.space_map_cnn = SpatialMappingCNN()                      # spatial_w_rm.py:50-52
         self.box_merge = RoadMapBoxesMergingCNN()
+        precision = hparam(hparams, "precision", None)                # "fp32" (default) | "fp32x3": the box head's up-convs by split products
+        if precision is not None:
+            if precision not in ("fp32", "fp32x3"):
+                raise ValueError(f"precision must be 'fp32' or 'fp32x3', got {precision!r}")
+            self.box_merge.precision = precision
 
     def forward(self, x, rm):
         """x [B,6,3,256,306], rm [B,1,800,800] -> (roadmap logits [B,800,800], box probabilities [B,800,800]).  Both may also be

@@ -9,7 +9,7 @@ from argparse import ArgumentParser
 import torch
 from torch import nn
 
-from . import ops
+from . import gconv, ops
 from .autoencoder import BasicAE
 from .heads import MergeFn, SpatialMapFn, _ORDER, as_nhwc, road_map_taps
 from .lightning import LightningModule, hparam, pretrained_ae
@@ -47,6 +47,10 @@ class SpatialMappingCNN(nn.Module):
 
 class _Merging(nn.Module):
     with_rm = False
+    # "fp32": the reference's arithmetic on the exact-fp32 matrix kernels.  "fp32x3": the dilated up-convs take every fp32 product as six
+    # bf16 x bf16 products of three-way split operands (csrc/dconv_split.hip; same 2e-5-of-peak bound against fp64 as the exact kernels in
+    # the tests, error model in DESIGN.md 3.3d; 59 -> 43 ms per config-3 step).  None: the process-wide default (gconv.SPLIT_BF16).
+    precision = None
 
     def _params(self, names):
         out = []
@@ -59,7 +63,10 @@ class _Merging(nn.Module):
         _gpu(ssr, type(self).__name__)
         names = ["ss_conv", "ss_deconv"] + (["rm_conv_1", "rm_conv_2"] if self.with_rm else []) + self.up_names
         rm4 = road_map_taps(rm) if self.with_rm else None
-        probs = MergeFn.apply(as_nhwc(ssr, 32), as_nhwc(spatial_map, 32), rm4, self.with_rm, *self._params(names))
+        if self.precision not in (None, "fp32", "fp32x3"):
+            raise ValueError(f"{type(self).__name__}.precision must be 'fp32' or 'fp32x3', got {self.precision!r}")
+        with gconv.split_products(None if self.precision is None else self.precision == "fp32x3"):
+            probs = MergeFn.apply(as_nhwc(ssr, 32), as_nhwc(spatial_map, 32), rm4, self.with_rm, *self._params(names))
         return probs.unsqueeze(1)                        # [B,1,800,800] like the reference
 
 
@@ -136,12 +143,16 @@ class BBSpatialRoadMap(LightningModule):
         self.ae.encoder.c3_only = True
         self.ae.decoder = None
         # hparams.precision = "bf16": the (frozen or fine-tuned) encoder conv stack on the bf16 matrix cores, its feature handed to
-        # the fp32 heads (no reference counterpart: oracle/bf16_parts.py states the contract)
-        self.ae.encoder.precision = str(hparam(hparams, "precision", self.ae.encoder.precision))
-        if self.ae.encoder.precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.ae.encoder.precision!r}")
+        # the fp32 heads (no reference counterpart: oracle/bf16_parts.py states the contract).  "fp32x3": everything fp32, the box
+        # head's dilated up-convs by split products on the bf16 pipe (_Merging.precision).  Default "fp32": the reference's arithmetic.
+        precision = str(hparam(hparams, "precision", self.ae.encoder.precision))
+        if precision not in ("fp32", "bf16", "fp32x3"):
+            raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp32x3', got {precision!r}")
+        self.ae.encoder.precision = "bf16" if precision == "bf16" else "fp32"
         self.space_map_cnn = SpatialMappingCNN()
         self.box_merge = RoadMapBoxesMergingCNN()
+        if hparam(hparams, "precision", None) is not None:
+            self.box_merge.precision = "fp32x3" if precision == "fp32x3" else "fp32"
 
     def wide_stitch_six_images(self, x):
         return ops.stitch6(x.contiguous(), want_nhwc4=False, want_nchw=True)[1]
@@ -210,4 +221,7 @@ class BBSpatialRoadMap(LightningModule):
         p.add_argument("--link", type=str, default="/scratch/ab8690/DLSP20Dataset/data")
         p.add_argument("--pretrained_path", type=str, default="")
         p.add_argument("--output_img_freq", type=int, default=500)
+        p.add_argument("--precision", type=str, default="fp32", choices=("fp32", "bf16", "fp32x3"),
+                       help="fp32: the reference's arithmetic; bf16: encoder conv stack on the bf16 matrix cores; fp32x3: the box head's "
+                            "dilated up-convs as six bf16 products per fp32 product (MI355X build only)")
         return p

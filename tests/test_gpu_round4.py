@@ -659,7 +659,7 @@ def test_split_bf16_pieces_reassemble_the_operand(dev):
     as not -- what keeps the dropped cross products zero-mean)."""
     import ctypes as C
     from driving_dirty_amd import _lib, gconv
-    b, h, w, c = 1, 3, 40, 32
+    b, h, w, c = 1, 6, 40, 32                                 # 7680 values: enough pairs for the statistics of the dropped terms below
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(b, h, w, c, generator=g) * torch.logspace(-6, 3, c)).to(dev)
     x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.0])
@@ -684,21 +684,118 @@ def test_split_bf16_pieces_reassemble_the_operand(dev):
     mid = planes[..., 1, :].permute(0, 1, 3, 2, 4).reshape(b, h, w, c)
     opposite = float(((mid * x) < 0).float().mean())
     assert 0.35 < opposite < 0.65, opposite
+    # ---- the error model of the six-product form, asserted on these very pieces ---------------------------------
+    # pieces: |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x| (each the round-to-nearest bf16 of an exact remainder)
+    lo = planes[..., 2, :].permute(0, 1, 3, 2, 4).reshape(b, h, w, c)
+    xa = x.double().abs()
+    assert bool((mid.double().abs() <= xa * 2.0 ** -8).all()) and bool((lo.double().abs() <= xa * 2.0 ** -16).all())
+    # a second operand: the same values in another order -- products a_k b_k over 3840 pairs of magnitudes 1e-6 .. 1e3
+    a3 = torch.stack([hi.double().flatten(), mid.double().flatten(), lo.double().flatten()])            # [3, n]
+    perm = torch.randperm(a3.shape[1], generator=torch.Generator().manual_seed(5)).to(dev)
+    b3 = a3[:, perm]
+    full = a3.sum(0) * b3.sum(0)
+    H, M, L = 0, 1, 2
+    kept = (a3[H] * b3[H] + a3[H] * b3[M] + a3[M] * b3[H] + a3[H] * b3[L] + a3[L] * b3[H] + a3[M] * b3[M])
+    dropped = a3[M] * b3[L] + a3[L] * b3[M] + a3[L] * b3[L]
+    assert float((full - kept - dropped).abs().max()) <= 1e-30 + 2.0 ** -50 * float(full.abs().max())      # nine terms, six issued, three dropped
+    live = full.abs() > 0
+    rel = (dropped[live] / full[live].abs())
+    # WORST CASE per product: |a_m b_l| + |a_l b_m| + |a_l b_l| <= (2 x 2^-24 + 2^-32) |a b| = 2^-23 (1 + 2^-9) |a b|: fp32's own product rounding
+    assert float(rel.abs().max()) <= 2.0 ** -23 * (1.0 + 2.0 ** -9)
+    # EXPECTED: zero-mean (rounded pieces carry no sign bias), rms <= 2^-24 |a b| (uniform remainders: sqrt(2)/3 x 2^-24 = 2.8e-8)
+    n = rel.numel()
+    rms = float(rel.pow(2).mean().sqrt())
+    assert rms <= 2.0 ** -24 and abs(float(rel.mean())) <= 5.0 * rms / n ** 0.5, (rms, float(rel.mean()))
+    # a K-term dot product: the dropped terms add like a random walk -- |sum dropped| against the bound 2^-23 sum |a b| and the expectation
+    K = 4704                                                                                          # up_conv_1's forward: 96 channels x 49 taps
+    prod, drop = full[:K * (n // K)].view(-1, K), dropped[:K * (n // K)].view(-1, K)
+    walk = drop.sum(1).abs() / prod.pow(2).sum(1).sqrt()
+    assert bool((drop.sum(1).abs() <= 2.0 ** -23 * (1.0 + 2.0 ** -9) * prod.abs().sum(1)).all()) and float(walk.max()) <= 4.0 * 2.0 ** -24
 
 
-def test_box_head_model_tests_pass_on_the_split_product_path(dev):
+def test_box_head_model_tests_pass_on_the_split_product_path(dev, golden):
     """The model-level tests of the box heads -- the three-way checks against the fp64 oracle (same-branch 2e-4, flip census, reference
-    fixtures), the B = 32 step against the mean of 32 single-scene steps, adjointness of every layer at bs 32 -- re-run
-    in a child process with DD_DCONV_SPLIT=1: the forwards, data gradients and (96 -> 64) weight gradient of up_conv_1 / up_conv_2 on the
-    split-product kernels.  Same tests, same tolerances, no allowance for the experiment."""
-    env = dict(os.environ, DD_DCONV_SPLIT="1")
-    sel = ("test_spatial_heads_three_way or test_bbox_training_step_three_way or test_merging_heads_signed_inputs_three_way or "
-           "test_bbox_step_b32_equals_mean_of_single_scene_steps or test_box_head_layers_full_size_linearity_and_adjointness")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
-    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert " passed" in tail and "failed" not in tail, tail
+    fixtures), the B = 32 step against the mean of 32 single-scene steps, adjointness of every layer at bs 32 -- re-run with the
+    precision mode "fp32x3" as the process-wide default (``gconv.split_products(True)``: what ``hparams.precision = "fp32x3"`` sets
+    per module): the forwards, data gradients and weight gradients of up_conv_1 / up_conv_2 on the split-product kernels.  Same test
+    functions, same tolerances, no allowance for the mode.  (In this process: round 4 ran them in a child pytest, 8 s of imports.)"""
+    import test_gpu_heads
+    import test_gpu_round2
+    import test_gpu_round3
+    from driving_dirty_amd import _lib, gconv
+    calls = []
+    real = _lib.lib().dd_dconv_fwd_split
+
+    def counted(*a):
+        calls.append(1)
+        return real(*a)
+    with gconv.split_products(True):
+        _lib.lib().dd_dconv_fwd_split = counted
+        try:
+            test_gpu_heads.test_spatial_heads_three_way(dev, golden)
+            for mse in (False, True):
+                test_gpu_heads.test_bbox_training_step_three_way(dev, mse)
+            for variant in ("rboxm", "boxm"):
+                test_gpu_round2.test_merging_heads_signed_inputs_three_way(dev, golden, variant)
+            test_gpu_round3.test_bbox_step_b32_equals_mean_of_single_scene_steps(dev)
+            for name in test_gpu_round3._BOX_LAYERS:
+                test_gpu_round3.test_box_head_layers_full_size_linearity_and_adjointness(dev, name)
+        finally:
+            _lib.lib().dd_dconv_fwd_split = real
+    assert len(calls) >= 20, "the split-product kernels were never reached"
+    assert gconv.SPLIT_BF16 is False
+
+
+def test_precision_mode_fp32x3_on_the_module_surface(dev):
+    """``hparams.precision = "fp32x3"`` on BBSpatialRoadMap / JointRoadMapBBox: the step runs on the split-product kernels (forward AND
+    backward, although the backward is started outside the module's ``with``), a module built without it stays on the exact kernels in
+    the same process, and the two losses agree to the mode's bound."""
+    from driving_dirty_amd import _lib, synth
+    from driving_dirty_amd.autoencoder import BasicAE
+    from driving_dirty_amd.joint import JointRoadMapBBox
+    from driving_dirty_amd.spatial import BBSpatialRoadMap
+    lib = _lib.lib()
+    seen = {"fwd_split": 0, "wgrad_split": 0}
+    real_f, real_w = lib.dd_dconv_fwd_split, lib.dd_dconv_wgrad_split
+
+    def count(key, fn):
+        def wrapped(*a):
+            seen[key] += 1
+            return fn(*a)
+        return wrapped
+    lib.dd_dconv_fwd_split, lib.dd_dconv_wgrad_split = count("fwd_split", real_f), count("wgrad_split", real_w)
+    try:
+        b = 2
+        views = synth.camera_batch(b, seed=41).to(dev)
+        road = synth.road_maps(b, seed=41).to(dev)
+        tgt = tuple({"bb_map": (synth.hash_uniform((800, 800), 300 + i, 0.0, 1.0) < 0.02).float().to(dev)} for i in range(b))
+        losses = {}
+        for precision in ("fp32", "fp32x3"):
+            ae = BasicAE(Namespace(hidden_dim=128, latent_dim=64))
+            m = BBSpatialRoadMap(Namespace(pretrained_ae=ae, unfreeze_epoch_no=10 ** 9, learning_rate=1e-3, output_img_freq=500, precision=precision))
+            synth.fill_module(m, seed=41)
+            m = m.to(dev)
+            assert m.box_merge.precision == precision and m.ae.encoder.precision == "fp32"
+            before = dict(seen)
+            out = m.training_step((tuple(views), tgt, tuple(road)), 0)
+            mid = dict(seen)
+            out["loss"].backward()
+            if precision == "fp32":
+                assert seen == before
+            else:
+                assert mid["fwd_split"] - before["fwd_split"] == 2                   # up_conv_1, up_conv_2 forward
+                assert seen["fwd_split"] - mid["fwd_split"] >= 2 and seen["wgrad_split"] - mid["wgrad_split"] == 2      # data + weight gradients
+            losses[precision] = float(out["loss"].detach())
+            del m, ae
+        assert abs(losses["fp32"] - losses["fp32x3"]) <= 2e-5 * abs(losses["fp32"])
+        with pytest.raises(ValueError):
+            BBSpatialRoadMap(Namespace(pretrained_ae=BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132)),
+                                       unfreeze_epoch_no=0, learning_rate=1e-3, precision="fp16"))
+        j = JointRoadMapBBox(Namespace(pretrained_ae=BasicAE(Namespace(hidden_dim=16, latent_dim=8, input_height=16, input_width=132)),
+                                       learning_rate=1e-3, output_img_freq=500, precision="fp32x3"))
+        assert j.box_merge.precision == "fp32x3"
+    finally:
+        lib.dd_dconv_fwd_split, lib.dd_dconv_wgrad_split = real_f, real_w
 
 
 def test_split_kernels_emit_the_planes_of_their_output(dev):
