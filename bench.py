@@ -57,10 +57,13 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the config-1 / config-3 / config-5 step timings after the headline")
     ap.add_argument("--adam-overlap", choices=("auto", "on", "off"), default="auto",
-                    help="Adam pass of the big tensors on a side stream beside the backward (on = auto) or after it (off).  With one Adam "
-                    "block per CU and the 33-instruction kernel (DESIGN.md 3.1c) the overlap pays on every configuration: same box, on / off: "
-                    "config 2 7.51-7.62 / 7.86-7.93 ms, config 5 (bf16) 9.21-9.27 / 9.53-9.59")
+                    help="optimizer passes of the big tensors on a side stream beside the backward (on) or after it (off).  auto = TrainStep's "
+                    "choice: beside the backward for the fp32 models (config 2, same box, on / off: 7.51-7.62 / 7.86-7.93 ms), after it with four "
+                    "workgroups per CU for a bf16 encoder (config 5: same step either way, each kernel at its own roof; "
+                    "profiles/r05_config5_adam_overlap_ab.txt)")
     ap.add_argument("--no-adam-overlap", action="store_true", help="= --adam-overlap off")
+    ap.add_argument("--adam-blocks-per-cu", type=int, default=0, help="persistent workgroups per CU of the optimizer kernels (0 = TrainStep's "
+                    "choice: 1 beside the backward, 4 after it); A/B")
     ap.add_argument("--cu-budget", type=int, default=0, help="compute units the conv grids may fill (0 = 256, or 240 when N > 1)")
     ap.add_argument("--hidden", type=int, default=HIDDEN, help="encoder hidden width (reference default 128; its other setting: 256)")
     ap.add_argument("--latent", type=int, default=LATENT, help="latent width (64; with --hidden 256: 128)")
@@ -977,7 +980,7 @@ def run_rank(a):
     dog.beat("model")
     cfg = setup_config(a, dev, rank)
     model, batch, per_gpu = cfg["model"], cfg["batch"], cfg["per_gpu_batch"]
-    overlap = {"on": True, "off": False, "auto": True}[a.adam_overlap] and not a.no_adam_overlap
+    overlap = {"on": True, "off": False, "auto": "auto"}[a.adam_overlap] if not a.no_adam_overlap else False      # auto: TrainStep decides by precision
     # sharded optimizer wherever the gradient message is big (tools/ddp_budget.py)
     shard = (comm or a.simulate_shard > 1) and {"on": True, "off": False, "auto": a.config in (2, 4, 5) or a.simulate_shard > 1}[a.shard_optimizer]
     # The optimizer and the gradient synchronisation are built over the model AS CONSTRUCTED -- feature extractor still frozen
@@ -1074,6 +1077,8 @@ def run_rank(a):
         torch.cuda.empty_cache()
 
     ts = make_step(shard, factor)
+    if a.adam_blocks_per_cu:
+        _lib.check(_lib.lib().dd_set_adam_blocks_per_cu(a.adam_blocks_per_cu), "dd_set_adam_blocks_per_cu")
     if a.config == 2:
         timer = KernelTimer()
     else:
@@ -1102,7 +1107,7 @@ def run_rank(a):
                              "tensor, no collectives; a per-GPU lower bound, not a training step (parameters meaningless)"} if a.simulate_shard > 1 else {}),
             "config": {"workload": cfg["workload"], "baseline_config": a.config, "global_batch": world * per_gpu,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
-                       "adam_overlap": bool(overlap),
+                       "adam_overlap": bool(ts.overlap),
                        "linear_wgrad": ("formed inside the Adam pass (rank-B): " + ", ".join(sorted(n for n, p in model.named_parameters()
                                                                                                       if any(p is w for w in ts.fused))))
                        if ts.fused and not (shard or (comm and not factor)) else "materialised (dd_linear_wgrad + dd_adam_step)",

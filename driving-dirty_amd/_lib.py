@@ -44,6 +44,7 @@ SIGNATURES = {
     "dd_last_error": (C.c_char_p, []),
     "dd_clock_probe": (_i32, [_p, _i32, _i32, _p]),
     "dd_set_cu_budget": (_i32, [_i32]),
+    "dd_set_adam_blocks_per_cu": (_i32, [_i32]),
     "dd_get_cu_budget": (_i32, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_stitch6_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
@@ -134,6 +135,10 @@ SIGNATURES = {
     "dd_deconv2x2_c1_workspace_bytes": (_i64, [_i32]),
     "dd_deconv2x2_c1_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_deconv2x2_c1_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "dd_strip6_supported": (_i32, [_i32, _i32]),
+    "dd_strip6_fwd": (_i32, [_p, _i32, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "dd_strip6_wgrad_workspace_bytes": (_i64, []),
+    "dd_strip6_wgrad": (_i32, [_p, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "dd_view_to_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_view_to_nhwc4_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_view_to_nhwc4_u8_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -16,7 +16,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdd_hotpath.so")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["runtime.hip", "conv3x3.hip", "layout_pool.hip", "dense.hip", "linear.hip", "gconv.hip", "dconv.hip", "dconv_t.hip", "dconv_m.hip", "dconv_split.hip", "conv1ch.hip", "ssconv.hip", "bn2d.hip", "raster.hip",
-           "conv3x3_bf16.hip", "mlp_tail.hip", "adam_rankb.hip"]
+           "conv3x3_bf16.hip", "mlp_tail.hip", "adam_rankb.hip", "strip6.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions.  adam_rankb.hip: MFMA accumulators in ordinary vector registers (the kernel's whole budget is 72 registers, and the
 # default form keeps a second copy of the accumulators in the accumulation registers)

@@ -307,7 +307,7 @@ int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const floa
   DD_REQUIRE(total < ((long)1 << 31), DD_ERR_UNSUPPORTED, "adam_rankb: too many tiles");
   a.total = (int)total;
   // one persistent workgroup per CU, as dd_adam_step (dense.hip): nothing of this launch is ever queued ahead of a conv kernel
-  static const int per_cu = getenv("DD_ADAM_BLOCKS_PER_CU") ? max(1, atoi(getenv("DD_ADAM_BLOCKS_PER_CU"))) : 1;
+  const int per_cu = dd_adam_blocks_internal();
   const int grid = (int)min(total, (long)DD_NUM_CU * per_cu);
   a.per = (int)((total + grid - 1) / grid);
   hipStream_t st = (hipStream_t)stream;

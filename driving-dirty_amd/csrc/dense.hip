@@ -586,7 +586,7 @@ int dd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   // current one ends, and a kernel of >= 456 registers then waits until they have all drained (tools/ubench/residency.hip; in the
   // step: the c2 data gradient 2.2 ms from dispatch to end instead of 1.6).  Alone the pass is also fastest this way (0.536 ms for
   // fc1's 481 MB = 6.3 TB/s; 4 blocks per CU: 0.586, 8: 0.595).
-  static const int per_cu = getenv("DD_ADAM_BLOCKS_PER_CU") ? max(1, atoi(getenv("DD_ADAM_BLOCKS_PER_CU"))) : 1;
+  const int per_cu = dd_adam_blocks_internal();
   const int grid = (int)min((n / 4 + 255) / 256 + 1, (long)DD_NUM_CU * per_cu);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
                      eps, (float)bc1, (float)sqrt(bc2), grad_scale);

@@ -16,7 +16,9 @@ int dd_fail(int code, const char* fmt, ...) {
 }
 
 static int g_cu_budget = DD_NUM_CU;
+static int g_adam_blocks = 1;      // persistent workgroups per CU of the optimizer kernels (dd_set_adam_blocks_per_cu)
 
+int dd_adam_blocks_internal() { return g_adam_blocks; }
 int dd_cu_budget_internal() { return g_cu_budget; }
 
 // One wave that samples the shader-clock counter (s_memtime: counts at the clock the CUs actually run at) against the constant
@@ -47,5 +49,11 @@ int dd_set_cu_budget(int32_t compute_units) {
   return 0;
 }
 int dd_get_cu_budget(void) { return g_cu_budget; }
+
+int dd_set_adam_blocks_per_cu(int32_t blocks) {
+  DD_REQUIRE(blocks >= 1 && blocks <= 8, DD_ERR_BAD_ARG, "set_adam_blocks_per_cu: %d not in 1..8", blocks);
+  g_adam_blocks = blocks;
+  return 0;
+}
 const char* dd_last_error(void) { return g_err; }
 }

@@ -457,6 +457,72 @@ def view_to_nhwc4(views, view, transform):
     return out
 
 
+def _sample_table(views, who):
+    """-> (ctypes table of per-sample device pointers, B, H, W, device, u8 flag, keepalive) for every form the data pipeline hands over:
+    fp32 [B,6,3,H,W], the collate's tuple of fp32 [6,3,H,W], uint8 [B,6,H,W,3] frames or a tuple of uint8 [6,H,W,3]."""
+    from . import ops
+    if ops.is_u8_frames(views):
+        table, b, h, w, dev, keep = ops.u8_table(views, who)
+        return table, b, h, w, dev, 1, keep
+    items = [views[i] for i in range(views.shape[0])] if isinstance(views, torch.Tensor) else list(views)
+    if not items:
+        raise _lib.HotpathError(f"{who}: empty batch")
+    _, _, h, w = items[0].shape
+    keep = []
+    for t in items:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (6, 3, h, w)):
+            raise _lib.HotpathError(f"{who}: expected fp32 [6,3,{h},{w}] samples on the GPU, got {tuple(getattr(t, 'shape', ()))}")
+        keep.append(t if t.is_contiguous() else t.contiguous())
+    table = (C.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+    return table, len(keep), h, w, keep[0].device, 0, keep
+
+
+STRIP6 = os.environ.get("DD_STRIP6", "1") != "0"      # A/B knob: 0 = the six strip convs of SpatialMappingCNN on the generic engine (round 4)
+
+
+def strip6_supported(h, w):
+    return STRIP6 and bool(_lib.lib().dd_strip6_supported(int(h), int(w)))
+
+
+def _ptr6(tensors, who, shapes=None):
+    for i, t in enumerate(tensors):
+        _chk(t, f"{who}[{i}]")
+        if shapes is not None and tuple(t.shape) != tuple(shapes[i]):
+            raise _lib.HotpathError(f"{who}[{i}]: shape {tuple(t.shape)} != {tuple(shapes[i])}")
+    return (C.c_void_p * 6)(*[t.data_ptr() for t in tensors])
+
+
+_STRIP_SHAPES = [(32, 3, 1, 50), (32, 3, 1, 50), (32, 3, 52, 1), (32, 3, 52, 1), (32, 3, 1, 50), (32, 3, 1, 50)]      # bl, fl, b, f, br, fr
+
+
+def strip6_fwd(views, weights, biases):
+    """The six strip convs of SpatialMappingCNN (+ bias + ReLU) in one launch, written into their tiles of the 3 x 2 mosaic
+    (dd_strip6_fwd; spatial_bb/components.py:34-73).  ``weights`` / ``biases``: bl, fl, b, f, br, fr.  -> mosaic [B, 3 th, 2 tw, 32]."""
+    table, b, h, w, dev, u8, _keep = _sample_table(views, "strip6_fwd")
+    th, tw = (h - 1) // 3 + 1, (w - 50) // 2 + 1
+    weights = [x.contiguous() for x in weights]
+    mosaic = torch.empty((b, 3 * th, 2 * tw, 32), device=dev, dtype=torch.float32)
+    check(_lib.lib().dd_strip6_fwd(table, u8, _ptr6(weights, "weight", _STRIP_SHAPES), _ptr6(biases, "bias", [(32,)] * 6), _p(mosaic), b, h, w,
+                                   _stream()), "dd_strip6_fwd")
+    return mosaic
+
+
+def strip6_wgrad(views, g):
+    """Weight and bias gradients of the six strip convs from dL/d(mosaic) (ReLU-masked) in one launch + a fixed-order reduce
+    (dd_strip6_wgrad).  -> ([dw] * 6, [db] * 6) in the order bl, fl, b, f, br, fr."""
+    table, b, h, w, dev, u8, _keep = _sample_table(views, "strip6_wgrad")
+    th, tw = (h - 1) // 3 + 1, (w - 50) // 2 + 1
+    _chk(g, "g")
+    if tuple(g.shape) != (b, 3 * th, 2 * tw, 32):
+        raise _lib.HotpathError(f"strip6_wgrad: g {tuple(g.shape)} != {(b, 3 * th, 2 * tw, 32)}")
+    dws = [torch.empty(s, device=dev, dtype=torch.float32) for s in _STRIP_SHAPES]
+    dbs = [torch.empty(32, device=dev, dtype=torch.float32) for _ in range(6)]
+    nbytes = _lib.lib().dd_strip6_wgrad_workspace_bytes()
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    check(_lib.lib().dd_strip6_wgrad(table, u8, _p(g), _ptr6(dws, "dw"), _ptr6(dbs, "db"), b, h, w, _p(ws), nbytes, _stream()), "dd_strip6_wgrad")
+    return dws, dbs
+
+
 def add(a, b):
     out = torch.empty_like(a)
     check(_lib.lib().dd_add(_p(_chk(a, "a")), _p(_chk(b, "b")), _p(out), a.numel(), _stream()), "dd_add")

@@ -125,10 +125,18 @@ class SpatialMapFn(torch.autograd.Function):
         p = {n: (params[2 * i], params[2 * i + 1]) for i, n in enumerate(_ORDER)}
         per_sample = isinstance(views, (tuple, list))      # the collate's tuple of [6,3,H,W] tensors: read through a pointer table
         b, dev = (len(views), views[0].device) if per_sample else (views.shape[0], views.device)
+        h_in, w_in = (views[0].shape[1:3] if views[0].dtype == torch.uint8 else views[0].shape[2:4]) if per_sample else \
+            (views.shape[2:4] if views.dtype == torch.uint8 else views.shape[3:5])
+        fused = gconv_mod.strip6_supported(h_in, w_in)
         th = tw = None
         mosaic = None
-        laid = []                                           # the six NHWC4 layouts, kept for the weight gradients (240 MB at bs 32 of 288 GB)
-        for name, vi, tf, tr, tc in _TILES:
+        laid = []                                           # generic path: the six NHWC4 layouts, kept for the weight gradients
+        if fused:
+            # all six strip convs in ONE launch reading the views where they lie: rot90 / flip / mosaic placement are index arithmetic
+            # in the kernel (csrc/strip6.hip), no re-laid copies at all
+            mosaic = gconv_mod.strip6_fwd(views, [p[n][0] for n, *_ in _TILES], [p[n][1] for n, *_ in _TILES])
+            th, tw = mosaic.shape[1] // 3, mosaic.shape[2] // 2
+        for name, vi, tf, tr, tc in (() if fused else _TILES):
             xv = view_to_nhwc4(views, vi, tf)
             laid.append(xv)
             oh, ow = cls._strip(name).out_hw(xv.shape[1], xv.shape[2])
@@ -149,7 +157,8 @@ class SpatialMapFn(torch.autograd.Function):
             ctx.samples = None
             ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
         ctx.tile = (th, tw)
-        ctx.laid = laid if KEEP_LAYOUTS else None           # inputs without gradients: plain references
+        ctx.fused = fused
+        ctx.laid = laid if (KEEP_LAYOUTS and not fused) else None           # inputs without gradients: plain references
         return out
 
     @staticmethod
@@ -165,7 +174,11 @@ class SpatialMapFn(torch.autograd.Function):
         grads["out_conv"] = cls.OUT.backward_weight(View(mosaic), View(g))
         gm = _empty(mosaic.shape, mosaic.device)
         cls.OUT.backward_data(w_out, View(g), View(gm), relu_src=mosaic)
-        for k, (name, vi, tf, tr, tc) in enumerate(_TILES):
+        if ctx.fused:                                       # six weight + bias gradients: one launch and a fixed-order reduce (csrc/strip6.hip)
+            dws, dbs = gconv_mod.strip6_wgrad(views, gm)
+            for k, (name, *_rest) in enumerate(_TILES):
+                grads[name] = (dws[k], dbs[k])
+        for k, (name, vi, tf, tr, tc) in enumerate(() if ctx.fused else _TILES):
             xv = ctx.laid[k] if ctx.laid is not None else view_to_nhwc4(views, vi, tf)      # kept from the forward (six launches of 15-55 us otherwise)
             grads[name] = cls._strip(name).backward_weight(View(xv), View(gm, 0, 32, tr * th, tc * tw, th, tw))
         flat = []

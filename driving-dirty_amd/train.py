@@ -30,7 +30,7 @@ from .optim import HipAdam
 
 
 class TrainStep:
-    def __init__(self, model, lr=None, adam_overlap=True, shard_optimizer=False, reserve_cus=None, process_group=None,
+    def __init__(self, model, lr=None, adam_overlap="auto", shard_optimizer=False, reserve_cus=None, process_group=None,
                  force_collectives=False, simulate_world=0, scheduler="auto", big_numel=1 << 20, chunk_numel=1 << 25, factor_linear=False,
                  fuse_linear_wgrad=True):
         self.model = model
@@ -51,7 +51,16 @@ class TrainStep:
                              force_collectives=force_collectives, shard_optimizer=shard_optimizer, simulate_world=simulate_world,
                              factor_linear=factor_linear)
         self.optimizer.attach(self.sync)
+        if adam_overlap == "auto":
+            # fp32 models: the passes of the big tensors ride beside the MFMA-bound c2 weight gradient.  A bf16 encoder has no MFMA-bound
+            # stretch -- its conv kernels are HBM-bound, and an 11.6 GB optimizer stream beside them only time-shares the same HBM
+            # (config 5: the c2 weight gradient at 0.19-0.28 of the HBM peak beside it, 0.62 alone; same step either way,
+            # profiles/r05_config5_adam_overlap_ab.txt): there the optimizer runs after the backward, four workgroups per CU
+            adam_overlap = not any(getattr(m, "precision", None) == "bf16" for m in model.modules())
         self.overlap = bool(adam_overlap)
+        if not self.overlap and next(model.parameters()).is_cuda:
+            from . import _lib
+            _lib.check(_lib.lib().dd_set_adam_blocks_per_cu(4), "dd_set_adam_blocks_per_cu")
         if self.overlap:
             self.optimizer.overlap_with_backward(big_numel=big_numel, grad_scale=self.sync.grad_scale,
                                                  grad_sync=self.sync if (self.sync.active or self.sync.shard) else None)

@@ -71,6 +71,11 @@ int dd_clock_probe(uint64_t* samples, int32_t nsamples, int32_t spin, void* stre
  * order for any grid). */
 int dd_set_cu_budget(int32_t compute_units);
 int dd_get_cu_budget(void);
+/* Persistent workgroups per CU of the optimizer kernels (dd_adam_step, dd_adam_step_rankb; 1..8, default 1).  ONE when the pass runs
+ * beside the fp32 conv backward -- a second workgroup per CU would be queued ahead of the next conv kernel, which then waits for the
+ * whole pass to drain; FOUR when it runs by itself (bf16 models: nothing MFMA-bound to hide under), where more workgroups in flight
+ * stream faster.  Process-wide, read at launch; never changes results (the update is elementwise). */
+int dd_set_adam_blocks_per_cu(int32_t blocks);
 
 /* ---- layout: 6-view gather (K4) --------------------------------------------------
  * views [B,6,3,H,W] fp32 -> wide NHWC4 image [B,H,6W,4] with the reference's view order
@@ -429,6 +434,25 @@ int dd_ssconv_fwd(const float* x, const float* w, const float* bias, float* y, i
                   void* stream);
 int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, float* out, int32_t batch, int32_t h, int32_t w,
                            void* stream);
+
+/* ---- the six strip convolutions of SpatialMappingCNN, one launch each way (spatial_bb/components.py:18-24 the layers -- four
+ * Conv2d(3, 32, (1, 50), stride (3, 2)) and two Conv2d(3, 32, (52, 1), stride (3, 2), padding 1) --, :34-65 their inputs: raw views,
+ * views rotated by +-90 degrees, views flipped in H and W, :70-73 the 3 x 2 mosaic they are concatenated into).  Every one of them is
+ * a 1-D convolution along a row of the RAW view, so rotation, flip and mosaic placement are index arithmetic inside the kernel: the
+ * views are read where they lie (`sample_ptrs`: HOST array of `batch` DEVICE pointers, one per sample: fp32 [6][3][H][W], or with
+ * u8 != 0 uint8 [6][H][W][3] decoded frames, ToTensor's /255 fused), nothing is re-laid.  Tile order of `weights` / `biases` /
+ * `dweights` / `dbiases` (HOST arrays of 6 DEVICE pointers): bl_conv, fl_conv, b_conv, f_conv, br_conv, fr_conv; weights in the
+ * modules' own layout [32][3][kh][kw].
+ *   fwd    mosaic [batch][3 th][2 tw][32] NHWC fp32 = ReLU(conv + bias) of every tile (th = (H - 1) / 3 + 1, tw = (W - 50) / 2 + 1)
+ *   wgrad  g = dL/d(mosaic) (already masked by the mosaic's ReLU) -> the six weight and bias gradients; per-wave partial sums in
+ *          `workspace` (dd_strip6_wgrad_workspace_bytes()), added in a fixed order: deterministic
+ * dd_strip6_supported: the six tiles must come out equal (H even, H % 3 != 0, W = H + 50; the reference's 256 x 306) and W <= 320. */
+int32_t dd_strip6_supported(int32_t height, int32_t width);
+int dd_strip6_fwd(const void* const* sample_ptrs, int32_t u8, const float* const* weights, const float* const* biases, float* mosaic,
+                  int32_t batch, int32_t height, int32_t width, void* stream);
+int64_t dd_strip6_wgrad_workspace_bytes(void);
+int dd_strip6_wgrad(const void* const* sample_ptrs, int32_t u8, const float* g, float* const* dweights, float* const* dbiases, int32_t batch,
+                    int32_t height, int32_t width, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* One camera view of views[B,6,3,H,W] -> NHWC4 [B,H',W',4] with the geometric transform SpatialMappingCNN applies
  * before its strip convs (spatial_bb/components.py:43-65): 0 = none, 1 = rot90(k=1, dims [2,3]) (view 4, "b"),

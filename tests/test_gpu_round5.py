@@ -191,3 +191,106 @@ def test_factor_mode_starts_the_input_gather_in_the_forward(dev):
         sync.remove()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ the six strip convs in one launch
+def _strip_reference(views64, ws, bs):
+    """The pre-ReLU mosaic [B,32,3 th,2 tw] in fp64 exactly as spatial_bb/components.py:34-73 builds it (torch ops on the CPU).
+    ws / bs: bl, fl, b, f, br, fr."""
+    import torch.nn.functional as F
+    v = [views64[:, i] for i in range(6)]
+    bl = F.conv2d(v[3], ws[0], bs[0], stride=(3, 2))
+    fl = F.conv2d(v[0], ws[1], bs[1], stride=(3, 2))
+    b = F.conv2d(torch.rot90(v[4], 1, [2, 3]), ws[2], bs[2], stride=(3, 2), padding=1)
+    f = F.conv2d(torch.rot90(v[1], 1, [3, 2]), ws[3], bs[3], stride=(3, 2), padding=1)
+    br = F.conv2d(torch.flip(v[5], [2, 3]), ws[4], bs[4], stride=(3, 2))
+    fr = F.conv2d(torch.flip(v[2], [2, 3]), ws[5], bs[5], stride=(3, 2))
+    rows = [torch.cat(p, dim=3) for p in ((bl, fl), (b, f), (br, fr))]
+    return torch.cat(rows, dim=2)
+
+
+@pytest.mark.parametrize("h,w,batch", [(256, 306, 3), (64, 114, 2), (256, 306, 66)])
+def test_strip6_forward_and_weight_gradient_against_fp64(dev, h, w, batch):
+    """dd_strip6_fwd / dd_strip6_wgrad (all six strip convs of SpatialMappingCNN in one launch each way, rot90 / flip / mosaic tiling as
+    index arithmetic) against the reference's own sequence of torch ops in fp64: forward 2e-6 of peak, weight and bias gradients 2e-5
+    (sums over up to 66 x 86 x 129 pixels).  64 x 114: other tile sizes (22 x 33); batch 66: two launches, the second accumulating."""
+    from driving_dirty_amd import gconv
+    assert gconv.strip6_supported(h, w)
+    g = torch.Generator().manual_seed(h + batch)
+    if batch > 8:      # one distinct sample repeated: the reference conv on the CPU stays cheap, the batch loop of the kernel is still exercised
+        one = torch.rand(2, 6, 3, h, w, generator=g)
+        views = one[torch.arange(batch) % 2].contiguous()
+    else:
+        views = torch.rand(batch, 6, 3, h, w, generator=g)
+    shapes = [(32, 3, 1, 50), (32, 3, 1, 50), (32, 3, 52, 1), (32, 3, 52, 1), (32, 3, 1, 50), (32, 3, 1, 50)]
+    ws = [(torch.rand(s, generator=g) - 0.5) * 0.2 for s in shapes]
+    bs = [(torch.rand(32, generator=g) - 0.5) * 0.2 for _ in shapes]
+    th, tw = (h - 1) // 3 + 1, (w - 50) // 2 + 1
+    got = gconv.strip6_fwd(views.to(dev), [x.to(dev) for x in ws], [x.to(dev) for x in bs])
+    assert tuple(got.shape) == (batch, 3 * th, 2 * tw, 32)
+    w64 = [x.double().requires_grad_(True) for x in ws]
+    b64 = [x.double().requires_grad_(True) for x in bs]
+    nref = batch if batch <= 8 else 2
+    pre = _strip_reference(views[:nref].double(), w64, b64)                 # [nref,32,3th,2tw]
+    ref = pre.relu().permute(0, 2, 3, 1)
+    ref = ref.detach()
+    peak = float(ref.abs().max())
+    for i in range(batch):
+        assert float((got[i].double().cpu() - ref[i % 2 if batch > 8 else i]).abs().max()) <= 2e-6 * peak, i
+    gm = (torch.rand(batch, 3 * th, 2 * tw, 32, generator=g) - 0.5)
+    if batch > 8:
+        gm = gm[torch.arange(batch) % 2].contiguous()
+    dws, dbs = gconv.strip6_wgrad(views.to(dev), gm.to(dev))
+    (pre * gm[:nref].double().permute(0, 3, 1, 2)).sum().backward()
+    mult = batch / nref if batch > 8 else 1.0                              # the repeated samples: the same gradient batch / 2 times
+    for k in range(6):
+        rw, rb = w64[k].grad * mult, b64[k].grad * mult
+        assert float((dws[k].double().cpu() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()), k
+        assert float((dbs[k].double().cpu() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()), k
+    again = gconv.strip6_wgrad(views.to(dev), gm.to(dev))                   # fixed-order partial sums: bit-reproducible
+    assert all(torch.equal(a, b) for a, b in zip(again[0] + again[1], dws + dbs))
+
+
+def test_strip6_reads_every_input_form_alike(dev):
+    """fp32 [B,6,3,H,W], the collate's tuple of [6,3,H,W], uint8 [B,6,H,W,3] frames and a tuple of [6,H,W,3]: the same mosaic and the same
+    gradients bit for bit (ToTensor's /255 is fused as a true division; the fp32 views here are what ToTensor makes of the frames)."""
+    from driving_dirty_amd import gconv
+    g = torch.Generator().manual_seed(9)
+    frames = torch.randint(0, 256, (3, 6, 256, 306, 3), dtype=torch.uint8, generator=g)
+    views = frames.permute(0, 1, 4, 2, 3).float().div(255).contiguous()     # on the CPU: a true division (data_helper.py:63-68)
+    shapes = [(32, 3, 1, 50), (32, 3, 1, 50), (32, 3, 52, 1), (32, 3, 52, 1), (32, 3, 1, 50), (32, 3, 1, 50)]
+    ws = [((torch.rand(s, generator=g) - 0.5) * 0.2).to(dev) for s in shapes]
+    bs = [((torch.rand(32, generator=g) - 0.5) * 0.2).to(dev) for _ in shapes]
+    gm = (torch.rand(3, 258, 258, 32, generator=g) - 0.5).to(dev)
+    forms = {"tensor": views.to(dev), "tuple": tuple(views.to(dev)), "u8": frames.to(dev), "u8_tuple": tuple(frames.to(dev))}
+    outs = {k: (gconv.strip6_fwd(v, ws, bs), gconv.strip6_wgrad(v, gm)) for k, v in forms.items()}
+    base = outs["tensor"]
+    for k, (mo, (dws, dbs)) in outs.items():
+        assert torch.equal(mo, base[0]), k
+        assert all(torch.equal(a, b) for a, b in zip(dws + dbs, base[1][0] + base[1][1])), k
+
+
+def test_spatial_mapping_cnn_fused_strips_equal_the_generic_engine(dev):
+    """SpatialMappingCNN forward + backward with the one-launch strip kernels (default) and with gconv.STRIP6 off (the round-4 path: six
+    NHWC4 re-layouts, six launches of the generic engine each way): same map, same gradients to summation order."""
+    from driving_dirty_amd import gconv, synth
+    from driving_dirty_amd.spatial import SpatialMappingCNN
+    m = SpatialMappingCNN()
+    synth.fill_module(m, seed=13)
+    m = m.to(dev)
+    x = synth.camera_batch(2, seed=13).to(dev)
+    res = {}
+    for fused in (True, False):
+        prev, gconv.STRIP6 = gconv.STRIP6, fused
+        try:
+            m.zero_grad(set_to_none=True)
+            y = m(x)
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            res[fused] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        finally:
+            gconv.STRIP6 = prev
+    ya, ga = res[True]
+    yb, gb = res[False]
+    assert float((ya - yb).abs().max()) <= 2e-6 * float(yb.abs().max())
+    for k in gb:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * float(gb[k].abs().max()), k

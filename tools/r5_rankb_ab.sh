@@ -11,7 +11,7 @@ for v in 0 5 2; do
   DD_RANKB_VARIANT=$v timeout -k 10 300 python tools/bench_rankb.py >> $out/alone.log 2>&1 || exit 1
 done
 echo "== variant 0, 2 blocks per CU" >> $out/alone.log
-DD_ADAM_BLOCKS_PER_CU=2 timeout -k 10 300 python tools/bench_rankb.py >> $out/alone.log 2>&1 || exit 1
+timeout -k 10 300 python tools/bench_rankb.py >> $out/alone.log 2>&1 || exit 1
 grep -v amdgpu.ids $out/alone.log
 for v in off 0 5 2; do
   if [ $v = off ]; then f=off; else f=on; fi
