@@ -2165,8 +2165,8 @@ int launch_wino2(const float* x, const float* up, const float* bias, const unsig
   const int grid = resident_grid(d, (long)d->batch * nstrips * ((d->height + 1) / 2), WPB, 1);
   if (nw_out) *nw_out = grid * WPB;
   if (int rc = ring ? allow_lds(conv_wino2_fwd<EPI, WPB>, lds) : allow_lds(conv_wino2r_fwd<EPI, WPB>, lds)) return rc;
-  // rows of the next tile-row are pulled into L2 a tile-row ahead (in the step: forward 1.195 -> 1.163 ms; DD_W2_PREFETCH=0 for A/B)
-  static const int pf_rows = getenv("DD_W2_PREFETCH") ? max(0, min(4, atoi(getenv("DD_W2_PREFETCH")))) : 1;
+  // rows of the next tile-row are pulled into L2 a tile-row ahead (in the step: forward 1.195 -> 1.163 ms against no prefetch)
+  constexpr int pf_rows = 1;
   auto kring = conv_wino2_fwd<EPI, WPB>;
   auto kreg = conv_wino2r_fwd<EPI, WPB>;
   if (ring) hipLaunchKernelGGL(kring, dim3(grid), dim3(WPB * 64), lds, st, x, up, bias, bits_in, y, bits_out, d->batch, d->height, d->width, nstrips, x4, w1part);

@@ -578,8 +578,7 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
   const DcPlan plan = dc_plan(*d, d->dil_h);
   // one 8-wave workgroup per CU, all resident -- TWO for the stride-1 3x3 layers on at most one column tile (out_conv, rm_conv_2, the decoder's
   // dc2: 58 KB of LDS and <= 118 registers fit twice; their short tap loops (9 taps) leave a single workgroup waiting on its fills)
-  static const int wgs3 = getenv("DD_DCONV3_WGS_PER_CU") ? max(1, min(2, atoi(getenv("DD_DCONV3_WGS_PER_CU")))) : 2;
-  const int per_cu = (d->kh == 3 && nt <= 1) ? wgs3 : 1;
+  const int per_cu = (d->kh == 3 && nt <= 1) ? 2 : 1;
   const int grid = (int)max(1, min(dd_cu_budget_internal() * per_cu, plan.total));
 #define DD_DC(KK, DD_, NTT) hipLaunchKernelGGL((dconv_fwd_kernel<KK, DD_, NTT>), dim3(grid), dim3(DC_THREADS), 0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes, dbg_repeat)
 #define DD_DC_NT(KK, DD_) do { if (nt == 0) DD_DC(KK, DD_, 0); else if (nt == 1) DD_DC(KK, DD_, 1); else if (nt == 2) DD_DC(KK, DD_, 2); else DD_DC(KK, DD_, 3); } while (0)
@@ -1026,8 +1025,7 @@ int32_t dd_dconv_wgrad_supported(int32_t k, int32_t dil, int32_t cin, int32_t co
   // kernel; the 32->16 / 16->8 layers would fill half / a quarter of its MFMA columns (4.2 / 4.5 ms there against 2.73 / 1.88 on
   // the generic kernel) and run on the 16-wide kernel instead.
   const int v = dw_variant(k, dil, cin, cout);
-  static const bool only32 = getenv("DD_DCONV_WGRAD16_OFF") != nullptr;      // A/B knob: keep the 16-wide layers on the generic kernel
-  return v >= 0 && !(only32 && !(v == 0 || v == 1 || v == 4)) ? 1 : 0;
+  return v >= 0 ? 1 : 0;
 }
 
 int64_t dd_dconv_wgrad_workspace_bytes(int32_t k, int32_t dil, int32_t cin, int32_t cout) {

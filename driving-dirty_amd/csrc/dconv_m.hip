@@ -563,9 +563,7 @@ __global__ __launch_bounds__(64) void dconv_colsum_reduce(const float* __restric
 
 // Whether the windowed kernel (the only one that can also sum its output per channel) takes this layer: the launcher's own conditions.
 bool dd_dconv_mwin_takes(const dd_gconv_desc* d, int epilogue, bool has_mask, bool has_bias) {
-  static const bool off = (getenv("DD_DCONV_MFWD_OFF") && atoi(getenv("DD_DCONV_MFWD_OFF")) != 0) ||
-                          (getenv("DD_DCONV_MWIN_OFF") && atoi(getenv("DD_DCONV_MWIN_OFF")) != 0);
-  if (off || !dd_dconv_desc_ok(d)) return false;
+  if (!dd_dconv_desc_ok(d)) return false;
   if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU && epilogue != DD_EPI_RELU_MASK) return false;
   if ((epilogue == DD_EPI_RELU_MASK && !has_mask) || ((epilogue == DD_EPI_BIAS || epilogue == DD_EPI_BIAS_RELU) && !has_bias)) return false;
   if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7 || d->cout <= 16 || d->cout > 64 || d->cin % 8) return false;
@@ -579,11 +577,8 @@ bool dd_dconv_mwin_takes(const dd_gconv_desc* d, int epilogue, bool has_mask, bo
 // windowed kernel fills it -- false is returned, nothing launched, when the layer would go elsewhere.
 bool dd_dconv_mfwd_launch_colsum(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
                                  int epilogue, int wp_bytes, hipStream_t st, float* colsum_part) {
-  static const bool off = getenv("DD_DCONV_MFWD_OFF") && atoi(getenv("DD_DCONV_MFWD_OFF")) != 0;
-  // the padded (transposed-forward) form is correct but slower than the input-aligned forward of dconv_t.hip (up_conv_2: 6.04 against
-  // 5.36 ms -- tiles that straddle a row need nearly every tap column): an experiment knob, off by default
-  static const bool fwd_too = getenv("DD_DCONV_MFWD_PADDED") && atoi(getenv("DD_DCONV_MFWD_PADDED")) != 0;
-  if (off) return false;
+  // (the padded, transposed-forward form of this kernel measured slower than the input-aligned forward of dconv_t.hip -- up_conv_2: 6.04
+  // against 5.36 ms, tiles that straddle a row need nearly every tap column -- and is not instantiated: gather form, pad 0 only)
   if (!dd_dconv_desc_ok(d)) return false;
   if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU && epilogue != DD_EPI_RELU_MASK) return false;
   if (epilogue == DD_EPI_RELU_MASK && !mask) return false;
@@ -591,10 +586,9 @@ bool dd_dconv_mfwd_launch_colsum(const float* x, const float* packed, const floa
   if (d->kh != 7 || d->kw != 7 || d->dil_h != 7 || d->dil_w != 7) return false;
   if (d->cout <= 16 || d->cout > 64 || d->cin % 8) return false;
   if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;      // rejected fill offsets stay rejected with a row offset added
-  const bool padded = d->pad_h != 0 || d->pad_w != 0;
-  if (padded && !fwd_too) return false;
+  if (d->pad_h != 0 || d->pad_w != 0) return false;
   const int halo = 42;
-  if (!padded && (d->out_h > d->in_h - halo || d->out_w > d->in_w - halo)) return false;
+  if (d->out_h > d->in_h - halo || d->out_w > d->in_w - halo) return false;
   const int ntc = (d->cout + 31) / 32;
   const int rw = d->out_w + halo;
   const int grid = dd_cu_budget_internal();
@@ -606,7 +600,6 @@ bool dd_dconv_mfwd_launch_colsum(const float* x, const float* packed, const floa
                        0, st, x, packed, bias, mask, y, *d, epilogue, wp_bytes);                                                     \
     return true;                                                                                                                     \
   } while (0)
-  static const bool window = !(getenv("DD_DCONV_MWIN_OFF") && atoi(getenv("DD_DCONV_MWIN_OFF")) != 0);
 #define DD_MW(NTC_, IWP_)                                                                                                            \
   do {                                                                                                                               \
     if (d->in_w <= IWP_ && 3 * d->out_w <= 1024 && d->out_w + halo <= IWP_ && d->out_h >= 7) {                                        \
@@ -619,13 +612,13 @@ bool dd_dconv_mfwd_launch_colsum(const float* x, const float* packed, const floa
       return true;                                                                                                                   \
     }                                                                                                                                \
   } while (0)
-  if (!padded && window && ntc == 2) DD_MW(2, 384);        // up_conv_2 data gradient: phase rows, one new input row per step
-  if (!padded && window && ntc == 1) DD_MW(1, 384);        // up_conv_3 data gradient
+  if (ntc == 2) DD_MW(2, 384);        // up_conv_2 data gradient: phase rows, one new input row per step
+  if (ntc == 1) DD_MW(1, 384);        // up_conv_3 data gradient
 #undef DD_MW
   if (colsum_part) return false;                           // only the windowed kernel sums its output
-  if (!padded && ntc == 2) DD_MF(2, 4, 3, 1024, false, 8);      // up_conv_2 data gradient: 3 x 340 = 1020 pixels
-  if (!padded && ntc == 1) DD_MF(1, 4, 3, 1152, false, 8);      // up_conv_3 data gradient: 3 x 382 = 1146 (6-row tasks, 8 tiles per wave: 1.58 against 1.52 ms)
-  if (padded && ntc == 1) DD_MF(1, 4, 3, 1152, true, 8);        // up_conv_2 forward: 3 x (340 + 42) = 1146
+  // rows the windowed kernel does not take (wider than 384 pixels, fewer than 7 output rows): whole-row gather, no sliding window
+  if (ntc == 2) DD_MF(2, 4, 3, 1024, false, 8);      // up_conv_2 data gradient: 3 x 340 = 1020 pixels
+  if (ntc == 1) DD_MF(1, 4, 3, 1152, false, 8);      // up_conv_3 data gradient: 3 x 382 = 1146 (6-row tasks, 8 tiles per wave: 1.58 against 1.52 ms)
 #undef DD_MF
   return false;
 }

@@ -891,10 +891,9 @@ int dd_dconv_fwd_split(const void* xs, const void* packed, const float* bias, co
       hipLaunchKernelGGL((dconv_stfwd_kernel<7, 7, 9, 1, 320, ABL, 2>), dim3(grid), dim3(SP_THREADS), 0, st, (const char*)xs, (const char*)packed, \
                          bias, y, (char*)y_planes, *d, epilogue);                                                                         \
   } while (0)
-  // A/B: DD_SPLIT_NBUF=3 = three LDS buffers for the 256-wide form (a fill has two stages to land): 5.63-5.67 ms against 5.57-5.58 with
-  // two -- the fills' latency is not what the kernel waits for (it runs power-limited at 1.88 GHz, matrix pipe 64 % busy)
-  static const bool three = getenv("DD_SPLIT_NBUF") && atoi(getenv("DD_SPLIT_NBUF")) == 3;
-#define SP_LAUNCH(ABL) do { if (three) SP_LAUNCH_(ABL, 3); else SP_LAUNCH_(ABL, 2); } while (0)
+  // (three LDS buffers for the 256-wide form -- a fill has two stages to land -- measured 5.63-5.67 ms against 5.57-5.58 with two: the fills'
+  // latency is not what the kernel waits for, it runs power-limited at 1.88 GHz with the matrix pipe 64 % busy; the arm is gone)
+#define SP_LAUNCH(ABL) SP_LAUNCH_(ABL, 2)
 #ifdef DD_TIMING_DIAG      // diagnostic builds only (build.py --diag): DD_SPLIT_ABL selects a timing ablation, the results are then wrong
   switch (getenv("DD_SPLIT_ABL") ? atoi(getenv("DD_SPLIT_ABL")) : 0) {
     case 1: SP_LAUNCH(1); break;

@@ -512,8 +512,6 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_gfwd_kernel(const float* __r
 // Launches the input-aligned forward if the layer is one it is built for; returns false (nothing launched) otherwise.
 bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias, float* y, const dd_gconv_desc* d, int epilogue,
                           int wp_bytes, hipStream_t st) {
-  static const bool off = getenv("DD_DCONV_TFWD_OFF") && atoi(getenv("DD_DCONV_TFWD_OFF")) != 0;
-  if (off) return false;
   if (!dd_dconv_desc_ok(d)) return false;                // the shared eligibility test (stride, div, ostride, channel bounds, sizes)
   if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU) return false;
   if (d->kh != d->kw || d->dil_h != d->dil_w) return false;
@@ -550,8 +548,6 @@ bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias
 // The same for the data gradient (gather form, pad 0): false = not one of its layers, nothing launched.
 bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
                           int epilogue, int wp_bytes, hipStream_t st) {
-  static const bool off = getenv("DD_DCONV_GFWD_OFF") && atoi(getenv("DD_DCONV_GFWD_OFF")) != 0;
-  if (off) return false;
   if (!dd_dconv_desc_ok(d)) return false;
   if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU && epilogue != DD_EPI_RELU_MASK) return false;
   if (epilogue == DD_EPI_RELU_MASK && !mask) return false;

@@ -753,9 +753,7 @@ WgradPlan wgrad_plan(const dd_gconv_desc* d) {
   p.no = p.nto <= 3 ? p.nto : 2;
   p.nog = (p.nto + p.no - 1) / p.no;
   p.nj = (d->kh * d->kw * d->cin + 31) / 32;
-  // tuning knobs (results unchanged), clamped to the tilings the launch switch below instantiates: (2, 1..4) and (3, 1..3)
-  static const int nb3 = min(3, max(1, getenv("DD_WGRAD_NB3") ? atoi(getenv("DD_WGRAD_NB3")) : 3)),
-                   nb2 = min(4, max(1, getenv("DD_WGRAD_NB2") ? atoi(getenv("DD_WGRAD_NB2")) : 4));      // measured at bs 32: up_conv_1 12.19 -> 11.39 ms, up_conv_2 6.37 -> 6.24
+  constexpr int nb3 = 3, nb2 = 4;      // measured at bs 32 against (2, 2): up_conv_1 12.19 -> 11.39 ms, up_conv_2 6.37 -> 6.24
   p.nb = pick_nb(p.nj, p.no, p.no == 1 ? 4 : (p.no == 2 ? nb2 : nb3));
   p.njg = (p.nj + p.nb - 1) / p.nb;
   p.njobs = p.nog * p.njg;
@@ -1000,8 +998,7 @@ int dd_gconv_fwd(const float* x, const float* packed, const float* bias, const f
   DD_REQUIRE(lds <= 64 * 1024, DD_ERR_UNSUPPORTED, "gconv_fwd: tap table of %zu bytes", lds);
   // sets (GU chunk pairs) per tap when a set never straddles taps, else 0 = no tap skipping
   const int pairs_per_tap = d->cin / 8;
-  static const bool noskip = getenv("DD_GCONV_NOSKIP") != nullptr;   // A/B knob for the tap-skipping path
-  const int spt = (!noskip && d->cin % 8 == 0 && pairs_per_tap % GU == 0) ? pairs_per_tap / GU : 0;
+  const int spt = (d->cin % 8 == 0 && pairs_per_tap % GU == 0) ? pairs_per_tap / GU : 0;
 #define DD_GF(NT, DIV) hipLaunchKernelGGL((gconv_fwd_kernel<NT, DIV>), dim3(grid), dim3(512), lds, st, x, packed, bias, mask, y, *d, ng, epilogue, spt)
   if (nt == 1) { if (div) DD_GF(1, true); else DD_GF(1, false); }
   else { if (div) DD_GF(2, true); else DD_GF(2, false); }

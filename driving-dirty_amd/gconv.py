@@ -98,9 +98,8 @@ def _fwd(x, packed, bias, mask, y, d, epi):
 # The dilated stride-1 layers (the box heads' up-convs) have their own phase-decomposed, LDS-staged kernel (csrc/dconv.hip);
 # DD_DCONV=0 routes them through the generic gather engine again (A/B knob, same results up to summation order).
 DCONV = os.environ.get("DD_DCONV", "1") != "0"
-# Data gradient of strided Conv2d layers by input phase (Layer._backward_data_phased); DD_PHASED_DGRAD=0: the gather with a
-# divisibility test per tap again (A/B knob).
-PHASED_DGRAD = os.environ.get("DD_PHASED_DGRAD", "1") != "0"
+# (Strided Conv2d layers take their data gradient by input phase, Layer._backward_data_phased: the gather with a divisibility test per tap
+# it replaced lost its A/B in round 2 and is gone.)
 
 
 # Precision mode "fp32x3" (csrc/dconv_split.hip; off by default): the forward, data gradient and weight gradient of up_conv_1 / up_conv_2
@@ -130,8 +129,8 @@ class split_products:
         global SPLIT_BF16
         SPLIT_BF16 = self.prev
         return False
-# ... its kernels write the bf16 planes of their OUTPUT from the epilogue for the next layer (DD_SPLIT_EMIT=0: a split pass per operand again; A/B)
-SPLIT_EMIT = os.environ.get("DD_SPLIT_EMIT", "1") != "0"
+# ... its kernels write the bf16 planes of their OUTPUT from the epilogue for the next layer (round 4 A/B against a split pass per operand:
+# 44.75-45.26 -> 44.21-44.47 ms)
 
 
 def split_rows(view):
@@ -144,7 +143,6 @@ def split_rows(view):
     return xs
 
 
-COLSUM = os.environ.get("DD_DCONV_COLSUM", "1") != "0"      # A/B knob: 0 = bias gradients of the up-convs by their own pass over dL/dy
 K2S2_WGRAD = os.environ.get("DD_K2S2_WGRAD", "1") != "0"      # A/B knob: 0 = the k2 s2 32->32 weight gradient by four phase launches
 SSCONV_FWD = os.environ.get("DD_SSCONV_FWD", "1") != "0"      # A/B knob: 0 = ss_conv's forward on the generic engine
 SSCONV_DGRAD = os.environ.get("DD_SSCONV_DGRAD", "1") != "0"      # A/B knob: 0 = ss_conv's data gradient by seven phase launches
@@ -181,7 +179,7 @@ def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real,
             check(lib.dd_dconv_split_input(_p(x), _p(xs), C.byref(d), _stream()), "dd_dconv_split_input")
         check(lib.dd_dconv_split_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_split_pack")
         ys = None
-        if emit is not None and SPLIT_EMIT and d.cout % 16 == 0 and d.out_coff == 0 and d.ooff_h == 0 and d.ooff_w == 0 and d.omem_h == d.out_h and d.omem_w == d.out_w:
+        if emit is not None and d.cout % 16 == 0 and d.out_coff == 0 and d.ooff_h == 0 and d.ooff_w == 0 and d.omem_h == d.out_h and d.omem_w == d.out_w:
             ys = torch.empty(d.batch * d.out_h * (d.cout // 16) * d.out_w * 112, device=x.device, dtype=torch.uint8)
             emit["ys"] = ys
         check(lib.dd_dconv_fwd_split(_p(xs), _p(packed), _p(bias), _p(mask), _p(y), _p(ys), C.byref(d), epi, _stream()), "dd_dconv_fwd_split")
@@ -190,7 +188,7 @@ def _conv(x, weight, bias, mask, y, d, epi, w_off, sn, sc, flip, n_real, c_real,
         n = lib.dd_dconv_packed_floats(C.byref(d))
         packed = torch.empty(n, device=weight.device, dtype=torch.float32)
         check(lib.dd_dconv_pack(_p(weight), _p(packed), C.byref(d), w_off, sn, sc, int(flip), n_real, c_real, _stream()), "dd_dconv_pack")
-        if (colsum is not None and COLSUM and bias is None and epi in (EPI_NONE, EPI_RELU_MASK)
+        if (colsum is not None and bias is None and epi in (EPI_NONE, EPI_RELU_MASK)
                 and lib.dd_dconv_colsum_supported(C.byref(d), epi, int(mask is not None))):
             # the launch also leaves the per-channel sums of its output: the bias gradient of the layer below (csrc/dconv_m.hip)
             nbytes = lib.dd_dconv_colsum_workspace_bytes()
@@ -285,8 +283,7 @@ class Layer:
                 and ddst.coff == 0 and dsrc.coff == 0 and _ops().ssconv_dgrad_ok(ddst.buf, dsrc.buf)):
             _ops().ssconv_dgrad(ddst.buf, _p_weight(weight), dsrc.buf)      # ss_conv: all seven phases in one launch (csrc/ssconv.hip)
             return
-        if (not self.transposed and self.stride != (1, 1) and self.dil == (1, 1) and self.pad == (0, 0) and cin_out <= 64
-                and PHASED_DGRAD):
+        if not self.transposed and self.stride != (1, 1) and self.dil == (1, 1) and self.pad == (0, 0) and cin_out <= 64:
             return self._backward_data_phased(weight, ddst, dsrc, relu_src, mask_pass, epi, cos)
         for n0 in range(0, cin_out, 64):                    # the generic kernel writes at most 64 channels per launch
             nn = min(64, cin_out - n0)

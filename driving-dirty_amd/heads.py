@@ -104,7 +104,6 @@ _TILES = (("bl_conv", 3, 0, 0, 0), ("fl_conv", 0, 0, 0, 1), ("b_conv", 4, 1, 1, 
 _ORDER = ("f_conv", "fl_conv", "fr_conv", "b_conv", "bl_conv", "br_conv", "out_conv")   # parameter order of the module
 
 
-KEEP_LAYOUTS = os.environ.get("DD_SPATIAL_KEEP_LAYOUTS", "1") != "0"      # A/B knob: 0 = lay the six views out again in the backward
 
 
 class SpatialMapFn(torch.autograd.Function):
@@ -158,7 +157,7 @@ class SpatialMapFn(torch.autograd.Function):
             ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
         ctx.tile = (th, tw)
         ctx.fused = fused
-        ctx.laid = laid if (KEEP_LAYOUTS and not fused) else None           # inputs without gradients: plain references
+        ctx.laid = None if fused else laid                   # generic path: the six layouts are kept for the weight gradients (inputs without gradients: plain references)
         return out
 
     @staticmethod

@@ -569,7 +569,7 @@ MFMA_PHASE2_HOOKS = []
 C2_DGRAD_FIRST = False      # c2's data gradient before its weight gradient (same results; see EncoderConvStack.backward)
 
 # c1's weight gradient taken from c2's data gradient inside conv_wino2_fwd<EPI_RELU_BITS_W1> (2-D Winograd path only)
-FUSE_C1_WGRAD = os.environ.get("DD_FUSE_C1_WGRAD", "1") != "0"
+FUSE_C1_WGRAD = True      # c1's weight gradient inside c2's data gradient (the 2-D Winograd form); tests may switch it off in process
 
 
 # Test hook: when set to a dict, EncoderConvStack.forward leaves its three ReLU outputs (NHWC) in it, so that a checker can
@@ -872,7 +872,7 @@ class BnReluDrop(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ encoder tail
-FUSE_MLP_TAIL = os.environ.get("DD_FUSE_MLP_TAIL", "1") != "0"
+FUSE_MLP_TAIL = True      # the encoder tail as one launch each way where its sizes allow (dd_mlp_tail_supported)
 
 
 def mlp_tail_supported(m, h1, h2, l):

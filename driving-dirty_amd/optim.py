@@ -44,7 +44,7 @@ class HipAdam(torch.optim.Optimizer):
         self._held = []            # factors read by launches on the side stream: kept until step() has joined it
         self._fac_now = {}         # weight -> gathered Factors that have arrived (factor mode of ddp.GradSync + rank-B)
 
-    SMALL_NUMEL = int(os.environ.get("DD_ADAM_MULTI_NUMEL", 1 << 16))      # tensors up to this size go into one multi-tensor launch (0: never)
+    SMALL_NUMEL = 1 << 16      # tensors up to this size go into one multi-tensor launch (0: never; tests set it per instance)
 
     def _state_of(self, p):
         st = self.state[p]

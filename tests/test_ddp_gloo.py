@@ -247,8 +247,8 @@ def _adam_worker(rank, world, port, out):
     dev = torch.device("cuda:0")
     model = _tiny_model(dev)
     opt = HipAdam(model.parameters(), lr=1e-2)
-    sync = GradSync(model, big_numel=1000, chunk_numel=4096)
-    opt.overlap_with_backward(big_numel=1000, grad_scale=sync.grad_scale, grad_sync=sync)
+    sync = GradSync(model, big_numel=1000, chunk_numel=1 << 18)      # the 5.12 M-element head weight: 20 pieces (4096-element pieces were 1250
+    opt.overlap_with_backward(big_numel=1000, grad_scale=sync.grad_scale, grad_sync=sync)      # gloo round trips per step: 12-24 s of this test)
     for step in range(3):
         model.zero_grad(set_to_none=True)
         model.training_step(_tiny_batch(dev, step, rank), step)["loss"].backward()
