@@ -302,7 +302,7 @@ int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const floa
   a.bc2_sqrt = (float)sqrt(bc2);
   a.inv_bc2 = 1.f / a.bc2_sqrt;
   a.gscale = grad_scale;
-  const bool short_rows = rows <= 32 && a.ntile_k <= 2;      // adam_rankb_short_kernel: its work list is of n-groups, all k-tiles of a group together
+  const bool short_rows = rows <= 32 && a.ntile_k == 1;      // adam_rankb_short_kernel: its work list is of n-groups
   const long total = (long)((a.ntile_n + 3) / 4) * (short_rows ? 1 : a.ntile_k);
   DD_REQUIRE(total < ((long)1 << 31), DD_ERR_UNSUPPORTED, "adam_rankb: too many tiles");
   a.total = (int)total;
@@ -311,8 +311,9 @@ int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const floa
   const int grid = (int)min(total, (long)DD_NUM_CU * per_cu);
   a.per = (int)((total + grid - 1) / grid);
   hipStream_t st = (hipStream_t)stream;
-  if (short_rows && a.ntile_k == 1) hipLaunchKernelGGL((adam_rankb_short_kernel<1, 2>), dim3(grid), dim3(256), 0, st, a);
-  else if (short_rows) hipLaunchKernelGGL((adam_rankb_short_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);
+  // (two k-tiles per group -- the decoder's fc2, K = 128 -- ran on a <2, RG = 1> build of the short form (its RG = 2 build needs 76 registers):
+  // 2.98 ms beside the conv backward for 0.80 alone; the long-row form below keeps two rows of p / m / v in flight for it)
+  if (short_rows) hipLaunchKernelGGL((adam_rankb_short_kernel<1, 2>), dim3(grid), dim3(256), 0, st, a);
   else if (rows <= 32) hipLaunchKernelGGL((adam_rankb_lds_kernel<1, 2>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((adam_rankb_lds_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);
   DD_LAUNCH_CHECK("adam_rankb");

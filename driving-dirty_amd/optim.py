@@ -85,12 +85,36 @@ class HipAdam(torch.optim.Optimizer):
         s = self._sync
         return s is not None and (getattr(s, "active", False) or getattr(s, "shard", False)) and not getattr(s, "factor", False)
 
+    # Beside the backward a rank-B pass needs 72 registers: it fits beside the c2 WEIGHT gradient (440) and nowhere else -- the fused data
+    # gradient behind it (475) cannot start on a CU until the optimizer's workgroup there has drained, while the plain 48-register
+    # dd_adam_step does run beside both.  So the rank-B passes must be over when the weight gradient is (~1.2 ms at 32 rows, in which they
+    # move ~4 GB): the registered tensors take the rank-B pass smallest first while their p / m / v bytes fit that budget, the others keep
+    # their materialised gradient and the plain pass.  Config 2: head 1.0 GB + fc1 2.9 GB, both rank-B (7.8 -> 7.6 ms).  Autoencoder:
+    # fc1 2.9 GB rank-B, the decoder's fc2 (3.9 GB) plain -- both rank-B (6.7 GB) left the data gradient waiting 1.6 ms: 11.2 -> 12.4 ms.
+    # (A/B on one box: autoencoder bs 32 with the budget 11.05-11.12 ms, without it 12.10-12.18, no rank-B 11.13-11.41; config 2 with
+    # both tensors inside the budget 7.54-7.58 ms, with fc1 pushed out of it 7.64-7.71.)
+    RANKB_BYTES_PER_ROW = 1.25e8
+
+    def _rankb_fits(self, p, rows):
+        if self._side is None:
+            return True                                       # passes after the backward, by themselves: no window to fit
+        budget = self.RANKB_BYTES_PER_ROW * rows
+        for q in sorted((q for q in self._rankb if q.requires_grad), key=lambda q: q.numel()):
+            budget -= 24.0 * q.numel()
+            if budget < 0:
+                return False
+            if q is p:
+                return True
+        return False
+
     def linear_factors(self, weight, x, dy):
         """Called by ``ops.Linear.backward`` (on the backward's stream) for a weight registered in ``ops.RANKB``.  Returns 0: declined,
         the caller forms dW and db as usual; 1: the weight's gradient will be formed from (x, dy) inside its Adam pass, the caller
         still owes db; 2: the bias is updated by that pass too."""
         p = self._rankb_keys.get(weight.data_ptr())
         if p is None or not p.requires_grad or p.grad is not None or self._sync_blocks_rankb():
+            return 0
+        if x.shape[0] > 64 or (p not in self._rankb_now and not self._rankb_fits(p, x.shape[0])):
             return 0
         if not (x.is_contiguous() and dy.is_contiguous() and x.dtype == torch.float32 and dy.dtype == torch.float32):
             return 0
@@ -391,8 +415,12 @@ class HipAdam(torch.optim.Optimizer):
         ev = torch.cuda.current_stream().record_event()
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
+            # rank-B passes first: they only fit beside the weight gradient, the plain passes behind them also run beside the data gradient
             for p, group in self._pending:
-                if self._take_rankb(p, group, self._scale):
+                if p in self._rankb_now:
+                    self._take_rankb(p, group, self._scale)
+            for p, group in self._pending:
+                if p in self._early:
                     continue
                 shards = self._sync.shards(p) if self._sync is not None else None
                 pieces = self._sync.pieces(p) if self._sync is not None else None
