@@ -81,6 +81,9 @@ def parse_args():
     ap.add_argument("--fuse-linear-wgrad", choices=("on", "off"), default="on",
                     help="rank-B optimizer pass: the weight gradients of the big Linear layers are formed inside their Adam pass, never written "
                          "(off: dd_linear_wgrad + dd_adam_step, the round-4 arrangement; A/B)")
+    ap.add_argument("--passes-last", choices=("auto", "on", "off"), default="auto",
+                    help="c2's data gradient first and the optimizer passes beside its weight gradient, last (auto: with the rank-B pass on one GPU "
+                         "or in factor mode); off: the round-4 order; A/B")
     ap.add_argument("--alt-all-reduce", choices=("on", "off"), default="on",
                     help="N > 1 with a sharded / factor-gather default: time the plain all-reduce step first and carry it in the line (on)")
     ap.add_argument("--simulate-shard", type=int, default=0, metavar="N",
@@ -994,7 +997,7 @@ def run_rank(a):
     def make_step(shard_, factor_):
         return TrainStep(model, lr=1e-3, adam_overlap=overlap, shard_optimizer=shard_, reserve_cus=reserve, force_collectives=rehearse,
                          simulate_world=a.simulate_shard if a.simulate_shard > 1 else 0, scheduler=False, factor_linear=factor_,
-                         fuse_linear_wgrad=a.fuse_linear_wgrad == "on")
+                         fuse_linear_wgrad=a.fuse_linear_wgrad == "on", passes_last={"auto": "auto", "on": True, "off": False}[a.passes_last])
 
     def timed_region(ts, timer, tag):
         """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over ranks of the wall time."""

@@ -370,6 +370,23 @@ class HipAdam(torch.optim.Optimizer):
         self.refresh()
         lightning.on_unfreeze(self)
 
+    def passes_last(self, on=True):
+        """Where the queued optimizer passes are launched in the encoder's backward: at the first MFMA hook (in front of c2's weight
+        gradient, then its data gradient: the round-1..4 order) or, ``on``, with c2's DATA gradient first and the passes beside its
+        weight gradient, which then goes last (``ops.C2_DGRAD_FIRST``).  The rank-B passes (72 registers) fit beside the weight gradient
+        only: launched in front of it they are still resident when the 475-register data gradient is dispatched, and that kernel waits
+        for them CU by CU (1.9 ms from dispatch to end for 1.4 ms of work).  Same step time either way on one GPU (round 5 A/B: 7.51 /
+        7.51 ms), but with the passes last the step's longest kernel runs -- and is timed -- by itself."""
+        if self._side is None:
+            return
+        here, there = (ops.MFMA_PHASE2_HOOKS, ops.MFMA_PHASE_HOOKS) if on else (ops.MFMA_PHASE_HOOKS, ops.MFMA_PHASE2_HOOKS)
+        if self._flush_pending in there:
+            there.remove(self._flush_pending)
+        if self._flush_pending not in here:
+            here.insert(0, self._flush_pending)
+        self._last = bool(on)
+        ops.C2_DGRAD_FIRST = bool(on) or bool(getattr(self._sync, "factor", False))
+
     def refresh(self):
         """Hook the big parameters that require a gradient and are not hooked yet: a frozen feature extractor
         (roadmap_bce_v2.py:45-47) gets its hooks when ``LightningModule.unfreeze()`` switches it on.  A big parameter
@@ -395,10 +412,11 @@ class HipAdam(torch.optim.Optimizer):
         self._rankb, self._rankb_keys, self._rankb_now, self._fac_now = {}, {}, {}, {}
         if self._flush_pending in ops.MFMA_PHASE_HOOKS:
             ops.MFMA_PHASE_HOOKS.remove(self._flush_pending)
+        if self._flush_pending in ops.MFMA_PHASE2_HOOKS:
+            ops.MFMA_PHASE2_HOOKS.remove(self._flush_pending)
         if self._flush_factored in ops.MFMA_PHASE2_HOOKS:
             ops.MFMA_PHASE2_HOOKS.remove(self._flush_factored)
-            if getattr(self._sync, "factor", False):
-                ops.C2_DGRAD_FIRST = False
+            ops.C2_DGRAD_FIRST = False
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._side = None

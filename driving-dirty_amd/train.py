@@ -32,7 +32,7 @@ from .optim import HipAdam
 class TrainStep:
     def __init__(self, model, lr=None, adam_overlap="auto", shard_optimizer=False, reserve_cus=None, process_group=None,
                  force_collectives=False, simulate_world=0, scheduler="auto", big_numel=1 << 20, chunk_numel=1 << 25, factor_linear=False,
-                 fuse_linear_wgrad=True):
+                 fuse_linear_wgrad=True, passes_last="auto"):
         self.model = model
         hp = getattr(model, "hparams", None)
         if lr is None:
@@ -67,6 +67,13 @@ class TrainStep:
         # rank-B mode: the weight gradient of the big Linear layers is formed inside their Adam pass, never written (optim.py); the
         # optimizer declines by itself where the gradient has to travel as a tensor (all-reduce / sharded GradSync)
         self.fused = self.optimizer.fuse_linear_wgrad(model, min_numel=big_numel) if fuse_linear_wgrad else []
+        # rank-B passes only fit beside c2's weight gradient: that kernel goes last, the data gradient runs by itself in front of it
+        # (HipAdam.passes_last).  Under an all-reduce / sharded GradSync the passes are the plain 48-register kernel, ready at the top of
+        # the backward, and keep the old order (they run beside both conv kernels).
+        if passes_last == "auto":
+            passes_last = bool(self.fused) and not ((self.sync.active or self.sync.shard) and not self.sync.factor)
+        if self.overlap and passes_last:
+            self.optimizer.passes_last(True)
         if scheduler == "auto":      # the modules that return ([optimizer], [scheduler]) from configure_optimizers
             scheduler = self._reference_has_scheduler(model)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, patience=10) if scheduler else None

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""AE pre-training step (config 1's GPU twin, bs 32) through TrainStep with the rank-B optimizer pass on / off (one process, same box)."""
+"""AE pre-training step (config 1's GPU twin, bs 32) through TrainStep with the rank-B optimizer pass on / off (one process, same box).
+PASSES_LAST=on|off|auto: HipAdam.passes_last (c2's data gradient first, the optimizer passes beside its weight gradient)."""
 import os
 import sys
 import time
@@ -17,7 +18,8 @@ for rep in range(2):
     for fuse in (False, True):
         torch.manual_seed(20200505)
         ae = BasicAE(Namespace(hidden_dim=128, latent_dim=64, learning_rate=1e-3, output_img_freq=500)).to(dev)
-        ts = TrainStep(ae, lr=1e-3, scheduler=False, fuse_linear_wgrad=fuse)
+        pl = {"on": True, "off": False, "auto": "auto"}[os.environ.get("PASSES_LAST", "auto")]
+        ts = TrainStep(ae, lr=1e-3, scheduler=False, fuse_linear_wgrad=fuse, passes_last=pl)
         views = torch.rand(b, 6, 3, 256, 306, device=dev)
         for i in range(3):
             ts(views, i)
