@@ -272,13 +272,19 @@ def test_bench_two_ranks_over_gloo_on_one_card(dev, config):
     """`bench.py --gpus 2 --config C` starting its own ranks, both on this card, gradients over gloo (DD_DIST_BACKEND=gloo): the N > 1
     control flow of every BASELINE configuration that exists only on several GPUs -- config 4 on the sharded optimizer, config 5 on the
     factor gather (the N = 2 default)."""
-    extra = ("--factor-linear", "off") if config == 4 else ()      # N = 2 defaults to the factor gather (config 5 here); config 4: the sharded optimizer
+    # N = 2 defaults to the factor gather (config 5 here); config 4: the sharded optimizer, without the all-reduce step in front of it (the
+    # two-mode line is asserted on config 5 here and on config 2 under torch.distributed.run below; 3 s of a 64 ms step saved)
+    extra = ("--factor-linear", "off", "--alt-all-reduce", "off") if config == 4 else ()
     line, err = _bench({"DD_DIST_BACKEND": "gloo", "DD_RESERVED_CUS": "0"}, "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1", *extra)
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["baseline_config"] == config
     assert line["config"]["optimizer"].startswith({3: "replicated", 4: "sharded", 5: "replicated; the big Linear layers all-gather"}[config])
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0
-    assert "[rank 0] bench.py preflight:" in err
+    assert "[rank 0] bench.py preflight:" in err and line["collective_probe"]["ms"] > 0
+    if config == 5:
+        assert line["config"]["alt_all_reduce"]["ms_per_step"] > 0 and "[rank 0] bench.py alt_all_reduce:" in err
+    elif config == 3:
+        assert line["config"]["alt_all_reduce_ms"] == line["ms_per_step"]      # the default mode IS the plain all-reduce
 
 
 def test_bench_under_torch_distributed_run_as_the_driver_launches_it(dev):
@@ -314,7 +320,7 @@ def test_bench_watchdog_prints_the_all_reduce_line_when_the_default_mode_stalls(
     """A rank that hangs in the DEFAULT mode's timed region (fault injection at a step index only that phase reaches is not possible --
     both phases count from 0 -- so the hang is injected by step AND phase): the watchdog fires, and rank 0's last words are a complete
     JSON line for the all-reduce step that did run, marked `default_mode_failed`."""
-    env = dict(os.environ, DD_DIST_BACKEND="gloo", DD_RESERVED_CUS="0", PYTHONPATH=ROOT, DD_WATCHDOG_S="12", DD_BENCH_FAULT="1:3:hang:default")
+    env = dict(os.environ, DD_DIST_BACKEND="gloo", DD_RESERVED_CUS="0", PYTHONPATH=ROOT, DD_WATCHDOG_S="10", DD_BENCH_FAULT="1:3:hang:default")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-others", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode != 0
