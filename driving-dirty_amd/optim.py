@@ -43,6 +43,7 @@ class HipAdam(torch.optim.Optimizer):
         self._rankb_now = {}       # weight -> (x, dy) of this step's backward, until the pass has been launched
         self._held = []            # factors read by launches on the side stream: kept until step() has joined it
         self._fac_now = {}         # weight -> gathered Factors that have arrived (factor mode of ddp.GradSync + rank-B)
+        self._last = False         # passes_last(): c2's data gradient first, the queued passes beside its weight gradient
 
     SMALL_NUMEL = 1 << 16      # tensors up to this size go into one multi-tensor launch (0: never; tests set it per instance)
 
@@ -85,27 +86,55 @@ class HipAdam(torch.optim.Optimizer):
         s = self._sync
         return s is not None and (getattr(s, "active", False) or getattr(s, "shard", False)) and not getattr(s, "factor", False)
 
-    # Beside the backward a rank-B pass needs 72 registers: it fits beside the c2 WEIGHT gradient (440) and nowhere else -- the fused data
-    # gradient behind it (475) cannot start on a CU until the optimizer's workgroup there has drained, while the plain 48-register
-    # dd_adam_step does run beside both.  So the rank-B passes must be over when the weight gradient is (~1.2 ms at 32 rows, in which they
-    # move ~4 GB): the registered tensors take the rank-B pass smallest first while their p / m / v bytes fit that budget, the others keep
-    # their materialised gradient and the plain pass.  Config 2: head 1.0 GB + fc1 2.9 GB, both rank-B (7.8 -> 7.6 ms).  Autoencoder:
-    # fc1 2.9 GB rank-B, the decoder's fc2 (3.9 GB) plain -- both rank-B (6.7 GB) left the data gradient waiting 1.6 ms: 11.2 -> 12.4 ms.
-    # (A/B on one box: autoencoder bs 32 with the budget 11.05-11.12 ms, without it 12.10-12.18, no rank-B 11.13-11.41; config 2 with
-    # both tensors inside the budget 7.54-7.58 ms, with fc1 pushed out of it 7.64-7.71.)
-    RANKB_BYTES_PER_ROW = 1.25e8
+    # Beside the backward a rank-B pass needs 72 registers: it fits beside the c2 WEIGHT gradient (440) and beside the small kernels in
+    # front of the conv stack's backward, not beside the fused data gradient (475), which cannot start on a CU until the optimizer's
+    # workgroup there has drained (the plain 48-register dd_adam_step runs beside all of them).  With the passes last (passes_last) there are
+    # two places for a rank-B pass, both sized per batch row (config 2 at 32 rows in brackets):
+    #   * the WINDOW beside the weight gradient (~1.2 ms; a pass moves ~2.5 GB/ms there): the largest registered tensor whose p / m / v
+    #     bytes fit WINDOW_BYTES_PER_ROW (3.2 GB: fc1's 2.9 GB, 1.26 ms);
+    #   * EARLY, on the side stream the moment the factors exist, beside the FC tail's and c3's HBM-bound kernels (~1.5 ms until the data
+    #     gradient is dispatched): the smaller tensors, smallest first, while they fit EARLY_BYTES_PER_ROW (1.6 GB: the head's 1.0 GB, 0.37 ms).
+    # Everything else keeps its materialised gradient and the plain pass.  A/B on one box each (profiles/r05_ab_rankb_schedule.txt): config 2
+    # both in the window 7.40, head early 7.29 ms; autoencoder bs 32 with both of its tensors (6.7 GB) on the pass 12.1 ms -- the data gradient
+    # waited 1.6 ms for them --, fc1 alone 11.0-11.1 (no rank-B: 11.1-11.4); hidden 256: the head rides, fc1 (5.8 GB) stays plain.
+    WINDOW_BYTES_PER_ROW = 1.0e8
+    EARLY_BYTES_PER_ROW = 0.5e8
+
+    def _rankb_plan(self, rows):
+        """{tensor: "window" | "early"} for the registered tensors that take the rank-B pass at this batch size (overlap mode)."""
+        live = sorted((q for q in self._rankb if q.requires_grad), key=lambda q: q.numel())
+        key = (rows, self._last, tuple(id(q) for q in live))
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan
+        cost = lambda q: 24.0 * q.numel()
+        plan = {}
+        fits = [q for q in live if cost(q) <= self.WINDOW_BYTES_PER_ROW * rows]
+        if fits:
+            plan[fits[-1]] = "window"
+        if self._last:
+            budget = self.EARLY_BYTES_PER_ROW * rows
+            for q in live:
+                if q not in plan and q.numel() >= self._big_numel and cost(q) <= budget:
+                    plan[q] = "early"
+                    budget -= cost(q)
+        else:      # passes in front of the weight gradient (no rank-B window of their own): what fits it together, smallest first
+            budget = 1.25 * self.WINDOW_BYTES_PER_ROW * rows
+            plan = {}
+            for q in live:
+                budget -= cost(q)
+                if budget < 0:
+                    break
+                plan[q] = "window"
+        self._plan_key, self._plan = key, plan
+        return plan
 
     def _rankb_fits(self, p, rows):
         if self._side is None:
             return True                                       # passes after the backward, by themselves: no window to fit
-        budget = self.RANKB_BYTES_PER_ROW * rows
-        for q in sorted((q for q in self._rankb if q.requires_grad), key=lambda q: q.numel()):
-            budget -= 24.0 * q.numel()
-            if budget < 0:
-                return False
-            if q is p:
-                return True
-        return False
+        return p in self._rankb_plan(rows)
+
+    def _goes_early(self, p, rows):
+        return self._rankb_plan(rows).get(p) == "early"
 
     def linear_factors(self, weight, x, dy):
         """Called by ``ops.Linear.backward`` (on the backward's stream) for a weight registered in ``ops.RANKB``.  Returns 0: declined,
@@ -130,6 +159,15 @@ class HipAdam(torch.optim.Optimizer):
         else:
             self._queue_rankb(p)
         self._rankb_now[p] = (x, dy, bias)
+        if prev is None and self._side is not None and self._last and self._goes_early(p, x.shape[0]):
+            # the window beside c2's weight gradient belongs to the LARGEST rank-B tensor (it fills it: fc1's pass 1.26 ms beside a 1.21 ms
+            # kernel); a smaller one queued in front of it would push it past the kernel's end.  It goes to the side stream now, beside the
+            # small HBM-bound kernels between here and the conv stack's backward (head: 0.37 ms there; config 2 7.40 -> 7.29 ms, same box)
+            ev = torch.cuda.current_stream().record_event()
+            with torch.no_grad(), torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                self._take_rankb(p, self._group_of(p), self._scale)
+            self._pending = [(q, g) for q, g in self._pending if q is not p]
         return 2 if bias is not None else 1
 
     def factor_bias(self, weight):
