@@ -789,7 +789,7 @@ class Linear(torch.autograd.Function):
         if sync is not None and ctx.needs_input_grad[1] and sync.linear_factors(weight, x, dy):
             # data parallel, factor mode (ddp.GradSync): x and dy travel instead of dW; the optimizer forms the global-batch gradient
             # (rank-B mode of the optimizer: inside its Adam pass, the bias from the gathered dy as well)
-            if ctx.has_bias and ctx.needs_input_grad[2] and not (fused is not None and fused.factor_bias(weight)):
+            if ctx.has_bias and ctx.needs_input_grad[2] and not (fused is not None and fused.factor_bias(weight, sync.world * m)):
                 db = column_sum(dy)
         elif fused is not None and ctx.needs_input_grad[1] and (taken := fused.linear_factors(weight, x, dy)):
             # rank-B mode (optim.HipAdam): no dW at all, dd_adam_step_rankb forms it from (x, dy) inside the optimizer pass

@@ -143,7 +143,7 @@ class HipAdam(torch.optim.Optimizer):
         p = self._rankb_keys.get(weight.data_ptr())
         if p is None or not p.requires_grad or p.grad is not None or self._sync_blocks_rankb():
             return 0
-        if x.shape[0] > 64 or (p not in self._rankb_now and not self._rankb_fits(p, x.shape[0])):
+        if x.shape[0] > self.MAX_ROWS or (p not in self._rankb_now and not self._rankb_fits(p, x.shape[0])):
             return 0
         if not (x.is_contiguous() and dy.is_contiguous() and x.dtype == torch.float32 and dy.dtype == torch.float32):
             return 0
@@ -170,12 +170,14 @@ class HipAdam(torch.optim.Optimizer):
             self._pending = [(q, g) for q, g in self._pending if q is not p]
         return 2 if bias is not None else 1
 
-    def factor_bias(self, weight):
-        """Factor mode of ddp.GradSync: whether the pass over the gathered factors will update this layer's bias too (then the caller
-        owes no bias gradient)."""
+    MAX_ROWS = 64      # dd_adam_step_rankb: batch rows (world x batch for gathered factors)
+
+    def factor_bias(self, weight, rows):
+        """Factor mode of ddp.GradSync: whether the pass over the gathered factors (``rows`` = world x batch of them) will update this
+        layer's bias too (then the caller owes no bias gradient)."""
         p = self._rankb_keys.get(weight.data_ptr())
         bias = self._rankb.get(p) if p is not None else None
-        return bias is not None and bias.requires_grad and bias.grad is None and not self._sync_blocks_rankb()
+        return (bias is not None and bias.requires_grad and bias.grad is None and rows <= self.MAX_ROWS and not self._sync_blocks_rankb())
 
     def _queue_rankb(self, p):
         if self._side is not None and p.numel() >= self._big_numel:
@@ -228,7 +230,7 @@ class HipAdam(torch.optim.Optimizer):
             return False
         for work in fac.works:
             work.wait()
-        if p in self._rankb:      # rank-B mode: no gradient tensor at all, the gathered factors go straight into the Adam pass
+        if p in self._rankb and fac.rows <= self.MAX_ROWS:      # rank-B mode: no gradient tensor, the gathered factors go straight into the Adam pass
             self._fac_now[p] = fac
             return True
         g = self._fgrad.get(p)

@@ -294,3 +294,39 @@ def test_spatial_mapping_cnn_fused_strips_equal_the_generic_engine(dev):
     assert float((ya - yb).abs().max()) <= 2e-6 * float(yb.abs().max())
     for k in gb:
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * float(gb[k].abs().max()), k
+
+
+def test_factor_mode_over_64_gathered_rows_falls_back_to_the_materialised_gradient(dev):
+    """dd_adam_step_rankb takes at most 64 rows.  In ddp.GradSync factor mode the rows are world x batch: past 64 the optimizer forms the
+    gathered gradient with dd_linear_wgrad as in round 4, and ``factor_bias`` tells ops.Linear.backward that the bias gradient is still
+    owed (a stub stands in for the GradSync: the decision and the fallback are the optimizer's)."""
+    from driving_dirty_amd import ddp
+    from driving_dirty_amd.optim import HipAdam
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(64, 4096).to(dev)
+    ref = torch.nn.Linear(64, 4096).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    opt = HipAdam(lin.parameters(), lr=1e-2)
+    assert len(opt.fuse_linear_wgrad(lin, min_numel=1024)) == 1
+    rows = 80
+    x, dy = torch.rand(rows, 64, device=dev), torch.rand(rows, 4096, device=dev) - 0.5
+
+    class Stub:
+        factor, active, shard = True, True, False
+
+        def take_factors(self, p):
+            return ddp.Factors([], x, dy, rows)
+
+        def has_factors(self, p):
+            return False
+    opt._sync = Stub()
+    assert opt.factor_bias(lin.weight, 64) and not opt.factor_bias(lin.weight, rows)
+    assert opt._update_factored(lin.weight, opt.param_groups[0], 0.5)
+    assert lin.weight.grad is not None                         # the materialised path
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    ref.weight.grad = (dy.t() @ x) * 0.5
+    ref.bias.grad = torch.zeros_like(ref.bias)
+    ropt.step()
+    assert float((lin.weight - ref.weight).abs().max() / ref.weight.abs().max()) <= 1e-6
+    opt._sync = None
+    opt.close()
