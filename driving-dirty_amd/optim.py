@@ -92,13 +92,15 @@ class HipAdam(torch.optim.Optimizer):
     # two places for a rank-B pass, both sized per batch row (config 2 at 32 rows in brackets):
     #   * the WINDOW beside the weight gradient (~1.2 ms; a pass moves ~2.5 GB/ms there): the largest registered tensor whose p / m / v
     #     bytes fit WINDOW_BYTES_PER_ROW (3.2 GB: fc1's 2.9 GB, 1.26 ms);
-    #   * EARLY, on the side stream the moment the factors exist, beside the FC tail's and c3's HBM-bound kernels (~1.5 ms until the data
-    #     gradient is dispatched): the smaller tensors, smallest first, while they fit EARLY_BYTES_PER_ROW (1.6 GB: the head's 1.0 GB, 0.37 ms).
+    #   * EARLY, on the side stream the moment the factors exist, beside the FC tail's and c3's HBM-bound kernels (1.5-2 ms until the data
+    #     gradient is dispatched): the other tensors, smallest first, while they fit EARLY_BYTES_PER_ROW (4 GB: the head's 1.0 GB, 0.37 ms
+    #     there; the autoencoder's decoder fc2, 3.9 GB, whose factors exist before the encoder's backward starts: 11.17 -> 10.96 ms).
     # Everything else keeps its materialised gradient and the plain pass.  A/B on one box each (profiles/r05_ab_rankb_schedule.txt): config 2
-    # both in the window 7.40, head early 7.29 ms; autoencoder bs 32 with both of its tensors (6.7 GB) on the pass 12.1 ms -- the data gradient
-    # waited 1.6 ms for them --, fc1 alone 11.0-11.1 (no rank-B: 11.1-11.4); hidden 256: the head rides, fc1 (5.8 GB) stays plain.
+    # both in the window 7.40, head early 7.29 ms; autoencoder bs 32 with both of its tensors (6.7 GB) queued for the window 12.1 ms -- the data
+    # gradient waited 1.6 ms for them --, fc1 in the window and the decoder's fc2 plain 11.0-11.2, fc2 early 10.9-11.0 (no rank-B: 11.1-11.4);
+    # hidden 256: the head rides, fc1 (5.8 GB) stays plain.
     WINDOW_BYTES_PER_ROW = 1.0e8
-    EARLY_BYTES_PER_ROW = 0.5e8
+    EARLY_BYTES_PER_ROW = 1.25e8
 
     def _rankb_plan(self, rows):
         """{tensor: "window" | "early"} for the registered tensors that take the rank-B pass at this batch size (overlap mode)."""
