@@ -189,7 +189,11 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
           // the patch row fetched during this tap row: row ky of the next chunk, or (last chunk) a row of the next task's chunk 0
           const int nky = nxt.ky0 + (ky - ky0);
           const bool st_next = !more && have_next && nky <= nxt.ky1;
+#ifdef TF_ABL_NOFILL      // ablation builds (tools/build_variant.sh; results are then wrong): no patch fills at all
+          const bool st = false;
+#else
           const bool st = more || st_next;
+#endif
           const int srow = more ? ky : nky;
           f32x4 stage[G::NPR];
           if (st) {
@@ -197,7 +201,11 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
             const __amdgpu_buffer_rsrc_t rs = more ? xs : xn;
 #pragma unroll
             for (int i = 0; i < G::NPR; ++i)
+#ifdef TF_ABL_CHUNKMAJOR      // ablation: the addresses a chunk-major image [row][chunk][pixel][8] would have (whole lines, one contiguous run)
+              stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + TF_THREADS * i) * 16 + rowoff, (more ? q + 1 : 0) * d.in_w * 32, 0));
+#else
               stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[i] + rowoff, more ? 32 * (q + 1) : 0, 0));
+#endif
           }
           for (int rep = 1; rep < dbg_repeat; ++rep) {      // DD_DCONV_REPEAT: timing diagnostic only (results are then wrong)
 #pragma unroll
@@ -228,7 +236,9 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
               acc[i] = DD_MFMA(Af[i % AR].y, Bf[i].y, acc[i]);
               acc[i] = DD_MFMA(Af[i % AR].z, Bf[i].z, acc[i]);
               acc[i] = DD_MFMA(Af[i % AR].w, Bf[i].w, acc[i]);
+#ifndef TF_ABL_NOB      // ablation: weight fragments loaded once
               bload(i, qn, kyn, ntn);
+#endif
               Af[i % AR] = *(const frag*)(lbase + aoff[(i + AR) % NSLOT] + (i + AR < NSLOT ? ky : kya) * (G::ROWF * 4));
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -272,8 +282,13 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
     {
       if (tid < G::HALO * (P / 4)) *(f32x4*)&img[n_mt * TW * P + tid * 4] = f32x4{0.f, 0.f, 0.f, 0.f};
       static_assert(G::HALO * (P / 4) <= TF_THREADS, "one zeroing store per thread");
+#ifdef TF_ABL_NOEPI      // ablation: one pass of the K
+#pragma unroll
+      for (int pass = K - 1; pass >= K - 1; --pass) {
+#else
 #pragma unroll
       for (int pass = K - 1; pass >= 0; --pass) {
+#endif
         const int shift = D * (K - 1 - pass);                // = pad_w - D*pass (the launcher checked pad_w)
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {

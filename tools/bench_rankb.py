@@ -12,8 +12,10 @@ from driving_dirty_amd import ops  # noqa: E402
 from tools.bench_kernels import timeit  # noqa: E402
 
 dev = torch.device("cuda:0")
-shapes = {"fc1": (128, 940032), "head": (640000, 64), "dec_fc2": (1253376, 128)}
+shapes = {"fc1": (128, 940032), "head": (640000, 64), "dec_fc2": (1253376, 128), "fc1_2x": (128, 4080128)}      # fc1_2x: config 5 (ROWS=16)
 rows = int(os.environ.get("ROWS", "32"))
+if os.environ.get("BLOCKS"):      # persistent workgroups per CU of the optimizer kernels (TrainStep: 1 beside the backward, 4 after it)
+    ops.check(ops._lib.lib().dd_set_adam_blocks_per_cu(int(os.environ["BLOCKS"])), "dd_set_adam_blocks_per_cu")
 for name, (n, k) in shapes.items():
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
