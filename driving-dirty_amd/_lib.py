@@ -45,6 +45,7 @@ SIGNATURES = {
     "dd_clock_probe": (_i32, [_p, _i32, _i32, _p]),
     "dd_set_cu_budget": (_i32, [_i32]),
     "dd_set_adam_blocks_per_cu": (_i32, [_i32]),
+    "dd_set_adam_spare_cus": (_i32, [_i32]),
     "dd_get_cu_budget": (_i32, []),
     "dd_stitch6": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_stitch6_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _p]),

@@ -308,7 +308,7 @@ int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const floa
   a.total = (int)total;
   // one persistent workgroup per CU, as dd_adam_step (dense.hip): nothing of this launch is ever queued ahead of a conv kernel
   const int per_cu = dd_adam_blocks_internal();
-  const int grid = (int)min(total, (long)DD_NUM_CU * per_cu);
+  const int grid = (int)min(total, (long)max(DD_NUM_CU - dd_adam_spare_internal(), 1) * per_cu);
   a.per = (int)((total + grid - 1) / grid);
   hipStream_t st = (hipStream_t)stream;
   // (two k-tiles per group -- the decoder's fc2, K = 128 -- ran on a <2, RG = 1> build of the short form (its RG = 2 build needs 76 registers):

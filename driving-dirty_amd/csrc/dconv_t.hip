@@ -51,6 +51,7 @@ struct TfGeom {
 // kernel reads from global memory is written by it, so only the LDS patch / row image need the ordering.
 __device__ __forceinline__ void tf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
 struct TfTask {
   int b, nt, oy, ry, ky0, ky1;
 };
@@ -294,10 +295,20 @@ __global__ __launch_bounds__(TF_THREADS) void dconv_tfwd_kernel(const float* __r
         for (int i = 0; i < NSLOT; ++i) {
           if (ONE_MT ? (i == pass && s_ok[i]) : (s_ok[i] && s_kx[i] == pass)) {
             float* p0 = img + ioff_lane + s_mt[i] * (TW * P);
+            // (pass < K - 1: all 16 reads, then all 16 adds and writes -- written as `*pe += acc` the compiler made eight serial
+            // ds_read2 -> s_waitcnt -> v_add -> ds_write2 round trips of it, ~2000 cycles per pass with every wave of the CU waiting;
+            // the registers of the tiles stored in earlier passes are free by now.  ds_add_f32, the LDS unit's own float add, is far
+            // slower still: up_conv_1's forward 9.6 -> 13.8 ms)
+            float t[NE];
+            if (pass != K - 1) {
+#pragma unroll
+              for (int e = 0; e < NE; ++e) t[e] = p0[((e & 3) + 8 * (e >> 2) + shift) * P];
+              __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
               float* pe = p0 + ((e & 3) + 8 * (e >> 2) + shift) * P;
-              if (pass == K - 1) *pe = acc[i][e]; else *pe += acc[i][e];
+              *pe = pass == K - 1 ? acc[i][e] : t[e] + acc[i][e];
             }
           }
         }

@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int dd_fail(int code, const char* fmt, ...);
 int dd_adam_blocks_internal();  // persistent workgroups per CU of dd_adam_step / dd_adam_step_rankb: dd_set_adam_blocks_per_cu
+int dd_adam_spare_internal();   // compute units dd_adam_step_rankb leaves free of its workgroups: dd_set_adam_spare_cus
 int dd_cu_budget_internal();   // compute units the resident-grid (persistent) kernels may fill: dd_set_cu_budget
 
 #define DD_REQUIRE(cond, code, ...)            \

@@ -17,8 +17,10 @@ int dd_fail(int code, const char* fmt, ...) {
 
 static int g_cu_budget = DD_NUM_CU;
 static int g_adam_blocks = 1;      // persistent workgroups per CU of the optimizer kernels (dd_set_adam_blocks_per_cu)
+static int g_adam_spare = 0;       // compute units dd_adam_step_rankb leaves without a workgroup of its own (dd_set_adam_spare_cus)
 
 int dd_adam_blocks_internal() { return g_adam_blocks; }
+int dd_adam_spare_internal() { return g_adam_spare; }
 int dd_cu_budget_internal() { return g_cu_budget; }
 
 // One wave that samples the shader-clock counter (s_memtime: counts at the clock the CUs actually run at) against the constant
@@ -53,6 +55,12 @@ int dd_get_cu_budget(void) { return g_cu_budget; }
 int dd_set_adam_blocks_per_cu(int32_t blocks) {
   DD_REQUIRE(blocks >= 1 && blocks <= 8, DD_ERR_BAD_ARG, "set_adam_blocks_per_cu: %d not in 1..8", blocks);
   g_adam_blocks = blocks;
+  return 0;
+}
+int dd_set_adam_spare_cus(int32_t compute_units) {
+  DD_REQUIRE(compute_units >= 0 && compute_units <= DD_NUM_CU / 2, DD_ERR_BAD_ARG, "set_adam_spare_cus: %d not in 0..%d", compute_units,
+             DD_NUM_CU / 2);
+  g_adam_spare = compute_units;
   return 0;
 }
 const char* dd_last_error(void) { return g_err; }

@@ -165,14 +165,23 @@ class HipAdam(torch.optim.Optimizer):
             # the window beside c2's weight gradient belongs to the LARGEST rank-B tensor (it fills it: fc1's pass 1.26 ms beside a 1.21 ms
             # kernel); a smaller one queued in front of it would push it past the kernel's end.  It goes to the side stream now, beside the
             # small HBM-bound kernels between here and the conv stack's backward (head: 0.37 ms there; config 2 7.40 -> 7.29 ms, same box)
+            # One CU per XCD stays free of the pass: a single-workgroup kernel of the backward that needs nearly a whole CU's LDS
+            # (dd_mlp_tail_bwd, 154 KB) cannot start beside a workgroup of the pass (16 KB) and, with one on every CU, waited for the first
+            # of them to retire -- 0.6 ms of the autoencoder's step, whose decoder fc2 pass (1.0 ms) is in flight when the encoder's FC tail
+            # comes up (profiles/r05_ae_bs32_kernel_stats.csv: mlp_tail_bwd 626 us there, 40 us by itself)
             ev = torch.cuda.current_stream().record_event()
             with torch.no_grad(), torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
-                self._take_rankb(p, self._group_of(p), self._scale)
+                ops.check(ops._lib.lib().dd_set_adam_spare_cus(self.EARLY_SPARE_CUS), "dd_set_adam_spare_cus")
+                try:
+                    self._take_rankb(p, self._group_of(p), self._scale)
+                finally:
+                    ops.check(ops._lib.lib().dd_set_adam_spare_cus(0), "dd_set_adam_spare_cus")
             self._pending = [(q, g) for q, g in self._pending if q is not p]
         return 2 if bias is not None else 1
 
     MAX_ROWS = 64      # dd_adam_step_rankb: batch rows (world x batch for gathered factors)
+    EARLY_SPARE_CUS = 8      # CUs an "early" pass leaves free of its workgroups (dd_set_adam_spare_cus)
 
     def factor_bias(self, weight, rows):
         """Factor mode of ddp.GradSync: whether the pass over the gathered factors (``rows`` = world x batch of them) will update this

@@ -76,6 +76,12 @@ int dd_get_cu_budget(void);
  * whole pass to drain; FOUR when it runs by itself (bf16 models: nothing MFMA-bound to hide under), where more workgroups in flight
  * stream faster.  Process-wide, read at launch; never changes results (the update is elementwise). */
 int dd_set_adam_blocks_per_cu(int32_t blocks);
+/* Compute units dd_adam_step_rankb leaves WITHOUT a workgroup of its own (0..128, default 0; the grid shrinks by that many workgroups per
+ * dd_set_adam_blocks_per_cu).  A pass that runs beside the backward from the moment its factors exist (optim.HipAdam's "early" slot)
+ * holds 16-24 KB of LDS on every CU for a millisecond: a single-workgroup kernel of the backward that needs nearly the whole LDS
+ * (dd_mlp_tail_bwd: 154 KB) then waits for the first workgroup of the pass to retire -- the autoencoder's step lost 0.6 ms there.
+ * With 8 spare units such kernels start at once.  Process-wide, read at launch; never changes results. */
+int dd_set_adam_spare_cus(int32_t compute_units);
 
 /* ---- layout: 6-view gather (K4) --------------------------------------------------
  * views [B,6,3,H,W] fp32 -> wide NHWC4 image [B,H,6W,4] with the reference's view order

@@ -87,6 +87,29 @@ def test_adam_rankb_refuses_bad_arguments(dev):
                             1e-3, 0.9, 0.999, 1e-8, 1)
 
 
+def test_adam_rankb_spare_compute_units_change_the_grid_not_the_result(dev):
+    """dd_set_adam_spare_cus: the pass launches that many fewer workgroups per dd_set_adam_blocks_per_cu (HipAdam's early slot leaves one
+    CU per XCD to single-workgroup kernels of the backward); every element takes the same arithmetic whichever workgroup owns it."""
+    from driving_dirty_amd import _lib, ops
+    lib = _lib.lib()
+    torch.manual_seed(5)
+    n, k, rows = 1024, 2052, 32                                 # 256 row groups x 2 k-tiles... more tiles than workgroups either way
+    p0 = torch.randn(n, k, device=dev) * 0.02
+    x, dy = torch.randn(rows, k, device=dev), torch.randn(rows, n, device=dev) * 1e-2
+    outs = []
+    for spare in (0, 8, 128):
+        assert lib.dd_set_adam_spare_cus(spare) == 0
+        try:
+            p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+            ops.adam_step_rankb(p, m, v, dy, x, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 1)
+            outs.append((p, m, v))
+        finally:
+            assert lib.dd_set_adam_spare_cus(0) == 0
+    for p, m, v in outs[1:]:
+        assert torch.equal(p, outs[0][0]) and torch.equal(m, outs[0][1]) and torch.equal(v, outs[0][2])
+    assert lib.dd_set_adam_spare_cus(-1) != 0 and lib.dd_set_adam_spare_cus(129) != 0
+
+
 def test_column_sum_matches_fp64(dev):
     from driving_dirty_amd import ops
     for m, n in ((32, 640), (7, 50), (3, 1027)):

@@ -12,8 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from driving_dirty_amd.autoencoder import BasicAE  # noqa: E402
 from driving_dirty_amd.train import TrainStep  # noqa: E402
 
+from driving_dirty_amd.optim import HipAdam  # noqa: E402
+
 dev = torch.device("cuda:0")
 b = int(os.environ.get("BATCH", "32"))
+if os.environ.get("SPARE"):      # CUs the early rank-B pass leaves free (A/B of HipAdam.EARLY_SPARE_CUS)
+    HipAdam.EARLY_SPARE_CUS = int(os.environ["SPARE"])
 for rep in range(2):
     for fuse in (False, True):
         torch.manual_seed(20200505)
