@@ -178,6 +178,9 @@ SIGNATURES = {
     "dd_conv_bf16_wgrad": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     "dd_pool4_bf16_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_relu_bf16_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_pool4_bf16_idx_elems": (_i64, [_i32, _i32, _i32, _i32]),
+    "dd_pool4_bf16_fwd_idx": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_pool4_idx_relu_bf16_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
     "dd_bf16_to_f32": (_i32, [_p, _p, _i64, _p]),
     "dd_adam_step": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _p]),

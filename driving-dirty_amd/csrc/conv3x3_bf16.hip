@@ -41,11 +41,20 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(f
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
-__device__ __forceinline__ u32x2 bload2(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+// Output streams carry the non-temporal hint (aux bit 1), as in conv3x3.hip; input streams carry it in the weight-gradient kernels only.
+// A/B/A/B on one box, bs 16, 512 x 3672 (tools/ab_libs.sh over tools/bench_bf16.py): stores -- c1 forward 0.69 -> 0.59 ms, c2 forward
+// 0.99 -> 0.87, c2 data gradient 0.89 -> 0.86; loads on top of that -- c3 / c1 / c2 weight gradient 0.43 -> 0.39, 0.44 -> 0.40, 0.79 -> 0.78,
+// but c1 forward 0.45 -> 0.51 (its 8-byte pixels are re-read by the neighbouring strips), the others unchanged.  Not on the pool forward's
+// stores: its 32-byte pieces want to be merged in the L2 first (0.21 -> 0.41 ms with the hint).
+constexpr int BF_NT = 2;
+template <int AUX = 0>
+__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX); }
+template <int AUX = 0>
+__device__ __forceinline__ u32x2 bload2(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX); }
 __device__ __forceinline__ unsigned bload1(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
-__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, int off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0); }
-__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0); }
+constexpr int BF_ST = BF_NT;
+__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, int off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, BF_ST); }
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, BF_ST); }
 
 // LDS geometry of one wave.  CIN == 32: 64-byte pixels in 16-byte chunks of 8 channels; CIN == 4 (3 real channels):
 // 8-byte pixels, one "chunk" per pixel.
@@ -73,7 +82,7 @@ struct RowRegs<4> { typedef u32x2 T; };
 // chunk swizzle for the ds_read_b128 of 16 consecutive pixels (64-byte pitch): pixels p and p+4 would share banks
 __device__ __forceinline__ int swz(int q) { return (q >> 2) & 3; }
 
-template <int CIN, int S>
+template <int CIN, int S, int AUX = 0>
 __device__ __forceinline__ void load_row(const unsigned short* __restrict__ img, int H, int W, int iy, int gx0, int lane,
                                          typename RowRegs<CIN>::T (&r)[BCfg<CIN, S>::NLOAD]) {
   using C = BCfg<CIN, S>;
@@ -84,8 +93,8 @@ __device__ __forceinline__ void load_row(const unsigned short* __restrict__ img,
     const int c = lane + 64 * i;
     const int q = c / C::CHUNKS, ch = c % C::CHUNKS;
     const int off = (c < C::NCH) ? ((gx0 + q) * C::PXB + ch * C::CHB) : -16;      // negative pixel -> huge offset -> zeros
-    if constexpr (CIN == 32) r[i] = bload4(rs, off);
-    else r[i] = bload2(rs, off);
+    if constexpr (CIN == 32) r[i] = bload4<AUX>(rs, off);
+    else r[i] = bload2<AUX>(rs, off);
   }
 }
 
@@ -136,7 +145,7 @@ __device__ __forceinline__ void flush_tile(const char* tile, __amdgpu_buffer_rsr
     const int c = 64 * k + lane;
     const int pix = c >> 2, q = c & 3;
     const u32x4 v = *(const u32x4*)(tile + pix * 64 + ((q ^ stage_swz(pix)) << 4));
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, base_off + c * 16, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, base_off + c * 16, 0, BF_ST);
   }
 }
 
@@ -191,7 +200,11 @@ __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* _
     const int y1 = (int)min((long)Ho, y0 + (end - idx));
     idx += y1 - y0;
     const int b = (int)(col / nstrips), x0 = (int)(col % nstrips) * 32;
+#ifdef BF_ABL_NOREAD      // ablation builds (tools/build_variant.sh; wrong results): every image reads image 0 (cache-resident input)
+    const unsigned short* xb = x;
+#else
     const unsigned short* xb = x + (long)b * H * W * CIN;
+#endif
     const int gx0 = S * x0 - 1;
 
     // group(t): the input rows output row t+1 adds to the window, and the sign word of output row t
@@ -263,7 +276,11 @@ __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* _
         store_row<CIN, S, true>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, cur.rows[s2]);
       }
 
+#ifdef BF_ABL_NOSTORE     // ablation: the output row goes to a zero-size descriptor (issued, counted, dropped)
+      const bool live = false;
+#else
       const bool live = t < y1;                 // the second half of the last pair may be a dummy row: stores dropped
+#endif
       const long opix = (long)(b * Ho + (live ? t : 0)) * Wo;
       const __amdgpu_buffer_rsrc_t ys = rsrc(y + opix * 32, live ? Wo * 64 : 0);
       float v[16];
@@ -281,7 +298,11 @@ __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* _
       flush_tile<32>(tile, ys, x0 * 64, lane);
       if (EPI == 0) {   // the two half-waves hold the two 16-channel halves of pixel n's word
         const unsigned word = mine | (unsigned)__shfl_xor((int)mine, 32);
+#ifdef BF_ABL_NOBITS      // ablation: no sign words written
+        const bool want = false;
+#else
         const bool want = live && bits_out != nullptr;
+#endif
         const __amdgpu_buffer_rsrc_t bs = rsrc(want ? bits_out + opix : (unsigned*)y, want ? Wo * 4 : 0);
         bstore1(bs, (h == 0) ? (x0 + n) * 4 : -16, word);
       }
@@ -303,8 +324,8 @@ __global__ __launch_bounds__(WPB * 64) void bf_strip_fwd(const unsigned short* _
     {   // mirror the loop body's stores so that the loop header sees the same queue from both predecessors
       const __amdgpu_buffer_rsrc_t none = rsrc(y, 0);
       const u32x4 z = {0u, 0u, 0u, 0u};
-      __builtin_amdgcn_raw_buffer_store_b128(z, none, lane * 16, 0, 0);          // distinct offsets: two stores, not one
-      __builtin_amdgcn_raw_buffer_store_b128(z, none, 1024 + lane * 16, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(z, none, lane * 16, 0, BF_ST);          // distinct offsets: two stores, not one
+      __builtin_amdgcn_raw_buffer_store_b128(z, none, 1024 + lane * 16, 0, BF_ST);
       if (EPI == 0) bstore1(none, lane * 4, 0u);
     }
     asm volatile("" ::: "memory");
@@ -480,26 +501,26 @@ __global__ __launch_bounds__(WPB * 64) void bf_wgrad(const unsigned short* __res
     for (int d = 0; d < 3; ++d) {
       R t[C::NLOAD];
       const int iy = S * y0 - 1 + d;
-      load_row<CIN, S>(xb, H, W, iy, gx0, lane, t);
+      load_row<CIN, S, BF_NT>(xb, H, W, iy, gx0, lane, t);
       store_row<CIN, S, false>(ring + ((iy + 1) % 3) * C::SLOTB, spill, lane, t);
     }
     u32x4 dcur[2];
     {
       const __amdgpu_buffer_rsrc_t ds = rsrc(dyb + (long)y0 * Wo * 32, Wo * 64);
-      dcur[0] = bload4(ds, doff);
-      dcur[1] = bload4(ds, doff + 1024);
+      dcur[0] = bload4<BF_NT>(ds, doff);
+      dcur[1] = bload4<BF_NT>(ds, doff + 1024);
     }
 
     for (int yy = y0; yy < y1; ++yy) {
       R pre[S][C::NLOAD];
 #pragma unroll
-      for (int s = 0; s < S; ++s) load_row<CIN, S>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
+      for (int s = 0; s < S; ++s) load_row<CIN, S, BF_NT>(xb, H, W, S * yy + 2 + s, gx0, lane, pre[s]);
       u32x4 dnext[2];
       {
         const bool ok = yy + 1 < Ho;
         const __amdgpu_buffer_rsrc_t ds = rsrc(dyb + (long)(ok ? yy + 1 : 0) * Wo * 32, ok ? Wo * 64 : 0);
-        dnext[0] = bload4(ds, doff);
-        dnext[1] = bload4(ds, doff + 1024);
+        dnext[0] = bload4<BF_NT>(ds, doff);
+        dnext[1] = bload4<BF_NT>(ds, doff + 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
 
@@ -713,7 +734,7 @@ __global__ __launch_bounds__(256) void pool4_bf16_fwd(const u32x2* __restrict__ 
     float m[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const u32x2 v = src[(long)k * groups];
+      const u32x2 v = __builtin_nontemporal_load(src + (long)k * groups);
       const float f[4] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y)};
 #pragma unroll
       for (int c = 0; c < 4; ++c) m[c] = (k == 0) ? f[c] : fmaxf(m[c], f[c]);
@@ -739,7 +760,7 @@ __global__ __launch_bounds__(256) void pool4_bf16_bwd(const float* __restrict__ 
     float f[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const u32x2 v = feat[base + (long)k * groups];
+      const u32x2 v = __builtin_nontemporal_load(feat + base + (long)k * groups);
       f[k][0] = bf_lo(v.x); f[k][1] = bf_hi(v.x); f[k][2] = bf_lo(v.y); f[k][3] = bf_hi(v.y);
     }
     const float* gp = dpooled + b * (quads * C) + qd;
@@ -761,8 +782,94 @@ __global__ __launch_bounds__(256) void pool4_bf16_bwd(const float* __restrict__ 
       u32x2 o;
       o.x = pack_bf16(d[k][0], d[k][1]);
       o.y = pack_bf16(d[k][2], d[k][3]);
-      dfeat[base + (long)k * groups] = o;
+      __builtin_nontemporal_store(o, dfeat + base + (long)k * groups);
     }
+  }
+}
+
+// ---- the same pool for C = 32 in tiles of 64 windows, with the backward's routing codes (the fp32 path's pool4_fwd_quad<true> /
+// pool4_bwd_idx_quad, layout_pool.hip: 4 bits per window = first maximum | (max > 0) << 2, one 16-bit word per (window, 4 channels)).
+// A workgroup owns 64 consecutive windows (256 pixels, 16 KB of bf16) of one image.  Forward: thread = (window, 8 channels), four 16-byte
+// loads; the 32 x 64 maxima go through LDS so that every channel plane receives 256 contiguous bytes (one thread per (window, 4
+// channels) wrote 32-byte pieces: 3.4 TB/s).  Backward: the gradient tile [32][64] and the codes come in through LDS the same way and the
+// 256 pixels leave as one contiguous 16 KB run of whole lines; the 0.48 GB feature is not read again (30 MB of codes instead).
+__global__ __launch_bounds__(256) void pool4_bf16_fwd_tile(const u32x4* __restrict__ feat, float* __restrict__ pooled,
+                                                           unsigned* __restrict__ idx, long quads, int qblocks) {
+  __shared__ float t[32][65];
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x / qblocks;
+  const long q0 = (long)(blockIdx.x - b * qblocks) * 64;
+  const int nq = (int)min(64L, quads - q0);
+  const int q = tid >> 2, c8 = tid & 3;
+  if (q < nq) {
+    const u32x4* src = feat + ((b * quads + q0 + q) * 4) * 4 + c8;      // pixel 4(q0 + q), chunk c8; a pixel is 4 chunks of 16 bytes
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(src + 4 * k);
+    unsigned codes = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned w = v[k][j >> 1];
+        f[k] = (j & 1) ? bf_hi(w) : bf_lo(w);
+      }
+      float m = f[0];
+      unsigned am = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (f[k] > m) { m = f[k]; am = k; }
+      t[8 * c8 + j][q] = m;
+      codes |= (am | (m > 0.f ? 4u : 0u)) << (4 * j);
+    }
+    if (idx) idx[(b * quads + q0 + q) * 4 + c8] = codes;      // two 16-bit words: channel groups 2 c8 and 2 c8 + 1
+  }
+  __syncthreads();
+  float* o = pooled + b * (quads * 32) + q0;
+  const int qq = tid & 63;
+  if (qq < nq) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (tid >> 6) + 4 * j;
+      o[(long)c * quads + qq] = t[c][qq];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool4_bf16_bwd_tile(const float* __restrict__ dpooled, const unsigned* __restrict__ idx,
+                                                           u32x4* __restrict__ dfeat, long quads, int qblocks) {
+  __shared__ float g[32][65];
+  __shared__ unsigned cd[64][4];
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x / qblocks;
+  const long q0 = (long)(blockIdx.x - b * qblocks) * 64;
+  const int nq = (int)min(64L, quads - q0);
+  const float* gp = dpooled + b * (quads * 32) + q0;
+  const int qq = tid & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = (tid >> 6) + 4 * j;
+    g[c][qq] = qq < nq ? gp[(long)c * quads + qq] : 0.f;
+  }
+  cd[tid >> 2][tid & 3] = (tid >> 2) < nq ? idx[(b * quads + q0) * 4 + tid] : 0u;
+  __syncthreads();
+  u32x4* out = dfeat + (b * quads + q0) * 16;      // 16 chunks of 16 bytes per window
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + 256 * k;                   // chunk i of the tile: pixel i >> 2, channels 8 (i & 3) ..
+    const int px = i >> 2, c8 = i & 3, qd = px >> 2, pos = px & 3;
+    if (qd >= nq) continue;
+    const unsigned codes = cd[qd][c8];
+    float d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned c4 = (codes >> (4 * j)) & 15u;
+      d[j] = ((c4 & 4u) && (c4 & 3u) == (unsigned)pos) ? g[8 * c8 + j][qd] : 0.f;
+    }
+    u32x4 o;
+    o.x = pack_bf16(d[0], d[1]); o.y = pack_bf16(d[2], d[3]); o.z = pack_bf16(d[4], d[5]); o.w = pack_bf16(d[6], d[7]);
+    __builtin_nontemporal_store(o, out + i);
   }
 }
 
@@ -1023,6 +1130,41 @@ int dd_pool4_relu_bf16_bwd(const float* dpooled, const uint16_t* feat, uint16_t*
   hipLaunchKernelGGL(pool4_bf16_bwd, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 8)), dim3(256), 0, (hipStream_t)stream,
                      dpooled, (const u32x2*)feat, (u32x2*)dfeat, batch, (long)h * w, c);
   DD_LAUNCH_CHECK("pool4_bf16_bwd");
+  return 0;
+}
+
+int64_t dd_pool4_bf16_idx_elems(int32_t batch, int32_t h, int32_t w, int32_t c) {
+  const long HW = (long)h * w;
+  if (batch <= 0 || h <= 0 || w <= 0 || c != 32 || HW % 4 != 0) {
+    dd_fail(DD_ERR_UNSUPPORTED, "pool4_bf16_idx: needs C == 32 and H*W %% 4 == 0, got %d x %d x %d", h, w, c);
+    return -1;
+  }
+  return (long)batch * (HW / 4) * (c / 4);
+}
+
+int dd_pool4_bf16_fwd_idx(const uint16_t* feat, float* pooled, uint16_t* idx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                          void* stream) {
+  DD_REQUIRE(feat && pooled && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "pool4_bf16_fwd_idx: bad argument");
+  DD_REQUIRE(c == 32 && ((long)h * w) % 4 == 0, DD_ERR_UNSUPPORTED, "pool4_bf16_fwd_idx: needs C == 32 and H*W %% 4 == 0 (got %dx%d, C %d)", h, w, c);
+  DD_REQUIRE(((uintptr_t)feat & 15) == 0 && ((uintptr_t)idx & 3) == 0, DD_ERR_BAD_ARG, "pool4_bf16_fwd_idx: feat must be 16-byte, idx 4-byte aligned");
+  const long quads = (long)h * w / 4, qblocks = (quads + 63) / 64;
+  DD_REQUIRE(batch * qblocks < (1L << 31), DD_ERR_UNSUPPORTED, "pool4_bf16_fwd_idx: too many tiles");
+  hipLaunchKernelGGL(pool4_bf16_fwd_tile, dim3((unsigned)(batch * qblocks)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)feat, pooled,
+                     (unsigned*)idx, quads, (int)qblocks);
+  DD_LAUNCH_CHECK("pool4_bf16_fwd_idx");
+  return 0;
+}
+
+int dd_pool4_idx_relu_bf16_bwd(const float* dpooled, const uint16_t* idx, uint16_t* dfeat, int32_t batch, int32_t h, int32_t w,
+                               int32_t c, void* stream) {
+  DD_REQUIRE(dpooled && idx && dfeat && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "pool4_idx_relu_bf16_bwd: bad argument");
+  DD_REQUIRE(c == 32 && ((long)h * w) % 4 == 0, DD_ERR_UNSUPPORTED, "pool4_idx_relu_bf16_bwd: needs C == 32 and H*W %% 4 == 0 (got %dx%d, C %d)", h, w, c);
+  DD_REQUIRE(((uintptr_t)dfeat & 15) == 0 && ((uintptr_t)idx & 3) == 0, DD_ERR_BAD_ARG, "pool4_idx_relu_bf16_bwd: dfeat must be 16-byte, idx 4-byte aligned");
+  const long quads = (long)h * w / 4, qblocks = (quads + 63) / 64;
+  DD_REQUIRE(batch * qblocks < (1L << 31), DD_ERR_UNSUPPORTED, "pool4_idx_relu_bf16_bwd: too many tiles");
+  hipLaunchKernelGGL(pool4_bf16_bwd_tile, dim3((unsigned)(batch * qblocks)), dim3(256), 0, (hipStream_t)stream, dpooled, (const unsigned*)idx,
+                     (u32x4*)dfeat, quads, (int)qblocks);
+  DD_LAUNCH_CHECK("pool4_idx_relu_bf16_bwd");
   return 0;
 }
 

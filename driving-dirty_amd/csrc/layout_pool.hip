@@ -230,6 +230,86 @@ __global__ __launch_bounds__(256) void pool4_bwd_idx_quad(const float* __restric
   }
 }
 
+// ---- C == 32: the same two kernels in tiles of 64 windows (256 pixels = 32 KB of one image) that go through LDS, so that BOTH sides of the
+// NHWC <-> NCHW-flat change of order move in whole lines: above, a wave's stores into a channel plane (forward) and its loads from one
+// (backward) are 32-byte pieces.  Same codes, same results bit for bit.
+__global__ __launch_bounds__(256) void pool4_fwd_tile32(const f32x4* __restrict__ feat, float* __restrict__ pooled,
+                                                        unsigned* __restrict__ idx, long quads, int qblocks) {
+  __shared__ float t[32][65];
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x / qblocks;
+  const long q0 = (long)(blockIdx.x - b * qblocks) * 64;
+  const int nq = (int)min(64L, quads - q0);
+  const int q = tid >> 2, c8 = tid & 3;              // thread = (window, 8 channels = chunks 2 c8 and 2 c8 + 1 of a pixel's 8)
+  if (q < nq) {
+    const f32x4* src = feat + ((b * quads + q0 + q) * 4) * 8 + 2 * c8;
+    f32x4 v[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k][0] = __builtin_nontemporal_load(src + 8 * k);
+      v[k][1] = __builtin_nontemporal_load(src + 8 * k + 1);
+    }
+    unsigned codes = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float m = v[0][j >> 2][j & 3];
+      unsigned am = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float f = v[k][j >> 2][j & 3];
+        if (f > m) { m = f; am = k; }
+      }
+      t[8 * c8 + j][q] = m;
+      codes |= (am | (m > 0.f ? 4u : 0u)) << (4 * j);
+    }
+    idx[(b * quads + q0 + q) * 4 + c8] = codes;      // two 16-bit words: channel groups 2 c8 and 2 c8 + 1
+  }
+  __syncthreads();
+  float* o = pooled + b * (quads * 32) + q0;
+  const int qq = tid & 63;
+  if (qq < nq) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (tid >> 6) + 4 * j;
+      o[(long)c * quads + qq] = t[c][qq];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool4_bwd_tile32(const float* __restrict__ dpooled, const unsigned* __restrict__ idx,
+                                                        f32x4* __restrict__ dfeat, long quads, int qblocks) {
+  __shared__ float g[32][65];
+  __shared__ unsigned cd[64][4];
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x / qblocks;
+  const long q0 = (long)(blockIdx.x - b * qblocks) * 64;
+  const int nq = (int)min(64L, quads - q0);
+  const float* gp = dpooled + b * (quads * 32) + q0;
+  const int qq = tid & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = (tid >> 6) + 4 * j;
+    g[c][qq] = qq < nq ? gp[(long)c * quads + qq] : 0.f;
+  }
+  cd[tid >> 2][tid & 3] = (tid >> 2) < nq ? idx[(b * quads + q0) * 4 + tid] : 0u;
+  __syncthreads();
+  f32x4* out = dfeat + (b * quads + q0) * 32;       // 32 chunks of 16 bytes per window
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid + 256 * k;                    // chunk i of the tile: pixel i >> 3, channels 4 (i & 7) ..
+    const int px = i >> 3, c4 = i & 7, qd = px >> 2, pos = px & 3;
+    if (qd >= nq) continue;
+    const unsigned codes = cd[qd][c4 >> 1] >> (16 * (c4 & 1));
+    f32x4 d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned c = (codes >> (4 * j)) & 15u;
+      d[j] = ((c & 4u) && (c & 3u) == (unsigned)pos) ? g[4 * c4 + j][qd] : 0.f;
+    }
+    __builtin_nontemporal_store(d, out + i);
+  }
+}
+
 __global__ __launch_bounds__(256) void pool4_bwd_quad(const float* __restrict__ dpooled,
                                                       const f32x4* __restrict__ feat, f32x4* __restrict__ dfeat,
                                                       int B, long HW, int C) {
@@ -516,8 +596,13 @@ int dd_pool4_fwd_idx(const float* feat, float* pooled, uint16_t* idx, int32_t ba
   DD_REQUIRE(feat && pooled && idx, DD_ERR_BAD_ARG, "pool4_fwd_idx: NULL pointer");
   const int64_t total = dd_pool4_idx_elems(batch, h, w, c);
   if (total < 0) return DD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pool4_fwd_quad<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat, pooled,
-                     (unsigned short*)idx, batch, (long)h * w, c);
+  const long quads = (long)h * w / 4, qblocks = (quads + 63) / 64;
+  if (c == 32 && batch * qblocks < (1L << 31) && ((uintptr_t)feat & 15) == 0 && ((uintptr_t)idx & 3) == 0)
+    hipLaunchKernelGGL(pool4_fwd_tile32, dim3((unsigned)(batch * qblocks)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat, pooled,
+                       (unsigned*)idx, quads, (int)qblocks);
+  else
+    hipLaunchKernelGGL(pool4_fwd_quad<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)feat, pooled,
+                       (unsigned short*)idx, batch, (long)h * w, c);
   DD_LAUNCH_CHECK("pool4_fwd_idx");
   return 0;
 }
@@ -527,8 +612,13 @@ int dd_pool4_idx_relu_bwd(const float* dpooled, const uint16_t* idx, float* dfea
   DD_REQUIRE(dpooled && idx && dfeat, DD_ERR_BAD_ARG, "pool4_idx_bwd: NULL pointer");
   const int64_t total = dd_pool4_idx_elems(batch, h, w, c);
   if (total < 0) return DD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pool4_bwd_idx_quad, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dpooled, (const unsigned short*)idx,
-                     (f32x4*)dfeat, batch, (long)h * w, c);
+  const long quads = (long)h * w / 4, qblocks = (quads + 63) / 64;
+  if (c == 32 && batch * qblocks < (1L << 31) && ((uintptr_t)dfeat & 15) == 0 && ((uintptr_t)idx & 3) == 0)
+    hipLaunchKernelGGL(pool4_bwd_tile32, dim3((unsigned)(batch * qblocks)), dim3(256), 0, (hipStream_t)stream, dpooled, (const unsigned*)idx,
+                       (f32x4*)dfeat, quads, (int)qblocks);
+  else
+    hipLaunchKernelGGL(pool4_bwd_idx_quad, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dpooled, (const unsigned short*)idx,
+                       (f32x4*)dfeat, batch, (long)h * w, c);
   DD_LAUNCH_CHECK("pool4_idx_bwd");
   return 0;
 }

@@ -137,6 +137,34 @@ def pool4_relu_bwd(dpooled, feat):
     return out
 
 
+def pool4_has_idx(h, w, c):
+    """Whether the tiled pool with routing codes takes this feature map (C == 32, H*W % 4 == 0)."""
+    return c == 32 and (h * w) % 4 == 0
+
+
+def pool4_fwd_idx(feat):
+    """pooled, codes: max_pool1d(4) + the backward's routing (dd_pool4_bf16_fwd_idx)."""
+    b, h, w, c = feat.shape
+    _bf(feat, "feat")
+    n = _lib.lib().dd_pool4_bf16_idx_elems(b, h, w, c)
+    if n < 0:
+        raise _lib.HotpathError(_lib.lib().dd_last_error().decode())
+    out = torch.empty((b, (c * h * w) // 4), device=feat.device, dtype=torch.float32)
+    idx = torch.empty(n, device=feat.device, dtype=torch.int16)
+    check(_lib.lib().dd_pool4_bf16_fwd_idx(_p(feat), _p(out), _p(idx), b, h, w, c, _stream()), "dd_pool4_bf16_fwd_idx")
+    return out, idx
+
+
+def pool4_idx_relu_bwd(dpooled, idx, shape):
+    b, h, w, c = shape
+    ops._dev(dpooled, "dpooled", (b, (c * h * w) // 4))
+    if idx.dtype != torch.int16 or idx.numel() != b * (h * w // 4) * (c // 4) or not idx.is_cuda:
+        raise _lib.HotpathError(f"pool4_idx_relu_bwd (bf16): bad routing codes {tuple(idx.shape)} {idx.dtype}")
+    out = torch.empty(shape, device=dpooled.device, dtype=torch.bfloat16)
+    check(_lib.lib().dd_pool4_idx_relu_bf16_bwd(_p(dpooled), _p(idx), _p(out), b, h, w, c, _stream()), "dd_pool4_idx_relu_bf16_bwd")
+    return out
+
+
 class EncoderConvStackBf16(torch.autograd.Function):
     """c1 -> ReLU -> c2 -> ReLU -> c3 (stride 2) -> ReLU -> NCHW-order max_pool1d(4), bf16 operands / fp32 accumulation.
 
@@ -160,8 +188,14 @@ class EncoderConvStackBf16(torch.autograd.Function):
             p3d = conv_pack(w3, d3, PACK_DGRAD_S2)
         if need[1] or need[2]:
             p2d = conv_pack(w2, d2, PACK_DGRAD_S1)
-        ctx.save_for_backward(x4, a1, a2, a3, p2d, p3d, s1, s2)
         ctx.pool = bool(pool)
+        ctx.a3_shape = tuple(a3.shape)
+        ctx.pool_idx = ctx.pool and pool4_has_idx(*a3.shape[1:])
+        if ctx.pool_idx:      # the pool's backward runs from 30 MB of routing codes: the 0.48 GB feature is neither kept nor read again
+            out, codes = pool4_fwd_idx(a3)
+            ctx.save_for_backward(x4, a1, a2, codes, p2d, p3d, s1, s2)
+            return out
+        ctx.save_for_backward(x4, a1, a2, a3, p2d, p3d, s1, s2)
         return pool4_fwd(a3) if pool else to_f32(a3)
 
     @staticmethod
@@ -169,7 +203,9 @@ class EncoderConvStackBf16(torch.autograd.Function):
         x4, a1, a2, a3, p2d, p3d, s1, s2 = ctx.saved_tensors
         b, h, w, _ = x4.shape
         d1, d2, d3 = conv_desc(b, h, w, 3, 1), conv_desc(b, h, w, 32, 1), conv_desc(b, h, w, 32, 2)
-        if ctx.pool:
+        if ctx.pool_idx:
+            g3 = pool4_idx_relu_bwd(grad_out.contiguous(), a3, ctx.a3_shape)      # a3 holds the routing codes here
+        elif ctx.pool:
             g3 = pool4_relu_bwd(grad_out.contiguous(), a3)
         else:      # feature exit: ReLU mask in fp32, then the one rounding to bf16 the contract prescribes for a pre-activation gradient
             g3 = to_bf16(ops.relu_bwd(grad_out.contiguous(), to_f32(a3)))

@@ -633,6 +633,17 @@ int dd_pool4_bf16_fwd(const uint16_t* feat, float* pooled, int32_t batch, int32_
 /* its backward with the ReLU in front of the pool fused (feat > 0), gradient written in bf16 */
 int dd_pool4_relu_bf16_bwd(const float* dpooled, const uint16_t* feat, uint16_t* dfeat, int32_t batch, int32_t h,
                            int32_t w, int32_t c, void* stream);
+/* The same pair for C == 32 with the backward's routing decided in the forward, as dd_pool4_fwd_idx / dd_pool4_idx_relu_bwd do for fp32:
+ * idx holds dd_pool4_bf16_idx_elems() 16-bit words, one per (window, 4 channels), 4 bits per channel = first maximum | (max > 0) << 2
+ * (torch keeps the earliest index on ties; the ReLU in front of the pool is the "> 0" bit).  The backward reads dpooled and idx only --
+ * the feature map is not kept for it -- and both kernels move 64-window tiles through LDS so that each side of the NHWC <-> NCHW-flat
+ * change of order is read and written in whole 128-byte lines.  idx may be NULL in the forward (no codes written).  feat / dfeat
+ * 16-byte aligned.  Results equal dd_pool4_bf16_fwd / dd_pool4_relu_bf16_bwd bit for bit. */
+int64_t dd_pool4_bf16_idx_elems(int32_t batch, int32_t h, int32_t w, int32_t c);
+int dd_pool4_bf16_fwd_idx(const uint16_t* feat, float* pooled, uint16_t* idx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                          void* stream);
+int dd_pool4_idx_relu_bf16_bwd(const float* dpooled, const uint16_t* idx, uint16_t* dfeat, int32_t batch, int32_t h, int32_t w,
+                               int32_t c, void* stream);
 int dd_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);     /* n % 4 == 0, round to nearest even */
 int dd_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
 

@@ -127,6 +127,33 @@ def test_pool_and_stitch(dev, b, h, w):
     assert torch.equal(ob.stitch6_bf16_samples([vd[i].clone() for i in range(b)]), wide)
 
 
+@pytest.mark.parametrize("b,h,w", [(2, 4, 6), (1, 8, 66), (3, 16, 130)])
+def test_tiled_pool_with_routing_codes_equals_torch_and_the_plain_pair(dev, b, h, w):
+    """dd_pool4_bf16_fwd_idx / dd_pool4_idx_relu_bf16_bwd (64-window tiles through LDS, the backward from 4-bit routing codes): max_pool1d(4)
+    of the NCHW-flattened feature and its gradient behind the ReLU exactly as torch computes them -- ties go to the earliest index, a
+    non-positive maximum passes nothing -- on ragged last tiles too, and bit for bit what the plain kernels give."""
+    from driving_dirty_amd import ops_bf16 as ob
+    feat = bf16r(hu((b, 32, h, w), "featt", -1.0, 1.0))
+    flat = feat.reshape(b, -1)
+    flat[:, 0:4] = 0.25                       # a window of four equal values: the first takes the gradient
+    flat[:, 4:8] = torch.tensor([-0.5, -0.25, -0.25, -1.0])      # negative maximum: the ReLU in front is closed
+    flat[:, 8:12] = torch.tensor([0.0, -1.0, 0.0, -1.0])         # maximum exactly zero: closed as well
+    flat[:, 12:16] = torch.tensor([0.5, 0.75, 0.75, 0.125])      # tie between positions 1 and 2
+    fd = nhwc(feat).to(dev).to(torch.bfloat16)
+    assert ob.pool4_has_idx(h, w, 32)
+    pooled, codes = ob.pool4_fwd_idx(fd)
+    ref = F.max_pool1d(feat.reshape(b, 1, -1), 4).squeeze(1)
+    assert torch.equal(pooled.cpu(), ref) and torch.equal(pooled, ob.pool4_fwd(fd))
+    gp = hu(tuple(ref.shape), "gpt")
+    featr = feat.clone().requires_grad_(True)
+    F.max_pool1d(F.relu(featr).reshape(b, 1, -1), 4).squeeze(1).backward(gp)
+    got = ob.pool4_idx_relu_bwd(gp.to(dev), codes, tuple(fd.shape))
+    assert torch.equal(nchw(got.float().cpu()), bf16r(featr.grad))
+    assert torch.equal(got, ob.pool4_relu_bwd(gp.to(dev), fd))
+    with pytest.raises(Exception):
+        ob.pool4_idx_relu_bwd(gp.to(dev), codes[:-1], tuple(fd.shape))
+
+
 def test_conv_stack_against_oracle(dev):
     """Whole stack forward + backward at a small ragged size; weights/bias gradients are fp32 sums."""
     from driving_dirty_amd import ops_bf16 as ob

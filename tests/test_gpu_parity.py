@@ -196,7 +196,7 @@ def test_pool4_nchw_order(dev, b, c, h, w):
     assert torch.equal(dfeat.permute(0, 3, 1, 2).cpu(), feat.grad * (feat.detach() > 0))
 
 
-@pytest.mark.parametrize("b,c,h,w", [(2, 32, 8, 11), (2, 32, 16, 22), (1, 8, 2, 2)])
+@pytest.mark.parametrize("b,c,h,w", [(2, 32, 8, 11), (2, 32, 16, 22), (3, 32, 16, 34), (1, 8, 2, 2)])
 def test_pool4_routing_codes(dev, b, c, h, w):
     """dd_pool4_fwd_idx / dd_pool4_idx_relu_bwd: routing decided in the forward (ties -> first index, all-zero windows
     -> no gradient), bit-identical to max_pool1d + its backward + the ReLU mask; shapes whose windows leave the channel

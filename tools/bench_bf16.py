@@ -73,6 +73,9 @@ def main():
         pooled = ob.pool4_fwd(a3)
         rec("pool_fwd", timeit(lambda: ob.pool4_fwd(a3), a.iters), pxo * (64 + 32), 0)
         rec("pool_bwd", timeit(lambda: ob.pool4_relu_bwd(pooled, a3), a.iters), pxo * (64 + 32 + 64), 0)
+        pooled2, codes = ob.pool4_fwd_idx(a3)
+        rec("pool_fwd_idx", timeit(lambda: ob.pool4_fwd_idx(a3), a.iters), pxo * (64 + 32 + 2), 0)
+        rec("pool_bwd_idx", timeit(lambda: ob.pool4_idx_relu_bwd(pooled2, codes, tuple(a3.shape)), a.iters), pxo * (32 + 2 + 64), 0)
         views = torch.rand(b, 6, 3, a.h, a.w, device=dev)
         rec("stitch_bf16", timeit(lambda: ob.stitch6_bf16(views), a.iters), px * (12 + 8), 0)
         del a1, a2, a3, g2, g3, x4, pooled, views
