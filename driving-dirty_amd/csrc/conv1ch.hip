@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) void conv1ch_wgrad_reduce(const float* __restr
   const int hh = (co >> 2) & 1, e = (co & 3) + 4 * (co >> 3);
   const int lane = 32 * hh + n;
   double s = 0.0;
-  for (int w = slice; w < nwg; w += 16) s += (double)part[(((long)w * 2 + nt) * 16 + e) * 64 + lane];
+  if (slice < nwg) dd_sum_strided(s, part + (((long)slice * 2 + nt) * 16 + e) * 64 + lane, 16L * 2 * 16 * 64, (nwg - slice + 15) / 16);
   red[slice][co] = s;
   __syncthreads();
   if (slice == 0) {

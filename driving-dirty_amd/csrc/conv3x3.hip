@@ -1968,22 +1968,22 @@ __global__ __launch_bounds__(256) void conv_wino2_wgrad_reduce_a(const float* __
   ((f32x4*)tsum)[((long)c * 16 + p) * 256 + f] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
-// Few vector registers (rolled loops: 40): this kernel is launched on the side stream while the c2 data gradient holds 464 of every
-// SIMD's 512 -- with the 136 of the unrolled form its 17 waves waited in the queue for that kernel to END (1.59 ms from dispatch
-// to completion in the trace, ~60 us of it running, and the optimizer's last launch waits for it).  The output transform runs as
-// running sums with coefficients 0 / +-1 in the order of the closed forms ((t0 + t1) + t2, t1 - t2, (t1 + t2) + t3): the same bits.
+// The output transform runs as running sums with coefficients 0 / +-1 in the order of the closed forms ((t0 + t1) + t2, t1 - t2,
+// (t1 + t2) + t3), one column v at a time.  (Rounds 3-4 kept this kernel at 40 registers with every loop rolled so that it fitted beside
+// the c2 data gradient's 464; that kernel now holds 475 and nothing fits beside it, and since round 5 the weight gradient this launch
+// reduces is the LAST conv kernel of the step, so the launch is the step's tail: its loads are batched per column instead.)
 __global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __restrict__ tsum, const float* __restrict__ bpart,
                                                                 float* __restrict__ dw, float* __restrict__ db, int nw) {
   const int l = threadIdx.x;
   const int r = blockIdx.x;   // accumulator register row, or 16 for the bias
   if (r == 16) {
+    // s[i] = the partials w = i, i + 4, ... in order, as the four-way loop this replaces -- with 64 loads in flight instead of 4 (the
+    // bias block was the long pole of the launch: nw / 4 dependent round trips, 34 us at the tail of the step)
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    int w = 0;
-    for (; w + 3 < nw; w += 4) {
+    const int full = nw & ~3;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[i] += bpart[(long)(w + i) * 64 + l];
-    }
-    for (int i = 0; w < nw; ++w, ++i) s[i] += bpart[(long)w * 64 + l];
+    for (int i = 0; i < 4; ++i) dd_sum_strided(s[i], bpart + (long)i * 64 + l, 256, full / 4);
+    for (int w = full, i = 0; w < nw; ++w, ++i) s[i] += bpart[(long)w * 64 + l];
     const float t = (s[0] + s[1]) + (s[2] + s[3]);
     const float other = __shfl_xor(t, 32);
     if (l < 32) db[l] = t + other;
@@ -1995,12 +1995,18 @@ __global__ __launch_bounds__(64) void conv_wino2_wgrad_reduce_b(const float* __r
 #pragma unroll 1
   for (int v = 0; v < 4; ++v) {
     float z[3] = {0.f, 0.f, 0.f};      // z[ky] = A^T[ky][u] t[u][v]
-#pragma unroll 1
+    // the 4 x 16 chunk sums of this column are requested together (one memory round trip per column instead of four); each t[u] is still
+    // the sum of its 16 chunks in chunk order
+    float tv[4][W2R_CHUNKS];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < W2R_CHUNKS; ++c) tv[u][c] = tsum[(((long)c * 16 + (u * 4 + v)) * 16 + r) * 64 + l];
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int p = u * 4 + v;
       float t = 0.f;
 #pragma unroll
-      for (int c = 0; c < W2R_CHUNKS; ++c) t += tsum[(((long)c * 16 + p) * 16 + r) * 64 + l];
+      for (int c = 0; c < W2R_CHUNKS; ++c) t += tv[u][c];
       // the halves of G left out of conv_wino2_wgrad's dy transform (powers of two: exact)
       t = t * ((u == 1 || u == 2) ? 0.5f : 1.f) * ((v == 1 || v == 2) ? 0.5f : 1.f);
       z[0] += (u < 3 ? 1.f : 0.f) * t;

@@ -599,15 +599,16 @@ __global__ __launch_bounds__(1024) void bf_wgrad_reduce(const float* __restrict_
   const int row = blockIdx.x;
   const float* src = (row < NT * 16) ? part + (long)row * 64 + l : bpart + l;
   const long stride = (row < NT * 16) ? (long)NT * 16 * 64 : 64;
+  // four running sums over the waves w = g + kG + 4G j (k = 0..3), then the ragged rest onto the first: the order of the four-way loop
+  // this replaces, with 64 loads in flight instead of 4 (8192 partials per element for c1: 128 dependent round trips, 37 us)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int w = g;
-  for (; w + 3 * G < nw; w += 4 * G) {
-    s0 += src[(long)w * stride];
-    s1 += src[(long)(w + G) * stride];
-    s2 += src[(long)(w + 2 * G) * stride];
-    s3 += src[(long)(w + 3 * G) * stride];
-  }
-  for (; w < nw; w += G) s0 += src[(long)w * stride];
+  const int m = (g + 3 * G < nw) ? (nw - 1 - 3 * G - g) / (4 * G) + 1 : 0;
+  dd_sum_strided(s0, src + (long)g * stride, 4 * G * stride, m);
+  dd_sum_strided(s1, src + (long)(g + G) * stride, 4 * G * stride, m);
+  dd_sum_strided(s2, src + (long)(g + 2 * G) * stride, 4 * G * stride, m);
+  dd_sum_strided(s3, src + (long)(g + 3 * G) * stride, 4 * G * stride, m);
+  const int w = g + 4 * G * m;
+  if (w < nw) dd_sum_strided(s0, src + (long)w * stride, G * stride, (nw - w + G - 1) / G);
   red[g][l] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g != 0) return;

@@ -826,16 +826,14 @@ __global__ __launch_bounds__(1024) void dconv_wgrad_reduce(const float* __restri
   double s = 0.0;
   if (G::BAL && t >= 8 * G::OWN) {      // a shared tile: every wave of every workgroup holds a partial sum
     const int i = G::OWN + (t - 8 * G::OWN);
-    for (int w = 0; w < wg_per_ky; ++w)
-      for (int wave = 0; wave < 8; ++wave)
-        s += (double)part[((((long)(ky * wg_per_ky + w) * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane];
+    // (workgroup, wave) pairs in order: wave index (ky * wg_per_ky + w) * 8 + wave runs through consecutive values
+    dd_sum_strided(s, part + ((((long)ky * wg_per_ky * 8) * G::TPW + i) * 16 + r) * 64 + lane, (long)G::TPW * 1024, wg_per_ky * 8);
   } else {
     const int set = t / G::OWN, i = t - set * G::OWN;
-    for (int w = 0; w < wg_per_ky; ++w)
-      for (int prt = 0; prt < G::PARTS; ++prt) {
-        const int wave = set + G::NSETS * prt;
-        s += (double)part[((((long)(ky * wg_per_ky + w) * 8 + wave) * G::TPW + i) * 16 + r) * 64 + lane];
-      }
+    // (workgroup, pixel part) pairs in order: wave = set + NSETS * prt, and NSETS * PARTS == 8 makes w * 8 + NSETS * prt = NSETS * (w * PARTS + prt)
+    static_assert(G::NSETS * G::PARTS == 8, "the pairs are one strided sequence");
+    dd_sum_strided(s, part + ((((long)ky * wg_per_ky * 8 + set) * G::TPW + i) * 16 + r) * 64 + lane, (long)G::NSETS * G::TPW * 1024,
+                   wg_per_ky * G::PARTS);
   }
   const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT, kx = t / (G::NTO * G::MT);
   const int c = mt * 32 + dd_acc_row(r, lane), o = nt * 32 + (lane & 31);
@@ -984,7 +982,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad16_reduce(const float* __restr
   const int ky = blockIdx.x / G::TPW, t = blockIdx.x - ky * G::TPW;
   const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0.0;
-  for (int w = 0; w < nwg; ++w) s += (double)part[((((long)w * K + ky) * G::TPW + t) * 4 + r) * 64 + lane];
+  dd_sum_strided(s, part + (((long)ky * G::TPW + t) * 4 + r) * 64 + lane, (long)K * G::TPW * 256, nwg);
   const int nt = t % G::NTO, mt = (t / G::NTO) % G::MT;
   const int kx = G::PAIR ? 2 * (t / (G::NTO * G::MT)) + ((lane & 15) >> 3) : t / (G::NTO * G::MT);
   const int c = mt * 16 + 4 * (lane >> 4) + r;                                  // D[row = 4*(lane >> 4) + r][col = lane & 15]

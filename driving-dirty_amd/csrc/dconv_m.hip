@@ -552,9 +552,18 @@ __global__ __launch_bounds__(64) void dconv_colsum_reduce(const float* __restric
   if (c >= cout) return;
   const int nt = c >> 5, n = c & 31;
   double sum = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    const float* q = cpart + (long)b * (ntc * 64) + nt * 64;
-    sum += (double)q[n] + (double)q[32 + n];
+  const float* q0 = cpart + nt * 64 + n;
+  for (int b0 = 0; b0 < nblocks; b0 += 16) {      // sixteen workgroups' pairs in flight; the sum runs in the order of the plain loop
+    float lo[16], hi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float* q = q0 + (long)min(b0 + j, nblocks - 1) * (ntc * 64);      // unconditional loads; past the end the last pair again, not added
+      lo[j] = q[0];
+      hi[j] = q[32];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (b0 + j < nblocks) sum += (double)lo[j] + (double)hi[j];
   }
   out[c] = (float)sum;
 }

@@ -61,6 +61,22 @@ __device__ __forceinline__ void dd_bstore1(__amdgpu_buffer_rsrc_t r, int off, fl
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
 
+// s += p[0] + p[stride] + ... (n terms), left to right -- the order, and so the bits, of the plain loop -- with SIXTEEN loads in flight:
+// the second stages of the weight / bias gradients add a few hundred per-workgroup partials per output element, and written as
+// `for (w...) s += part[w * stride]` each add waited for its own load: 50-60 us of memory latency per launch for a few KB of output
+// (round 5: 0.49 ms of the box-head step in ten such launches).
+template <typename Acc>
+__device__ __forceinline__ void dd_sum_strided(Acc& s, const float* __restrict__ p, long stride, int n) {
+  for (int i = 0; i < n; i += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = p[(long)min(i + j, n - 1) * stride];      // unconditional (a guarded load is a branch per load): past the end, the last term again, not added
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (i + j < n) s += (Acc)v[j];
+  }
+}
+
 // The contiguous range [idx, end) of `total` work items owned by piece `i` of `n` equal pieces.
 __device__ __forceinline__ void dd_range(long total, int i, int n, long& idx, long& end) {
   const long per = (total + n - 1) / n;

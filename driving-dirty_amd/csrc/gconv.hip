@@ -696,8 +696,7 @@ __global__ __launch_bounds__(256) void deconv2x2_c1_reduce(const float* __restri
   __shared__ float red[4][64];
   const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
   float s = 0.f;
-  if (i < nvals)
-    for (int b = g; b < nblocks; b += 4) s += partial[(long)b * nvals + i];
+  if (i < nvals && g < nblocks) dd_sum_strided(s, partial + (long)g * nvals + i, 4L * nvals, (nblocks - g + 3) / 4);
   red[g][i] = s;
   __syncthreads();
   if (g != 0 || i >= nvals) return;
@@ -940,22 +939,33 @@ __global__ __launch_bounds__(256) void deconv2x2_c32_wgrad_kernel(const float* _
   out[4096 + lane] = bsum;
 }
 
-__global__ __launch_bounds__(256) void deconv2x2_c32_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < 4096) {      // t = (p * 16 + e) * 64 + lane: element (ci = row of accumulator register e, co = lane & 31) of phase p = 2a + b
-    double s = 0.0;
-    for (int k = 0; k < D2W_WAVES; ++k) s += (double)part[(long)k * (4 * 1024 + 64) + t];
-    const int lane = t & 63, e = (t >> 6) & 15, p = t >> 10;
-    const int ci = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), co = lane & 31;
+// Second stage: block b < 64 owns the 64 consecutive elements t = 64 b + lane, block 64 the bias columns.  Its 16 thread groups each add
+// a contiguous sixteenth of the D2W_WAVES partials (fp64, in order, sixteen loads in flight), LDS adds the groups in order: a fixed order
+// whatever the grid.  (One thread per element walking all 1024 partials alone -- 17 workgroups on the chip -- was 53 us of load latency.)
+__global__ __launch_bounds__(1024) void deconv2x2_c32_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double red[16][64];
+  constexpr long STRIDE = 4 * 1024 + 64;
+  constexpr int PER = D2W_WAVES / 16;
+  static_assert(D2W_WAVES % 16 == 0, "sixteen equal ranges");
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const bool bias = blockIdx.x == 64;
+  if (bias && !db) return;
+  const int t = bias ? 4096 + lane : blockIdx.x * 64 + lane;      // element (p * 16 + e) * 64 + lane of phase p = 2a + b, or bias half-column
+  double s = 0.0;
+  dd_sum_strided(s, part + (long)g * PER * STRIDE + t, STRIDE, PER);
+  red[g][lane] = s;
+  __syncthreads();
+  if (g != 0) return;
+  s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += red[i][lane];
+  if (bias) {
+    const double other = __shfl_xor(s, 32);      // the two half-columns of an output channel
+    if (lane < 32) db[lane] = (float)(s + other);
+  } else {
+    const int l = t & 63, e = (t >> 6) & 15, p = t >> 10;
+    const int ci = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), co = l & 31;
     dw[(ci * 32 + co) * 4 + p] = (float)s;
-  } else if (t < 4096 + 32 && db) {
-    const int co = t - 4096;
-    double s = 0.0;
-    for (int k = 0; k < D2W_WAVES; ++k) {
-      const float* q = part + (long)k * (4 * 1024 + 64) + 4096;
-      s += (double)q[co] + (double)q[32 + co];
-    }
-    db[co] = (float)s;
   }
 }
 
@@ -1105,7 +1115,7 @@ int dd_deconv2x2_c32_wgrad(const float* x, const float* g, float* dw, float* db,
   hipLaunchKernelGGL(deconv2x2_c32_wgrad_kernel, dim3(D2W_WAVES / 4), dim3(256), 0, (hipStream_t)stream, x, g, (float*)workspace, npix, w,
                      g_cstore, g_coff);
   DD_LAUNCH_CHECK("deconv2x2_c32_wgrad");
-  hipLaunchKernelGGL(deconv2x2_c32_wgrad_reduce, dim3((4096 + 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+  hipLaunchKernelGGL(deconv2x2_c32_wgrad_reduce, dim3(65), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, dw,
                      db);
   DD_LAUNCH_CHECK("deconv2x2_c32_wgrad reduce");
   return 0;

@@ -272,22 +272,24 @@ struct S6Out {
   float* db[6];
 };
 
-// second stage: a workgroup owns 8 consecutive accumulator elements (tile, nt, r, lane); its 32 thread groups each add the waves
-// w = g, g + 32, ... of the tile, LDS adds the groups in order: fixed order, deterministic (one thread per element walking all 341
-// waves alone was a latency chain: 82 us)
-__global__ __launch_bounds__(256) void strip6_wgrad_reduce(const float* __restrict__ part, const S6Out out, int waves_per_tile, int accumulate) {
-  __shared__ float red[32][8];
-  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const int e = blockIdx.x * 8 + el;                          // [tile][nt][r][lane], 6 x 6144 elements
-  const int tile = e / 6144, rem = e % 6144, nt = rem / 1024, r = (rem % 1024) / 64, lane = rem % 64;
+// second stage: a workgroup owns 64 consecutive accumulator elements (tile, nt, r, lane): a whole register row, 256 contiguous bytes of
+// every partial; its 16 thread groups each add the waves w = g, g + 16, ... of the tile (sixteen loads in flight), LDS adds the groups in
+// order: fixed order, deterministic.  (One thread per element walking all 341 waves alone was a latency chain: 82 us; eight elements per
+// workgroup read 32-byte pieces: 33 us.)
+__global__ __launch_bounds__(1024) void strip6_wgrad_reduce(const float* __restrict__ part, const S6Out out, int waves_per_tile, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;                       // [tile][nt][r][lane], 6 x 6144 elements
+  const int tile = e / 6144, rem = e % 6144, nt = rem / 1024, r = (rem % 1024) / 64;
   float s = 0.f;
-  for (int w = g; w < waves_per_tile; w += 32) s += part[((long)(w * 6 + tile) * 6 + nt) * 1024 + r * 64 + lane];
-  red[g][el] = s;
+  if (g < waves_per_tile)
+    dd_sum_strided(s, part + ((long)(g * 6 + tile) * 6 + nt) * 1024 + r * 64 + lane, 16L * 36 * 1024, (waves_per_tile - g + 15) / 16);
+  red[g][lane] = s;
   __syncthreads();
   if (g != 0) return;
   s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) s += red[i][el];
+  for (int i = 0; i < 16; ++i) s += red[i][lane];
   const int T = (tile == 2 || tile == 3) ? 52 : 50;
   const int co = dd_acc_row(r, lane), c = nt >> 1, t = 32 * (nt & 1) + (lane & 31);
   if (t < T) {
@@ -388,7 +390,7 @@ int dd_strip6_wgrad(const void* const* sample_ptrs, int32_t u8, const float* g, 
     if (u8) hipLaunchKernelGGL(strip6_wgrad_kernel<true>, dim3(S6_WG_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(strip6_wgrad_kernel<false>, dim3(S6_WG_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
     DD_LAUNCH_CHECK("strip6_wgrad");
-    hipLaunchKernelGGL(strip6_wgrad_reduce, dim3(6 * 6 * 1024 / 8), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, wpt,
+    hipLaunchKernelGGL(strip6_wgrad_reduce, dim3(6 * 6 * 1024 / 64), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, out, wpt,
                        b0 > 0 ? 1 : 0);
     DD_LAUNCH_CHECK("strip6_wgrad_reduce");
   }
