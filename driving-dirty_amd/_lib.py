@@ -56,6 +56,7 @@ SIGNATURES = {
     "dd_subsample_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_subsample_nhwc4_u8_ptrs": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_copy_channels": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p]),
+    "dd_copy_channels_window": (_i32, [_p, _p] + [_i32] * 16 + [_p]),
     "dd_deconv2x2_c32_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_deconv2x2_c32_fwd_slice": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_deconv2x2_c32_wgrad_workspace_bytes": (_i64, []),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "dd_conv_wgrad_workspace_bytes": (_i64, [_DP]),
     "dd_conv_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _DP, _p]),
     "dd_relu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
+    "dd_relu_sign_bits": (_i32, [_p, _p, _i64, _p]),
+    "dd_relu_bwd_pad_bits": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_pool4_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_idx_elems": (_i64, [_i32, _i32, _i32, _i32]),

@@ -2089,6 +2089,51 @@ __global__ void conv_wino_pack_kernel(const float* __restrict__ w, float* __rest
   p[idx] = u;
 }
 
+// Sign words of a 32-channel NHWC activation: bits[p] bit c = x[p][c] > 0 -- what dd_conv_fwd_relu_bits writes beside its output, for an
+// activation another kernel produced (the strip mosaic in front of SpatialMappingCNN's out_conv, when that layer's data gradient runs on
+// the Winograd kernels).  A wave takes 64 pixels: each ballot covers two (lanes = channels, fully coalesced 256-byte loads), lane p keeps
+// the word of pixel p, the 64 words leave as one store.
+__global__ __launch_bounds__(256) void relu_sign_bits_kernel(const float* __restrict__ x, unsigned* __restrict__ bits, long npix) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long p0 = wave * 64; p0 < npix; p0 += nwaves * 64) {
+    unsigned word = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const long p = p0 + 2 * i + (lane >> 5);
+      const float v = p < npix ? x[p * 32 + (lane & 31)] : 0.f;
+      const unsigned long long m = __ballot(v > 0.f);
+      if (lane == 2 * i) word = (unsigned)m;
+      if (lane == 2 * i + 1) word = (unsigned)(m >> 32);
+    }
+    if (p0 + lane < npix) bits[p0 + lane] = word;
+  }
+}
+
+// out_pad [B, H + 2, W + 2, 32] = dy [B, H, W, 32] * (the ReLU was open: bit c of bits_pad[pixel]) in the interior, ZERO on the border ring:
+// the output gradient of a padding-0 3x3 layer laid out for the padding-1 kernels (its border outputs do not exist, so they carry no
+// gradient), with the layer's own ReLU backward applied from the sign words its forward wrote.
+__global__ __launch_bounds__(256) void relu_bwd_pad_bits_kernel(const f32x4* __restrict__ dy, const unsigned* __restrict__ bits_pad,
+                                                                f32x4* __restrict__ out_pad, int B, int H, int W) {
+  const long total = (long)B * (H + 2) * (W + 2) * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 7);
+    const long pp = i >> 3;
+    const int xx = (int)(pp % (W + 2)), yy = (int)((pp / (W + 2)) % (H + 2));
+    const long b = pp / ((long)(W + 2) * (H + 2));
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (xx >= 1 && xx <= W && yy >= 1 && yy <= H) {
+      const f32x4 g = dy[((b * H + (yy - 1)) * W + (xx - 1)) * 8 + q];
+      const unsigned m = bits_pad[pp] >> (4 * q);
+      o.x = (m & 1u) ? g.x : 0.f;
+      o.y = (m & 2u) ? g.y : 0.f;
+      o.z = (m & 4u) ? g.z : 0.f;
+      o.w = (m & 8u) ? g.w : 0.f;
+    }
+    __builtin_nontemporal_store(o, out_pad + i);
+  }
+}
+
 __global__ void relu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ y, f32x4* __restrict__ out,
                                 long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -2401,6 +2446,26 @@ int dd_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* st
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dy, (const f32x4*)y,
                      (f32x4*)out, n4);
   DD_LAUNCH_CHECK("relu_bwd");
+  return 0;
+}
+
+int dd_relu_sign_bits(const float* x, uint32_t* bits, int64_t npix, void* stream) {
+  DD_REQUIRE(x && bits && npix > 0, DD_ERR_BAD_ARG, "relu_sign_bits: bad argument");
+  const long waves = (npix + 63) / 64;
+  const int grid = (int)min((waves + 3) / 4, (long)DD_NUM_CU * 8);
+  hipLaunchKernelGGL(relu_sign_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bits, (long)npix);
+  DD_LAUNCH_CHECK("relu_sign_bits");
+  return 0;
+}
+
+int dd_relu_bwd_pad_bits(const float* dy, const uint32_t* bits_pad, float* out_pad, int32_t batch, int32_t h, int32_t w, void* stream) {
+  DD_REQUIRE(dy && bits_pad && out_pad && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "relu_bwd_pad_bits: bad argument");
+  DD_REQUIRE((((uintptr_t)dy | (uintptr_t)out_pad) & 15) == 0, DD_ERR_BAD_ARG, "relu_bwd_pad_bits: dy and out_pad must be 16-byte aligned");
+  const long total = (long)batch * (h + 2) * (w + 2) * 8;
+  const int grid = (int)min((total + 255) / 256, (long)DD_NUM_CU * 8);
+  hipLaunchKernelGGL(relu_bwd_pad_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dy, bits_pad, (f32x4*)out_pad,
+                     batch, h, w);
+  DD_LAUNCH_CHECK("relu_bwd_pad_bits");
   return 0;
 }
 

@@ -504,6 +504,24 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
   }
 }
 
+// the same between rectangular WINDOWS of the two buffers ([B, mem_h, mem_w, cstore] each, window origin (y0, x0), h x w pixels): the
+// interior of a padded activation into a concat slice, and back
+__global__ __launch_bounds__(256) void copy_channels_window_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w,
+                                                                   int c4, int s_mh, int s_mw, int s_y0, int s_x0, int s_cstore, int s_coff,
+                                                                   int d_mh, int d_mw, int d_y0, int d_x0, int d_cstore, int d_coff) {
+  const long total = (long)B * h * w * c4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    long p = i / c4;
+    const int x = (int)(p % w);
+    p /= w;
+    const int y = (int)(p % h);
+    const long b = p / h;
+    const long sp = (b * s_mh + s_y0 + y) * s_mw + s_x0 + x, dp = (b * d_mh + d_y0 + y) * d_mw + d_x0 + x;
+    *(f32x4*)(dst + dp * d_cstore + d_coff + c) = *(const f32x4*)(src + sp * s_cstore + s_coff + c);
+  }
+}
+
 // ---- ConvTranspose2d(32 -> 32, k2 s2) + bias + ReLU in ONE launch (the decoder's dc3, components.py:72,91; ss_deconv of the
 // box heads): the four output phases are four column tiles of one GEMM -- M = 32 input pixels, N = 4 x 32, K = 32 -- so
 // the input is read once (four generic 1x1 launches read it four times, 0.19 ms each at bs 32 for 80 MB in / 80 MB out).
@@ -1219,6 +1237,24 @@ int dd_copy_channels(const float* src, float* dst, int64_t npix, int32_t channel
   hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 16)), dim3(256), 0, (hipStream_t)stream, src,
                      dst, (long)npix, channels / 4, src_cstore, src_coff, dst_cstore, dst_coff);
   DD_LAUNCH_CHECK("copy_channels");
+  return 0;
+}
+
+int dd_copy_channels_window(const float* src, float* dst, int32_t batch, int32_t h, int32_t w, int32_t channels, int32_t src_mem_h,
+                            int32_t src_mem_w, int32_t src_y0, int32_t src_x0, int32_t src_cstore, int32_t src_coff, int32_t dst_mem_h,
+                            int32_t dst_mem_w, int32_t dst_y0, int32_t dst_x0, int32_t dst_cstore, int32_t dst_coff, void* stream) {
+  DD_REQUIRE(src && dst && batch > 0 && h > 0 && w > 0 && channels > 0, DD_ERR_BAD_ARG, "copy_channels_window: bad argument");
+  DD_REQUIRE(channels % 4 == 0 && src_cstore % 4 == 0 && src_coff % 4 == 0 && dst_cstore % 4 == 0 && dst_coff % 4 == 0 && src_coff >= 0 &&
+                 dst_coff >= 0 && src_coff + channels <= src_cstore && dst_coff + channels <= dst_cstore,
+             DD_ERR_UNSUPPORTED, "copy_channels_window: channel slices must be 4-aligned and inside their buffers");
+  DD_REQUIRE(src_y0 >= 0 && src_x0 >= 0 && src_y0 + h <= src_mem_h && src_x0 + w <= src_mem_w && dst_y0 >= 0 && dst_x0 >= 0 &&
+                 dst_y0 + h <= dst_mem_h && dst_x0 + w <= dst_mem_w,
+             DD_ERR_BAD_ARG, "copy_channels_window: a window leaves its buffer");
+  const long total = (long)batch * h * w * (channels / 4);
+  hipLaunchKernelGGL(copy_channels_window_kernel, dim3((unsigned)min((total + 255) / 256, (long)DD_NUM_CU * 16)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, batch, h, w, channels / 4, src_mem_h, src_mem_w, src_y0, src_x0, src_cstore, src_coff,
+                     dst_mem_h, dst_mem_w, dst_y0, dst_x0, dst_cstore, dst_coff);
+  DD_LAUNCH_CHECK("copy_channels_window");
   return 0;
 }
 

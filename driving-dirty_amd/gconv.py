@@ -407,10 +407,16 @@ class Layer:
 
 
 def copy_channels(src, dst):
-    """dst.buf[..., dst.coff : +chans] = src.buf[..., src.coff : +chans] (Views over whole NHWC buffers of equal pixel count)."""
-    assert src.chans == dst.chans and src.buf.shape[:3] == dst.buf.shape[:3]
-    for v in (src, dst):
-        assert v.off_h == 0 and v.off_w == 0 and v.h == v.buf.shape[1] and v.w == v.buf.shape[2]
+    """dst.buf[..., dst.coff : +chans] = src.buf[..., src.coff : +chans] over the Views' windows (equal h x w; whole buffers of equal
+    pixel count take the one-dimensional kernel)."""
+    assert src.chans == dst.chans and src.buf.shape[0] == dst.buf.shape[0] and (src.h, src.w) == (dst.h, dst.w)
+    whole = all(v.off_h == 0 and v.off_w == 0 and v.h == v.buf.shape[1] and v.w == v.buf.shape[2] for v in (src, dst))
+    if not whole:
+        check(_lib.lib().dd_copy_channels_window(_p(_chk(src.buf, "src")), _p(_chk(dst.buf, "dst")), src.buf.shape[0], src.h, src.w, src.chans,
+                                                 src.buf.shape[1], src.buf.shape[2], src.off_h, src.off_w, src.buf.shape[3], src.coff,
+                                                 dst.buf.shape[1], dst.buf.shape[2], dst.off_h, dst.off_w, dst.buf.shape[3], dst.coff,
+                                                 _stream()), "dd_copy_channels_window")
+        return
     npix = src.buf.shape[0] * src.buf.shape[1] * src.buf.shape[2]
     check(_lib.lib().dd_copy_channels(_p(_chk(src.buf, "src")), _p(_chk(dst.buf, "dst")), npix, src.chans, src.buf.shape[3], src.coff,
                                       dst.buf.shape[3], dst.coff, _stream()), "dd_copy_channels")

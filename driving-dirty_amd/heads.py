@@ -25,11 +25,38 @@ from .gconv import split_rows as gconv_split_rows
 TRACE = None
 
 
+def padded_nhwc(v):
+    """``v`` [B,H,W,C]: if it is a rectangular window of a dense NHWC buffer [B,Hm,Wm,C] that starts its storage (the interior of a padded
+    activation: SpatialMapFn's Winograd out_conv), return (that buffer, off_h, off_w); None otherwise."""
+    if v.dim() != 4 or v.is_contiguous():
+        return None
+    b, h, w, c = v.shape
+    sb, sh, sw, sc = v.stride()
+    if sc != 1 or sw != c or sh % c or sh < w * c:
+        return None
+    wm = sh // c
+    total = v.untyped_storage().nbytes() // v.element_size()
+    if b > 1:
+        if sb % sh:
+            return None
+        hm = sb // sh
+    else:
+        hm = total // sh
+    off = v.storage_offset()
+    if off % c or hm < h or total < b * hm * wm * c:
+        return None
+    off_h, off_w = (off // c) // wm, (off // c) % wm
+    if off_h + h > hm or off_w + w > wm:
+        return None
+    return v.as_strided((b, hm, wm, c), (hm * wm * c, wm * c, c, 1), 0), off_h, off_w
+
+
 def as_nhwc(t, cstore):
-    """NCHW-shaped tensor -> NHWC buffer [B,H,W,cstore]; free when ``t`` already is a channels-last view."""
+    """NCHW-shaped tensor -> NHWC buffer [B,H,W,cstore]; free when ``t`` already is a channels-last view (dense, or a window of a dense
+    NHWC buffer: ``padded_nhwc``)."""
     b, c, h, w = t.shape
     v = t.permute(0, 2, 3, 1)
-    if c == cstore and v.is_contiguous():
+    if c == cstore and (v.is_contiguous() or padded_nhwc(v) is not None):
         return v
     return ops.ToNHWC.apply(t, cstore)
 
@@ -106,6 +133,9 @@ _ORDER = ("f_conv", "fl_conv", "fr_conv", "b_conv", "bl_conv", "br_conv", "out_c
 
 
 
+WINO_OUT = True      # SpatialMapFn: out_conv on the Winograd kernels of the encoder's c2 layer (tests run both positions)
+
+
 class SpatialMapFn(torch.autograd.Function):
     """views [B,6,3,H,W] -> spatial map [B,256,256,32] (NHWC).  The six strip convs write their tile of the
     258x258 mosaic directly; rot90 / flip happen in the one pass that lays a view out as NHWC4."""
@@ -117,6 +147,15 @@ class SpatialMapFn(torch.autograd.Function):
     @staticmethod
     def _strip(name):
         return SpatialMapFn.FRONT if name in ("f_conv", "b_conv") else SpatialMapFn.SIDE
+
+    @staticmethod
+    def _wino_desc(mosaic):
+        """The c2-layer descriptor under which the Winograd kernels take out_conv on this mosaic, or None."""
+        b, mh, mw, c = mosaic.shape
+        if c != 32 or not mosaic.is_contiguous() or mh < 4 or mw < 4:
+            return None
+        d = ops.conv_desc(b, mh, mw, 32, 1)
+        return d if ops._lib.lib().dd_conv_wino2_packed_floats(ops.C.byref(d)) > 0 else None
 
     @staticmethod
     def forward(ctx, views, *params):
@@ -145,16 +184,27 @@ class SpatialMapFn(torch.autograd.Function):
             assert (oh, ow) == (th, tw), "the six strip convs must produce equal tiles"
             cls._strip(name).forward(p[name][0], p[name][1], View(xv), View(mosaic, 0, 32, tr * th, tc * tw, th, tw), EPI_BIAS_RELU)
         oh, ow = cls.OUT.out_hw(3 * th, 2 * tw)
-        out = _empty((b, oh, ow, 32), dev)
-        cls.OUT.forward(p["out_conv"][0], p["out_conv"][1], View(mosaic), View(out), EPI_BIAS_RELU)
+        ctx.wino = WINO_OUT and cls._wino_desc(mosaic) is not None
+        if ctx.wino:
+            # out_conv (32 -> 32, k3, padding 0) on the c2 layer's Winograd F(2x2,3x3) kernels: they compute the padding-1 convolution of the
+            # mosaic, whose interior is out_conv's output -- returned as a view, no crop pass; 4/9 of the multiplies (bs 32: forward 0.45 ->
+            # 0.22 ms, data gradient 0.51 -> 0.24, weight gradient 0.55 -> 0.26; tools/bench_outconv.py).  The backward runs from the sign
+            # words of this output; the 268 MB output itself is not kept.
+            d = cls._wino_desc(mosaic)
+            full, keep = ops.conv_wino2_fwd_bits(mosaic, ops.conv_wino2_pack(p["out_conv"][0], d, ops.PACK_FWD), p["out_conv"][1], d)
+            out = full[:, 1:1 + oh, 1:1 + ow, :]
+        else:
+            out = _empty((b, oh, ow, 32), dev)
+            cls.OUT.forward(p["out_conv"][0], p["out_conv"][1], View(mosaic), View(out), EPI_BIAS_RELU)
+            keep = out
         if TRACE is not None:
             TRACE.update(mosaic=mosaic, space_out=out, tile=(th, tw))
         if per_sample:
             ctx.samples = tuple(views)                      # inputs without gradients: plain references keep them alive
-            ctx.save_for_backward(mosaic, out, p["out_conv"][0])
+            ctx.save_for_backward(mosaic, keep, p["out_conv"][0])
         else:
             ctx.samples = None
-            ctx.save_for_backward(views, mosaic, out, p["out_conv"][0])
+            ctx.save_for_backward(views, mosaic, keep, p["out_conv"][0])
         ctx.tile = (th, tw)
         ctx.fused = fused
         ctx.laid = None if fused else laid                   # generic path: the six layouts are kept for the weight gradients (inputs without gradients: plain references)
@@ -168,11 +218,17 @@ class SpatialMapFn(torch.autograd.Function):
         else:
             views, mosaic, out, w_out = ctx.saved_tensors
         th, tw = ctx.tile
-        g = ops.relu_bwd(gout.contiguous(), out)
         grads = {}
-        grads["out_conv"] = cls.OUT.backward_weight(View(mosaic), View(g))
-        gm = _empty(mosaic.shape, mosaic.device)
-        cls.OUT.backward_data(w_out, View(g), View(gm), relu_src=mosaic)
+        if ctx.wino:      # `out` holds the sign words of the padded output here
+            d = cls._wino_desc(mosaic)
+            g = ops.relu_bwd_pad_bits(gout.contiguous(), out)      # dL/d(out_conv output) behind its ReLU, zero on the border ring the layer does not have
+            grads["out_conv"] = ops.conv_wino2_wgrad(mosaic, g, d)
+            gm = ops.conv_wino2_dgrad_bits(g, ops.conv_wino2_pack(w_out, d, ops.PACK_DGRAD_S1), ops.relu_sign_bits(mosaic), d)
+        else:
+            g = ops.relu_bwd(gout.contiguous(), out)
+            grads["out_conv"] = cls.OUT.backward_weight(View(mosaic), View(g))
+            gm = _empty(mosaic.shape, mosaic.device)
+            cls.OUT.backward_data(w_out, View(g), View(gm), relu_src=mosaic)
         if ctx.fused:                                       # six weight + bias gradients: one launch and a fixed-order reduce (csrc/strip6.hip)
             dws, dbs = gconv_mod.strip6_wgrad(views, gm)
             for k, (name, *_rest) in enumerate(_TILES):
@@ -240,7 +296,11 @@ class MergeFn(torch.autograd.Function):
             ops.deconv2x2_c32_fwd_into(s1, p_ssd[0].contiguous(), p_ssd[1], cat, 0, relu=True)
         else:
             cls.SS_DECONV.forward(p_ssd[0], p_ssd[1], View(s1), View(cat, 0, 32), EPI_BIAS_RELU)
-        copy_channels(View(space.contiguous()), View(cat, 32, 32))
+        base = padded_nhwc(space)
+        if base is None:
+            copy_channels(View(space.contiguous()), View(cat, 32, 32))
+        else:      # the interior of a padded activation (SpatialMapFn's Winograd out_conv): copied out of its window, no dense copy first
+            copy_channels(View(base[0], 0, 32, base[1], base[2], space.shape[1], space.shape[2]), View(cat, 32, 32))
         r1 = None
         if with_rm:
             r1 = ops.conv1ch_fwd(rm4, p_rm1[0], p_rm1[1], relu=True)      # rm_conv_1: taps as the K dimension (csrc/conv1ch.hip)

@@ -514,6 +514,27 @@ def relu_bwd(dy, y):
     return out
 
 
+def relu_sign_bits(x):
+    """int32 [B,H,W]: bit c = x[b,y,x,c] > 0 of an NHWC activation with 32 channels (dd_relu_sign_bits)."""
+    _dev(x, "x")
+    if x.dim() != 4 or x.shape[3] != 32:
+        raise _lib.HotpathError(f"relu_sign_bits: expected [B,H,W,32], got {tuple(x.shape)}")
+    bits = torch.empty(x.shape[:3], device=x.device, dtype=torch.int32)
+    check(_lib.lib().dd_relu_sign_bits(_p(x), _p(bits), bits.numel(), _stream()), "dd_relu_sign_bits")
+    return bits
+
+
+def relu_bwd_pad_bits(dy, bits_pad):
+    """dy [B,H,W,32], sign words [B,H+2,W+2] -> [B,H+2,W+2,32]: dy behind the ReLU in the interior, zero on the border ring."""
+    _dev(dy, "dy")
+    b, h, w, c = dy.shape
+    if c != 32 or not (bits_pad.is_cuda and bits_pad.dtype == torch.int32 and bits_pad.is_contiguous() and tuple(bits_pad.shape) == (b, h + 2, w + 2)):
+        raise _lib.HotpathError(f"relu_bwd_pad_bits: dy {tuple(dy.shape)} needs 32 channels and contiguous int32 sign words [B,H+2,W+2], got {tuple(bits_pad.shape)}")
+    out = torch.empty((b, h + 2, w + 2, 32), device=dy.device, dtype=torch.float32)
+    check(_lib.lib().dd_relu_bwd_pad_bits(_p(dy), _p(bits_pad), _p(out), b, h, w, _stream()), "dd_relu_bwd_pad_bits")
+    return out
+
+
 def pool4_fwd(feat):
     b, h, w, c = feat.shape
     _dev(feat, "feat")

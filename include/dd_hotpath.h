@@ -197,6 +197,16 @@ int dd_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias,
 /* out = dy * (y > 0), n elements (ReLU backward as a stand-alone pass). */
 int dd_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);
 
+/* Two helpers that let a padding-0 3x3 layer with 32 channels on both sides (SpatialMappingCNN.out_conv, spatial_bb/components.py:24,73:
+ * [B,258,258,32] -> [B,256,256,32]) run on the c2 layer's Winograd kernels below, which compute the padding-1 convolution of the same
+ * input: its outputs are the interior of theirs.
+ *   dd_relu_sign_bits: bits[p] bit c = x[p][c] > 0 for an NHWC activation of 32 channels -- the sign words dd_conv_*_fwd_relu_bits write
+ *     beside their own output, for an activation some other kernel produced (the data gradient's ReLU mask);
+ *   dd_relu_bwd_pad_bits: out_pad [B,h+2,w+2,32] = dy [B,h,w,32] where the sign word bits_pad [B,h+2,w+2] of that pixel has the channel's
+ *     bit set, zero elsewhere and on the border ring (outputs that do not exist in the padding-0 layer carry no gradient). */
+int dd_relu_sign_bits(const float* x, uint32_t* bits, int64_t npix, void* stream);
+int dd_relu_bwd_pad_bits(const float* dy, const uint32_t* bits_pad, float* out_pad, int32_t batch, int32_t h, int32_t w, void* stream);
+
 /* ---- NCHW-order max_pool1d(4) on an NHWC feature (K6) -----------------------------------
  * feat [B,H,W,C] NHWC.  The reference flattens the NCHW tensor and pools windows of 4 along
  * that vector (components.py:46-47); pooled[b, g] = max_{i<4} feat_nchw_flat[b, 4g+i],
@@ -497,6 +507,11 @@ int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias
  * gradient; everything a multiple of 4 channels. */
 int dd_copy_channels(const float* src, float* dst, int64_t npix, int32_t channels, int32_t src_cstore, int32_t src_coff,
                      int32_t dst_cstore, int32_t dst_coff, void* stream);
+/* The same between rectangular windows of the two buffers: src [B,src_mem_h,src_mem_w,src_cstore], window origin (src_y0, src_x0), and
+ * likewise dst; h x w pixels, `channels` channels from src_coff to dst_coff (the interior of a padded activation into a concat slice). */
+int dd_copy_channels_window(const float* src, float* dst, int32_t batch, int32_t h, int32_t w, int32_t channels, int32_t src_mem_h,
+                            int32_t src_mem_w, int32_t src_y0, int32_t src_x0, int32_t src_cstore, int32_t src_coff, int32_t dst_mem_h,
+                            int32_t dst_mem_w, int32_t dst_y0, int32_t dst_x0, int32_t dst_cstore, int32_t dst_coff, void* stream);
 /* out[i] = a[i] + b[i] (gradient fan-in of the shared views / feature), n % 4 == 0. */
 int dd_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* Mean binary cross-entropy on PROBABILITIES (spatial_w_rm.py:131 F.binary_cross_entropy; log clamped at -100 like

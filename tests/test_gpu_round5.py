@@ -319,6 +319,63 @@ def test_spatial_mapping_cnn_fused_strips_equal_the_generic_engine(dev):
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * float(gb[k].abs().max()), k
 
 
+def test_out_conv_on_the_winograd_kernels_equals_the_engine(dev):
+    """SpatialMappingCNN forward + backward with out_conv (32 -> 32, k3, padding 0) on the c2 layer's Winograd F(2x2,3x3) kernels (default:
+    the padding-1 convolution of the mosaic, whose interior is the layer's output, returned as a view) and on the dilated-conv engine
+    (heads.WINO_OUT off): same map, same gradients to the transforms' summation order -- and the merging head takes the view where it lies."""
+    from driving_dirty_amd import heads, synth
+    from driving_dirty_amd.spatial import SpatialMappingCNN
+    m = SpatialMappingCNN()
+    synth.fill_module(m, seed=17)
+    m = m.to(dev)
+    x = synth.camera_batch(3, seed=17).to(dev)
+    res = {}
+    for wino in (True, False):
+        prev, heads.WINO_OUT = heads.WINO_OUT, wino
+        try:
+            m.zero_grad(set_to_none=True)
+            y = m(x)
+            assert (heads.padded_nhwc(y.permute(0, 2, 3, 1)) is not None) == wino
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view(y.shape)).sum().backward()
+            res[wino] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        finally:
+            heads.WINO_OUT = prev
+    ya, ga = res[True]
+    yb, gb = res[False]
+    assert ya.shape == yb.shape and float((ya - yb).abs().max()) <= 5e-6 * float(yb.abs().max())
+    assert torch.equal(ya > 0, yb > 0) or float(((ya > 0) != (yb > 0)).float().mean()) < 1e-5
+    # two fp32 paths, each within the kernels' 2e-5 of the exact gradient (tests/test_gpu_heads.py holds either to the fp64 oracle): their
+    # difference may reach the sum of the two; measured 3.6e-5 on the strip weights, whose gradient sums 65 k positions of the data gradient
+    for k in gb:
+        assert float((ga[k] - gb[k]).abs().max()) <= 6e-5 * float(gb[k].abs().max()), k
+
+
+def test_sign_words_padded_relu_backward_and_window_copy(dev):
+    """The three helpers behind it: dd_relu_sign_bits, dd_relu_bwd_pad_bits, dd_copy_channels_window against torch, ragged sizes."""
+    from driving_dirty_amd import heads, ops
+    from driving_dirty_amd.gconv import View, copy_channels
+    torch.manual_seed(3)
+    for b, h, w in ((2, 5, 7), (3, 19, 33)):
+        x = torch.randn(b, h + 2, w + 2, 32, device=dev)
+        x[0, 0, 0, :] = 0.0                                   # zero is not positive
+        bits = ops.relu_sign_bits(x)
+        ref = ((x > 0).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
+        assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, ref)
+        dy = torch.randn(b, h, w, 32, device=dev)
+        got = ops.relu_bwd_pad_bits(dy, bits)
+        want = torch.zeros_like(x)
+        want[:, 1:-1, 1:-1] = dy * (x[:, 1:-1, 1:-1] > 0)
+        assert torch.equal(got, want)
+        dst = torch.full((b, h, w, 64), -1.0, device=dev)
+        inner = x[:, 1:-1, 1:-1, :]
+        base = heads.padded_nhwc(inner)
+        assert base is not None and base[1:] == (1, 1) and base[0].data_ptr() == x.data_ptr() and tuple(base[0].shape) == tuple(x.shape)
+        copy_channels(View(base[0], 0, 32, 1, 1, h, w), View(dst, 32, 32))
+        assert torch.equal(dst[..., 32:], inner) and float(dst[..., :32].max()) == -1.0
+    assert heads.padded_nhwc(torch.zeros(2, 4, 4, 32, device=dev)) is None
+    assert heads.padded_nhwc(torch.zeros(2, 4, 4, 64, device=dev)[..., :32]) is None      # a channel slice is not a spatial window
+
+
 def test_factor_mode_over_64_gathered_rows_falls_back_to_the_materialised_gradient(dev):
     """dd_adam_step_rankb takes at most 64 rows.  In ddp.GradSync factor mode the rows are world x batch: past 64 the optimizer forms the
     gathered gradient with dd_linear_wgrad as in round 4, and ``factor_bias`` tells ops.Linear.backward that the bias gradient is still
