@@ -79,13 +79,34 @@ class DecoderConvStack(torch.autograd.Function):
     L4 = Layer(32, 3, 1, transposed=True)
 
     @staticmethod
+    def _wino_desc(a1):
+        b, h, w, c = a1.shape
+        if c != 32 or h < 4 or w < 4:
+            return None
+        d = ops.conv_desc(b, h, w, 32, 1)
+        return d if ops._lib.lib().dd_conv_wino2_packed_floats(ops.C.byref(d)) > 0 else None
+
+    @staticmethod
+    def _as_conv(w):
+        """ConvTranspose2d weight [Cin,Cout,3,3] <-> the Conv2d weight [Cout,Cin,3,3] of the same map (stride 1): transposed and flipped."""
+        return w.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+
+    @staticmethod
     def forward(ctx, h, dh, dw, w1, b1, w2, b2, w3, b3, w4, b4):
         cls = DecoderConvStack
         b, dev = h.shape[0], h.device
         x0 = ops.nchw_to_nhwc(h.contiguous().view(b, 64, dh, dw), 64)
-        a1, a2 = _empty((b, dh, dw, 32), dev), _empty((b, dh, dw, 32), dev)
+        a1 = _empty((b, dh, dw, 32), dev)
         cls.L1.forward(w1, b1, View(x0), View(a1), EPI_BIAS_RELU)
-        cls.L2.forward(w2, b2, View(a1), View(a2), EPI_BIAS_RELU)
+        ctx.wino = WINO_DC2 and cls._wino_desc(a1) is not None
+        if ctx.wino:
+            # dc2 = ConvTranspose2d(32 -> 32, k3, padding 1): a padding-1 convolution with the weights transposed and flipped -- exactly the
+            # encoder's c2 layer, so it runs on that layer's Winograd F(2x2,3x3) kernels (4/9 of the multiplies)
+            d = cls._wino_desc(a1)
+            a2, _ = ops.conv_wino2_fwd_bits(a1, ops.conv_wino2_pack(cls._as_conv(w2), d, ops.PACK_FWD), b2, d)
+        else:
+            a2 = _empty((b, dh, dw, 32), dev)
+            cls.L2.forward(w2, b2, View(a1), View(a2), EPI_BIAS_RELU)
         if dw >= 32:      # dc3 in one launch (four phases = four column tiles), dc4 straight to the NCHW output
             a3 = ops.deconv2x2_c32_fwd(a2, w3.contiguous(), b3, relu=True)
             y = ops.conv1x1_c32_c3_nchw(a3, w4.contiguous(), b4)
@@ -112,9 +133,15 @@ class DecoderConvStack(torch.autograd.Function):
         dw3, db3 = cls.L3.backward_weight(View(a2), View(g3))
         g2 = _empty(a2.shape, dev)
         cls.L3.backward_data(w3, View(g3), View(g2), relu_src=a2)
-        dw2, db2 = cls.L2.backward_weight(View(a1), View(g2))
-        g1 = _empty(a1.shape, dev)
-        cls.L2.backward_data(w2, View(g2), View(g1), relu_src=a1)
+        if ctx.wino:
+            d = cls._wino_desc(a1)
+            dwc, db2 = ops.conv_wino2_wgrad(a1, g2, d)
+            dw2 = cls._as_conv(dwc)                          # the map is its own inverse
+            g1 = ops.conv_wino2_dgrad_bits(g2, ops.conv_wino2_pack(cls._as_conv(w2), d, ops.PACK_DGRAD_S1), ops.relu_sign_bits(a1), d)
+        else:
+            dw2, db2 = cls.L2.backward_weight(View(a1), View(g2))
+            g1 = _empty(a1.shape, dev)
+            cls.L2.backward_data(w2, View(g2), View(g1), relu_src=a1)
         dw1, db1 = cls.L1.backward_weight(View(x0), View(g1))
         gh = None
         if ctx.needs_input_grad[0]:
@@ -134,6 +161,7 @@ _ORDER = ("f_conv", "fl_conv", "fr_conv", "b_conv", "bl_conv", "br_conv", "out_c
 
 
 WINO_OUT = True      # SpatialMapFn: out_conv on the Winograd kernels of the encoder's c2 layer (tests run both positions)
+WINO_DC2 = True      # DecoderConvStack: dc2 likewise
 
 
 class SpatialMapFn(torch.autograd.Function):

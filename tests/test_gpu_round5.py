@@ -350,6 +350,37 @@ def test_out_conv_on_the_winograd_kernels_equals_the_engine(dev):
         assert float((ga[k] - gb[k]).abs().max()) <= 6e-5 * float(gb[k].abs().max()), k
 
 
+@pytest.mark.parametrize("dh,dw", [(16, 20), (128, 153)])
+def test_decoder_dc2_on_the_winograd_kernels_equals_the_engine(dev, dh, dw):
+    """DecoderConvStack with dc2 (ConvTranspose2d 32 -> 32, k3, padding 1 = a padding-1 convolution with transposed, flipped weights) on the
+    c2 layer's Winograd kernels (default) and on the dilated-conv engine (heads.WINO_DC2 off): output and every gradient to summation order."""
+    from driving_dirty_amd import heads
+    torch.manual_seed(23)
+    b = 2
+    h = torch.randn(b, 64 * dh * dw, device=dev, requires_grad=True)
+    ws = [torch.randn(64, 32, 3, 3, device=dev) * 0.06, torch.randn(32, device=dev) * 0.1, torch.randn(32, 32, 3, 3, device=dev) * 0.08,
+          torch.randn(32, device=dev) * 0.1, torch.randn(32, 32, 2, 2, device=dev) * 0.1, torch.randn(32, device=dev) * 0.1,
+          torch.randn(32, 3, 1, 1, device=dev) * 0.2, torch.randn(3, device=dev) * 0.1]
+    for t in ws:
+        t.requires_grad_(True)
+    res = {}
+    for wino in (True, False):
+        prev, heads.WINO_DC2 = heads.WINO_DC2, wino
+        try:
+            for t in [h] + ws:
+                t.grad = None
+            y = heads.DecoderConvStack.apply(h, dh, dw, *ws)
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view(y.shape)).sum().backward()
+            res[wino] = (y.detach().clone(), [t.grad.detach().clone() for t in [h] + ws])
+        finally:
+            heads.WINO_DC2 = prev
+    ya, ga = res[True]
+    yb, gb = res[False]
+    assert float((ya - yb).abs().max()) <= 5e-6 * float(yb.abs().max())
+    for i, (a, r) in enumerate(zip(ga, gb)):
+        assert float((a - r).abs().max()) <= 4e-5 * float(r.abs().max()), i
+
+
 def test_sign_words_padded_relu_backward_and_window_copy(dev):
     """The three helpers behind it: dd_relu_sign_bits, dd_relu_bwd_pad_bits, dd_copy_channels_window against torch, ragged sizes."""
     from driving_dirty_amd import heads, ops
