@@ -13,6 +13,7 @@ run bench_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench
 run bbox_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bbox_stats -o b -- python3 bench.py --config 3 --steps 4 --warmup 2
 run joint_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/joint_stats -o b -- python3 bench.py --config 4 --steps 4 --warmup 2
 run bf16_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_stats -o b -- python3 bench.py --config 5 --steps 4 --warmup 2
+run ae_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/ae_stats -o b -- python3 tools/profile_ae.py 32
 run mfma $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o p -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-others
 run up_sq $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/up_sq -o p -- python3 tools/bench_gconv.py --batch 32 --only up
 run up_wait $P --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/up_wait -o p -- python3 tools/bench_gconv.py --batch 32 --only up
@@ -20,7 +21,8 @@ run fetch $P --pmc FETCH_SIZE -d $O/fetch -o p -- python3 tools/bench_one.py win
 run write $P --pmc WRITE_SIZE -d $O/write -o p -- python3 tools/bench_one.py wino2_fwd,wino2_dgrad_w1,wino2_wgrad
 run up_fetch $P --pmc FETCH_SIZE -d $O/up_fetch -o p -- python3 tools/bench_gconv.py --batch 32 --only up
 run up_write $P --pmc WRITE_SIZE -d $O/up_write -o p -- python3 tools/bench_gconv.py --batch 32 --only up
-for n in bench bbox joint bf16; do cp $O/${n}_stats/b_kernel_stats.csv profiles/${R}_${n}_kernel_stats.csv 2>/dev/null; done
+for n in bench bbox joint bf16 ae; do cp $O/${n}_stats/b_kernel_stats.csv profiles/${R}_${n}_kernel_stats.csv 2>/dev/null; done
+mv profiles/${R}_ae_kernel_stats.csv profiles/${R}_ae_bs32_kernel_stats.csv 2>/dev/null
 mv profiles/${R}_bbox_kernel_stats.csv profiles/${R}_bbox_bs32_kernel_stats.csv 2>/dev/null
 python3 tools/pmc_mfma.py $O/mfma gpurun_out/${R}_mfma_util.json > $O/mfma_sum.log 2>&1
 python3 tools/pmc_sq.py gpurun_out/${R}_upconv_sq_counters.json $O/up_sq $O/up_wait > $O/up_sq_sum.log 2>&1
