@@ -93,6 +93,7 @@ SIGNATURES = {
     "dd_relu_bwd_pad_bits": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_pool4_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_pool4_relu_bwd_add": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_idx_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "dd_pool4_fwd_idx": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_idx_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),

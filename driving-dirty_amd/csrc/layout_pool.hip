@@ -310,6 +310,56 @@ __global__ __launch_bounds__(256) void pool4_bwd_tile32(const float* __restrict_
   }
 }
 
+// The c3 feature has TWO consumers in the joint roadmap + box model (the pool in front of fc1, and the box heads): its gradient is
+//   dfeat = (feat > 0) * (gfeat + route(dpooled)),   route = dpooled at the first maximum of each window, 0 elsewhere
+// -- three passes over 481 MB tensors as relu_bwd + pool4_bwd + add (0.75 ms at bs 32), one here: the gradient tile comes in through
+// LDS, thread = (window, 4 channels) reads the window's four pixels of feat and gfeat and writes four whole 128-byte lines with its
+// seven neighbours.  Same arithmetic: (feat > 0 ? gfeat : 0) + (routed, if the maximum is positive), one fp32 add per element.
+__global__ __launch_bounds__(256) void pool4_bwd_add_tile32(const float* __restrict__ dpooled, const f32x4* __restrict__ feat,
+                                                            const f32x4* __restrict__ gfeat, f32x4* __restrict__ dfeat, long quads,
+                                                            int qblocks) {
+  __shared__ float g[32][65];
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x / qblocks;
+  const long q0 = (long)(blockIdx.x - b * qblocks) * 64;
+  const int nq = (int)min(64L, quads - q0);
+  const float* gp = dpooled + b * (quads * 32) + q0;
+  const int qq = tid & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = (tid >> 6) + 4 * j;
+    g[c][qq] = qq < nq ? gp[(long)c * quads + qq] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + 256 * k;                    // (window i >> 3, channel group i & 7) of the tile
+    const int qd = i >> 3, c4 = i & 7;
+    if (qd >= nq) continue;
+    const long base = ((b * quads + q0 + qd) * 4) * 8 + c4;      // pixel 4 (q0 + qd), chunk c4; a pixel is 8 chunks of 16 bytes
+    f32x4 v[4], u[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      v[p] = __builtin_nontemporal_load(feat + base + 8 * p);
+      u[p] = __builtin_nontemporal_load(gfeat + base + 8 * p);
+    }
+    f32x4 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float m = v[0][j];
+      int am = 0;
+#pragma unroll
+      for (int p = 1; p < 4; ++p)
+        if (v[p][j] > m) { m = v[p][j]; am = p; }
+      const float gv = (m > 0.f) ? g[4 * c4 + j][qd] : 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) d[p][j] = (v[p][j] > 0.f ? u[p][j] : 0.f) + (am == p ? gv : 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) __builtin_nontemporal_store(d[p], dfeat + base + 8 * p);
+  }
+}
+
 __global__ __launch_bounds__(256) void pool4_bwd_quad(const float* __restrict__ dpooled,
                                                       const f32x4* __restrict__ feat, f32x4* __restrict__ dfeat,
                                                       int B, long HW, int C) {
@@ -580,6 +630,19 @@ int dd_pool4_relu_bwd(const float* dpooled, const float* feat, float* dfeat, int
                        batch, HW, c);
   }
   DD_LAUNCH_CHECK("pool4_bwd");
+  return 0;
+}
+
+int dd_pool4_relu_bwd_add(const float* dpooled, const float* feat, const float* gfeat, float* dfeat, int32_t batch, int32_t h, int32_t w,
+                          int32_t c, void* stream) {
+  DD_REQUIRE(dpooled && feat && gfeat && dfeat && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "pool4_relu_bwd_add: bad argument");
+  DD_REQUIRE(c == 32 && ((long)h * w) % 4 == 0, DD_ERR_UNSUPPORTED, "pool4_relu_bwd_add: needs C == 32 and H*W %% 4 == 0 (got %dx%d, C %d)", h, w, c);
+  DD_REQUIRE((((uintptr_t)feat | (uintptr_t)gfeat | (uintptr_t)dfeat) & 15) == 0, DD_ERR_BAD_ARG, "pool4_relu_bwd_add: 16-byte alignment");
+  const long quads = (long)h * w / 4, qblocks = (quads + 63) / 64;
+  DD_REQUIRE(batch * qblocks < (1L << 31), DD_ERR_UNSUPPORTED, "pool4_relu_bwd_add: too many tiles");
+  hipLaunchKernelGGL(pool4_bwd_add_tile32, dim3((unsigned)(batch * qblocks)), dim3(256), 0, (hipStream_t)stream, dpooled, (const f32x4*)feat,
+                     (const f32x4*)gfeat, (f32x4*)dfeat, quads, (int)qblocks);
+  DD_LAUNCH_CHECK("pool4_relu_bwd_add");
   return 0;
 }
 

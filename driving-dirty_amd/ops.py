@@ -571,6 +571,17 @@ def pool4_idx_relu_bwd(dpooled, idx, shape):
     return out
 
 
+def pool4_relu_bwd_add(dpooled, feat, gfeat):
+    """(feat > 0) * (gfeat + routed dpooled): the c3 feature's gradient when both the pool and the box heads consume it, one pass."""
+    b, h, w, c = feat.shape
+    _dev(dpooled, "dpooled", (b, (c * h * w) // 4))
+    _dev(feat, "feat")
+    _dev(gfeat, "gfeat", feat.shape)
+    out = torch.empty_like(feat)
+    check(_lib.lib().dd_pool4_relu_bwd_add(_p(dpooled), _p(feat), _p(gfeat), _p(out), b, h, w, c, _stream()), "dd_pool4_relu_bwd_add")
+    return out
+
+
 def pool4_relu_bwd(dpooled, feat):
     b, h, w, c = feat.shape
     _dev(dpooled, "dpooled", (b, (c * h * w) // 4))
@@ -694,12 +705,15 @@ class EncoderConvStack(torch.autograd.Function):
         rpt = ctx.rows_per_task
         d1, d2, d3 = conv_desc(b, h, w, 3, 1, rpt), conv_desc(b, h, w, 32, 1, rpt), conv_desc(b, h, w, 32, 2, rpt)
         if ctx.pool == 2:                     # two consumers of the c3 feature: their gradients add
-            parts = []
-            if grad is not None:
-                parts.append(relu_bwd(grad.contiguous(), a3))
-            if grad_pooled is not None:
-                parts.append(pool4_relu_bwd(grad_pooled.contiguous(), a3))
-            g3 = parts[0] if len(parts) == 1 else add(parts[0], parts[1])
+            if grad is not None and grad_pooled is not None and a3.shape[3] == 32 and (a3.shape[1] * a3.shape[2]) % 4 == 0:
+                g3 = pool4_relu_bwd_add(grad_pooled.contiguous(), a3, grad.contiguous())      # one pass instead of three over the 481 MB feature
+            else:
+                parts = []
+                if grad is not None:
+                    parts.append(relu_bwd(grad.contiguous(), a3))
+                if grad_pooled is not None:
+                    parts.append(pool4_relu_bwd(grad_pooled.contiguous(), a3))
+                g3 = parts[0] if len(parts) == 1 else add(parts[0], parts[1])
         else:
             grad = grad.contiguous()
             if ctx.codes:

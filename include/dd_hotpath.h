@@ -220,6 +220,11 @@ int dd_pool4_relu_bwd(const float* dpooled, const float* feat, float* dfeat, int
  * (4 bits per window: index of the first maximum | (max > 0) << 2; dd_pool4_idx_elems of them, -1 when H*W or C
  * is not a multiple of 4), and dd_pool4_idx_relu_bwd scatters dpooled from those codes alone -- the 481 MB c3
  * feature (components.py:43) is neither kept for nor re-read by the backward. */
+/* The joint roadmap + box model feeds the c3 feature to the pool AND to the box heads (joint_model: both losses on one encoder pass):
+ * dfeat = (feat > 0) * (gfeat + routed dpooled) in ONE pass -- dd_relu_bwd(gfeat, feat) + dd_pool4_relu_bwd(dpooled, feat) + dd_add, same
+ * arithmetic.  C == 32, H*W % 4 == 0, 16-byte aligned tensors. */
+int dd_pool4_relu_bwd_add(const float* dpooled, const float* feat, const float* gfeat, float* dfeat, int32_t batch, int32_t h, int32_t w,
+                          int32_t c, void* stream);
 int64_t dd_pool4_idx_elems(int32_t batch, int32_t h, int32_t w, int32_t c);
 int dd_pool4_fwd_idx(const float* feat, float* pooled, uint16_t* idx, int32_t batch, int32_t h, int32_t w, int32_t c,
                      void* stream);

@@ -381,6 +381,21 @@ def test_decoder_dc2_on_the_winograd_kernels_equals_the_engine(dev, dh, dw):
         assert float((a - r).abs().max()) <= 4e-5 * float(r.abs().max()), i
 
 
+@pytest.mark.parametrize("b,h,w", [(2, 8, 11), (3, 16, 34), (1, 128, 918)])
+def test_joint_feature_gradient_in_one_pass_equals_the_three(dev, b, h, w):
+    """dd_pool4_relu_bwd_add: the c3 feature's gradient when the pool AND the box heads consume it, (feat > 0) * (gfeat + routed dpooled),
+    bit for bit what dd_relu_bwd + dd_pool4_relu_bwd + dd_add give (ties to the first index, zero maxima closed), ragged last tiles."""
+    from driving_dirty_amd import ops
+    torch.manual_seed(b * 100 + w)
+    feat = torch.relu(torch.randn(b, h, w, 32, device=dev))
+    feat = (feat * 4).round() / 4                       # ties and all-zero windows
+    gfeat = torch.randn_like(feat)
+    dpooled = torch.randn(b, 32 * h * w // 4, device=dev)
+    want = ops.add(ops.relu_bwd(gfeat, feat), ops.pool4_relu_bwd(dpooled, feat))
+    got = ops.pool4_relu_bwd_add(dpooled, feat, gfeat)
+    assert torch.equal(got, want)
+
+
 def test_sign_words_padded_relu_backward_and_window_copy(dev):
     """The three helpers behind it: dd_relu_sign_bits, dd_relu_bwd_pad_bits, dd_copy_channels_window against torch, ragged sizes."""
     from driving_dirty_amd import heads, ops
