@@ -570,6 +570,11 @@ int dd_dconv_fwd(const float* x, const float* packed, const float* bias, const f
     DD_LAUNCH_CHECK("dconv_tfwd");
     return 0;
   }
+  // up_conv_4's forward (16 -> 8, k7 d3): input-aligned, four tap columns packed into one column tile (dconv_t.hip)
+  if (!mask && dd_dconv_tfwd8_launch(x, packed, bias, y, d, epilogue, st)) {
+    DD_LAUNCH_CHECK("dconv_tfwd8");
+    return 0;
+  }
   // the data gradient of the 96->64 / 64->32 layers: one output row per workgroup, unrolled tap columns (dconv_t.hip)
   if (dd_dconv_gfwd_launch(x, packed, bias, mask, y, d, epilogue, wp_bytes, st)) {
     DD_LAUNCH_CHECK("dconv_gfwd");

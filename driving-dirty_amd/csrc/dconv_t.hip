@@ -594,3 +594,203 @@ bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias
 #undef DD_GF
   return false;
 }
+
+namespace {
+
+// =====================================================================================================================
+// up_conv_4's forward (ConvTranspose2d 16 -> 8, k7, dilation 3: spatial_bb/components.py:138), input-aligned like dconv_tfwd_kernel, with
+// FOUR TAP COLUMNS PACKED INTO ONE COLUMN TILE.  Cout = 8 fills a quarter of a 32-wide tile (half of a 16-wide one: the gather kernel it
+// ran on, dconv_fwd_kernel<7, 3, 0>, reached 0.32 of the fp32 pipe, the least of any matrix kernel of the box heads).  In the input-aligned
+// form the A operand -- 32 input pixels x 8 channels -- is the same for every tap column; only the weights and the output shift differ.
+// So the B tile is [kx = 4g: 8 co | 4g + 1 | 4g + 2 | 4g + 3] for g = 0, 1 (column 7 of g = 1 is zero): 7/8 of every MFMA is useful, two
+// accumulator tiles per m-tile instead of seven, and lane (kxl = col >> 3, co = col & 7) adds its column at ITS shift pad_w - D kx.
+//   * a workgroup (8 waves) owns one output row; per tap row ky the input row oy - pad_h + D ky (in_w pixels x 16 channels, 80-byte pixel
+//     pitch: an odd number of 16-byte slots, conflict-free ds_read_b128) sits in LDS, double buffered across tap rows AND tasks;
+//   * all 49 x 16 x 8 weights sit in LDS for the workgroup's life (28 KB, re-laid from the standard image once);
+//   * 12 m-tiles x 2 groups = 24 tiles, three per wave (all of one group and one m-tile parity: the epilogue's four barrier-separated
+//     classes -- (group, parity) -- never touch the same pixel from two waves; within a wave LDS operations are ordered).
+template <int K, int D>
+__global__ __launch_bounds__(TF_THREADS) void dconv_tfwd8_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 const dd_gconv_desc d, int epi) {
+  constexpr int IWP = 384, PITCH = 80;     // bytes per pixel of a row image (16 channels + 16 bytes)
+  constexpr int ROWB = IWP * PITCH;
+  constexpr int HALO = D * (K - 1);
+  constexpr int NPR = (IWP * 4 + TF_THREADS - 1) / TF_THREADS;      // 16-byte pieces per thread and row
+  constexpr int IMGF = (IWP + HALO) * 8;                   // floats of the output row image: 8 channels per pixel
+  __shared__ __attribute__((aligned(16))) char rows[2][ROWB];
+  __shared__ __attribute__((aligned(16))) f32x4 wl[K][2][2][64];
+  __shared__ __attribute__((aligned(16))) float img[4][IMGF];      // one plane per tap column of a group (see the epilogue)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, n = lane & 31;
+  const int g = wave & 1;                                   // this wave's tap-column group; its m-tiles: (wave >> 1) + 4 j
+  const int in_bytes = d.in_h * d.in_w * d.in_cstore * 4;
+  const int out_bytes = d.omem_h * d.omem_w * d.out_cstore * 4;
+
+  // ---- weights: wl[ky][g][q][l] = four channels (8q + 4h + j) of column (kxl = n >> 3, co = n & 7) of tap (ky, 4g + kxl), from the standard
+  // image of dd_dconv_pack for Cout <= 16: wp[((q*T + tap)*64 + ((c8 >> 1) << 4 | co))*2 + (c8 & 1)], c8 = the channel inside its chunk
+  for (int i = tid; i < K * 2 * 2 * 64; i += TF_THREADS) {
+    const int l = i & 63, q = (i >> 6) & 1, gg = (i >> 7) & 1, ky = i >> 8;
+    const int kx = 4 * gg + ((l & 31) >> 3), co = l & 7, hh = l >> 5;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kx < K && co < d.cout) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c8 = 4 * hh + j;
+        v[j] = wp[((q * (K * K) + ky * K + kx) * 64 + (((c8 >> 1) << 4) | co)) * 2 + (c8 & 1)];
+      }
+    }
+    wl[ky][gg][q][l] = v;
+  }
+
+  // ---- fill plan: piece p = tid + 512 i of a row -> pixel p >> 2, 16-byte slot p & 3
+  int goff[NPR], loff[NPR];
+#pragma unroll
+  for (int i = 0; i < NPR; ++i) {
+    const int p = tid + TF_THREADS * i, px = p >> 2, sl = p & 3;
+    goff[i] = (px < d.in_w) ? (px * d.in_cstore + d.in_coff + 4 * sl) * 4 : (int)0xC0000000;
+    loff[i] = (px < IWP) ? px * PITCH + sl * 16 : -1;
+  }
+  // per-lane constants of the epilogue: element r of a tile -> float index (32 mt + row(r, h) + shift) * 8 + co
+  const int kx_lane = 4 * g + (n >> 3);
+  const bool col_ok = kx_lane < K && (n & 7) < d.cout;
+  const int e_lane = (n >> 3) * IMGF + (4 * h + d.pad_w - D * kx_lane) * 8 + (n & 7);      // (the launcher checked pad_w == D (K - 1): every shift >= 0)
+
+  // ---- tasks: as dconv_tfwd_kernel -- XCD = blockIdx % 8 owns an eighth of the (image, residue class, phase row) list
+  const int rows_max = (d.out_h + D - 1) / D;
+  const int per_x = gridDim.x >> 3, xcd = blockIdx.x & 7;
+  const int per_img = D * rows_max;
+  const long len = (long)d.batch * per_img;
+  const long seg1 = len * (xcd + 1) / 8;
+  auto decode = [&](long t, TfTask& k) -> bool {
+    k.b = (int)(t / per_img);
+    const int rem = (int)(t - (long)k.b * per_img);
+    const int r = rem / rows_max, jy = rem - r * rows_max;
+    k.nt = 0;
+    k.oy = r + D * jy;
+    k.ry = k.oy - d.pad_h;
+    k.ky0 = k.ry >= 0 ? 0 : (-k.ry + D - 1) / D;
+    k.ky1 = min(K - 1, (d.in_h - 1 - k.ry) >= 0 ? (d.in_h - 1 - k.ry) / D : -1);
+    return k.oy < d.out_h && k.ky1 >= k.ky0;
+  };
+  auto next_task = [&](long t, TfTask& k) -> long {
+    while (t < seg1 && !decode(t, k)) t += per_x;
+    return t < seg1 ? t : seg1;
+  };
+  auto request = [&](const TfTask& k, int ky, f32x4 (&st)[NPR]) {
+    const __amdgpu_buffer_rsrc_t xs = dd_rsrc(x + (long)k.b * d.in_h * d.in_w * d.in_cstore, in_bytes);
+    const int rowoff = (k.ry + D * ky) * d.in_w * d.in_cstore * 4;
+#pragma unroll
+    for (int i = 0; i < NPR; ++i) st[i] = dd_bload4(xs, (int)((unsigned)goff[i] + (unsigned)rowoff));
+  };
+  auto retire = [&](int buf, const f32x4 (&st)[NPR]) {
+#pragma unroll
+    for (int i = 0; i < NPR; ++i)
+      if (loff[i] >= 0) *(f32x4*)(rows[buf] + loff[i]) = st[i];
+  };
+
+  TfTask cur, nxt;
+  long t = next_task(len * xcd / 8 + (blockIdx.x >> 3), cur);
+  if (t >= seg1) return;
+  f32x4 stage[NPR];
+  request(cur, cur.ky0, stage);
+  retire(0, stage);
+  __syncthreads();                                          // weights and the first row
+  int par = 0;
+  while (t < seg1) {
+    const long tn = next_task(t + per_x, nxt);
+    const bool have_next = tn < seg1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int ky = cur.ky0; ky <= cur.ky1; ++ky) {
+      const bool lastk = ky == cur.ky1;
+      const bool st = !lastk || have_next;
+      if (st) request(lastk ? nxt : cur, lastk ? nxt.ky0 : ky + 1, stage);
+      __builtin_amdgcn_sched_barrier(0);
+      const char* rb = rows[par] + n * PITCH + h * 16;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 B = wl[ky][g][q][lane];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int mt = (wave >> 1) + 4 * i;
+          const f32x4 A = *(const f32x4*)(rb + mt * 32 * PITCH + q * 32);
+          acc[i] = DD_MFMA(A.x, B.x, acc[i]);
+          acc[i] = DD_MFMA(A.y, B.y, acc[i]);
+          acc[i] = DD_MFMA(A.z, B.z, acc[i]);
+          acc[i] = DD_MFMA(A.w, B.w, acc[i]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (st) retire(par ^ 1, stage);
+      if (!lastk) {
+        tf_barrier();
+        par ^= 1;
+      }
+    }
+    // ---- epilogue: zero the row image, add the tiles class by class, write the row out.  (The fill of the next task's first row was
+    // retired into the other buffer above; the barriers below publish it too.)  The image has FOUR PLANES, one per tap column of a group:
+    // inside a tile the columns of different taps land on the same output pixel from different accumulator rows (row + shift), and a
+    // batched read-add-write of all 16 rows would lose one of the two; per plane a tile's lanes never meet, the write-out adds the planes.
+    for (int i = tid; i < 4 * IMGF / 4; i += TF_THREADS) ((f32x4*)&img[0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    tf_barrier();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c == ((wave & 1) | (((wave >> 1) & 1) << 1)) && col_ok) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float* p0 = &img[0][0] + e_lane + ((wave >> 1) + 4 * i) * 256;
+          float tv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) tv[e] = p0[((e & 3) + 8 * (e >> 2)) * 8];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) p0[((e & 3) + 8 * (e >> 2)) * 8] = tv[e] + acc[i][e];
+        }
+      }
+      tf_barrier();
+    }
+    {
+      const __amdgpu_buffer_rsrc_t ys = dd_rsrc(y + (long)cur.b * d.omem_h * d.omem_w * d.out_cstore, out_bytes);
+      const int base = ((cur.oy + d.ooff_h) * d.omem_w + d.ooff_w) * d.out_cstore + d.out_coff;
+      for (int i = tid; i < d.out_w * 2; i += TF_THREADS) {      // 16-byte pieces: pixel i >> 1, channels 4 (i & 1) ..
+        const int px = i >> 1, c4 = 4 * (i & 1);
+        f32x4 o = (*(const f32x4*)&img[0][px * 8 + c4] + *(const f32x4*)&img[1][px * 8 + c4]) +
+                  (*(const f32x4*)&img[2][px * 8 + c4] + *(const f32x4*)&img[3][px * 8 + c4]);
+        if (epi == DD_EPI_BIAS || epi == DD_EPI_BIAS_RELU) {
+          o.x += c4 + 0 < d.cout ? bias[c4 + 0] : 0.f; o.y += c4 + 1 < d.cout ? bias[c4 + 1] : 0.f;
+          o.z += c4 + 2 < d.cout ? bias[c4 + 2] : 0.f; o.w += c4 + 3 < d.cout ? bias[c4 + 3] : 0.f;
+        }
+        if (epi == DD_EPI_BIAS_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        const int off = c4 < d.cout ? (base + px * d.out_cstore + c4) * 4 : -16;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), ys, off, 0, 0);
+      }
+    }
+    tf_barrier();
+    par ^= 1;
+    cur = nxt;
+    t = tn;
+  }
+}
+
+}  // namespace
+
+bool dd_dconv_tfwd8_launch(const float* x, const float* packed, const float* bias, float* y, const dd_gconv_desc* d, int epilogue,
+                           hipStream_t st) {
+  if (!dd_dconv_desc_ok(d)) return false;
+  if (epilogue != DD_EPI_NONE && epilogue != DD_EPI_BIAS && epilogue != DD_EPI_BIAS_RELU) return false;
+  if (d->kh != 7 || d->kw != 7 || d->dil_h != 3 || d->dil_w != 3 || d->pad_h != 18 || d->pad_w != 18) return false;
+  if (d->cin != 16 || d->cout < 1 || d->cout > 8 || d->cout % 4 || d->out_coff % 4 || d->out_cstore % 4) return false;
+  if (d->in_w > 384 || d->in_w < 32 || d->out_w != d->in_w + 18 || d->out_h != d->in_h + 18) return false;
+  if ((long)d->in_h * d->in_w * d->in_cstore * 4 >= (1L << 30)) return false;
+  if (((uintptr_t)bias & 3) != 0) return false;
+  const int grid = dd_cu_budget_internal() & ~7;
+  if (grid < 8) return false;
+  hipLaunchKernelGGL((dconv_tfwd8_kernel<7, 3>), dim3(grid), dim3(TF_THREADS), 0, st, x, packed, bias, y, *d, epilogue);
+  return true;
+}

@@ -89,6 +89,8 @@ __device__ __forceinline__ void dd_range(long total, int i, int n, long& idx, lo
 bool dd_dconv_desc_ok(const dd_gconv_desc* d);      // dconv.hip: the eligibility test of dd_dconv_fwd, for its two specialised launchers
 bool dd_dconv_tfwd_launch(const float* x, const float* packed, const float* bias, float* y, const dd_gconv_desc* d, int epilogue,
                           int wp_bytes, hipStream_t st);
+bool dd_dconv_tfwd8_launch(const float* x, const float* packed, const float* bias, float* y, const dd_gconv_desc* d, int epilogue,
+                           hipStream_t st);      // dconv_t.hip: up_conv_4's forward, four tap columns per column tile
 bool dd_dconv_gfwd_launch(const float* x, const float* packed, const float* bias, const float* mask, float* y, const dd_gconv_desc* d,
                           int epilogue, int wp_bytes, hipStream_t st);
 // dconv_m.hip: gather form with several output rows per workgroup (rows that are not a whole number of 8 m-tiles); false = not one of its layers.

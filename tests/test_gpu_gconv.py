@@ -72,6 +72,12 @@ CASES = [
     ("bm_up3_wide_op2", lambda: nn.ConvTranspose2d(16, 8, 6, dilation=6, output_padding=2), (1, 16, 20, 110)),
     ("bm_up2_32_16_k8d8", lambda: nn.ConvTranspose2d(32, 16, 8, dilation=8), (2, 32, 9, 60)),
     ("up3_two_pieces", lambda: nn.ConvTranspose2d(32, 16, 7, dilation=7), (1, 32, 6, 100)),      # wider than one 68-pixel piece of the 16-wide weight gradient
+    # up_conv_4's forward with four tap columns per column tile (dconv_tfwd8_kernel: rows of 32 .. 384 pixels)
+    ("up4_full_width", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (2, 16, 9, 382)),
+    ("up4_384_widest", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (1, 16, 3, 384)),
+    ("up4_33_three_images", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (3, 16, 25, 33)),
+    ("up4_cout4", lambda: nn.ConvTranspose2d(16, 4, 7, dilation=3), (1, 16, 8, 70)),
+    ("up4_31_gather", lambda: nn.ConvTranspose2d(16, 8, 7, dilation=3), (1, 16, 8, 31)),         # narrower than one m-tile: the gather kernel
 ]
 
 
