@@ -90,7 +90,7 @@ SIGNATURES = {
     "dd_conv_wgrad": (_i32, [_p, _p, _p, _p, _p, _i64, _DP, _p]),
     "dd_relu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
     "dd_relu_sign_bits": (_i32, [_p, _p, _i64, _p]),
-    "dd_relu_bwd_pad_bits": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "dd_relu_bwd_pad_bits": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_relu_bwd": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_pool4_relu_bwd_add": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
@@ -141,7 +141,7 @@ SIGNATURES = {
     "dd_deconv2x2_c1_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_deconv2x2_c1_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "dd_strip6_supported": (_i32, [_i32, _i32]),
-    "dd_strip6_fwd": (_i32, [_p, _i32, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "dd_strip6_fwd": (_i32, [_p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_strip6_wgrad_workspace_bytes": (_i64, []),
     "dd_strip6_wgrad": (_i32, [_p, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "dd_view_to_nhwc4": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

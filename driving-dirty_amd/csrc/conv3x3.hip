@@ -2113,8 +2113,8 @@ __global__ __launch_bounds__(256) void relu_sign_bits_kernel(const float* __rest
 // out_pad [B, H + 2, W + 2, 32] = dy [B, H, W, 32] * (the ReLU was open: bit c of bits_pad[pixel]) in the interior, ZERO on the border ring:
 // the output gradient of a padding-0 3x3 layer laid out for the padding-1 kernels (its border outputs do not exist, so they carry no
 // gradient), with the layer's own ReLU backward applied from the sign words its forward wrote.
-__global__ __launch_bounds__(256) void relu_bwd_pad_bits_kernel(const f32x4* __restrict__ dy, const unsigned* __restrict__ bits_pad,
-                                                                f32x4* __restrict__ out_pad, int B, int H, int W) {
+__global__ __launch_bounds__(256) void relu_bwd_pad_bits_kernel(const float* __restrict__ dy, const unsigned* __restrict__ bits_pad,
+                                                                f32x4* __restrict__ out_pad, int B, int H, int W, int dy_cstore, int dy_coff) {
   const long total = (long)B * (H + 2) * (W + 2) * 8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i & 7);
@@ -2123,7 +2123,7 @@ __global__ __launch_bounds__(256) void relu_bwd_pad_bits_kernel(const f32x4* __r
     const long b = pp / ((long)(W + 2) * (H + 2));
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (xx >= 1 && xx <= W && yy >= 1 && yy <= H) {
-      const f32x4 g = dy[((b * H + (yy - 1)) * W + (xx - 1)) * 8 + q];
+      const f32x4 g = *(const f32x4*)(dy + ((b * H + (yy - 1)) * W + (xx - 1)) * dy_cstore + dy_coff + 4 * q);
       const unsigned m = bits_pad[pp] >> (4 * q);
       o.x = (m & 1u) ? g.x : 0.f;
       o.y = (m & 2u) ? g.y : 0.f;
@@ -2458,13 +2458,16 @@ int dd_relu_sign_bits(const float* x, uint32_t* bits, int64_t npix, void* stream
   return 0;
 }
 
-int dd_relu_bwd_pad_bits(const float* dy, const uint32_t* bits_pad, float* out_pad, int32_t batch, int32_t h, int32_t w, void* stream) {
+int dd_relu_bwd_pad_bits(const float* dy, const uint32_t* bits_pad, float* out_pad, int32_t batch, int32_t h, int32_t w, int32_t dy_cstore,
+                         int32_t dy_coff, void* stream) {
   DD_REQUIRE(dy && bits_pad && out_pad && batch > 0 && h > 0 && w > 0, DD_ERR_BAD_ARG, "relu_bwd_pad_bits: bad argument");
+  DD_REQUIRE(dy_cstore >= 32 && dy_cstore % 4 == 0 && dy_coff >= 0 && dy_coff % 4 == 0 && dy_coff + 32 <= dy_cstore, DD_ERR_BAD_ARG,
+             "relu_bwd_pad_bits: dy's 32 channels must be a 4-aligned slice of its %d stored ones (offset %d)", dy_cstore, dy_coff);
   DD_REQUIRE((((uintptr_t)dy | (uintptr_t)out_pad) & 15) == 0, DD_ERR_BAD_ARG, "relu_bwd_pad_bits: dy and out_pad must be 16-byte aligned");
   const long total = (long)batch * (h + 2) * (w + 2) * 8;
   const int grid = (int)min((total + 255) / 256, (long)DD_NUM_CU * 8);
-  hipLaunchKernelGGL(relu_bwd_pad_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dy, bits_pad, (f32x4*)out_pad,
-                     batch, h, w);
+  hipLaunchKernelGGL(relu_bwd_pad_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, bits_pad, (f32x4*)out_pad,
+                     batch, h, w, dy_cstore, dy_coff);
   DD_LAUNCH_CHECK("relu_bwd_pad_bits");
   return 0;
 }

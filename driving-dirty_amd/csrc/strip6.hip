@@ -44,6 +44,7 @@ struct S6Args {
   const float* w[6];               // tile order bl, fl, b, f, br, fr: [32][3][T]
   const float* bias[6];
   float* mosaic;                   // forward: [nb][3 th][2 tw][32]
+  unsigned* bits;                  // forward, optional: the mosaic's sign words [nb][3 th][2 tw] (bit c = channel c > 0)
   const float* g;                  // weight gradient: dL/d(mosaic), ReLU-masked, same shape
   float* part;                     // weight gradient: [waves][6][16][64] partial accumulators
   int nb, H, W, th, tw, waves_per_tile;
@@ -145,13 +146,27 @@ __device__ __forceinline__ void s6_fwd_tile(const S6Args& a, int tile, int view,
       for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc = DD_MFMA(p[c * S6_PITCH + KD::ST * 2 * j], wreg[j * 3 + c], acc);
+      unsigned word = 0;                                      // sign word of position 32 mt + (lane & 31), kept by lanes 0 .. 31
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int pm = 32 * mt + dd_acc_row(r, lane);
+        const float v = acc[r] + bias;
         if (pm < np) {
           const int oy = KIND < 2 ? L : pm, ox = KIND < 2 ? pm : L;
-          const float v = acc[r] + bias;
           a.mosaic[((((long)b * 3 + tr) * a.th + oy) * (2 * a.tw) + tc * a.tw + ox) * 32 + m] = v > 0.f ? v : 0.f;
+        }
+        if (a.bits) {      // lanes 0-31 hold the 32 channels of position i0 = (r & 3) + 8 (r >> 2), lanes 32-63 those of i0 + 4: one ballot = two words
+          const unsigned long long bal = __ballot(v > 0.f);
+          const int i0 = (r & 3) + 8 * (r >> 2);
+          if (lane == i0) word = (unsigned)bal;
+          if (lane == i0 + 4) word = (unsigned)(bal >> 32);
+        }
+      }
+      if (a.bits) {
+        const int pm = 32 * mt + lane;
+        if (lane < 32 && pm < np) {
+          const int oy = KIND < 2 ? L : pm, ox = KIND < 2 ? pm : L;
+          a.bits[(((long)b * 3 + tr) * a.th + oy) * (2 * a.tw) + tc * a.tw + ox] = word;
         }
       }
     }
@@ -346,7 +361,7 @@ int32_t dd_strip6_supported(int32_t height, int32_t width) {
 }
 
 int dd_strip6_fwd(const void* const* sample_ptrs, int32_t u8, const float* const* weights, const float* const* biases, float* mosaic,
-                  int32_t batch, int32_t height, int32_t width, void* stream) {
+                  uint32_t* relu_bits, int32_t batch, int32_t height, int32_t width, void* stream) {
   DD_REQUIRE(sample_ptrs && weights && biases && mosaic && batch > 0, DD_ERR_BAD_ARG, "strip6_fwd: bad argument");
   int th, tw;
   DD_REQUIRE(s6_shape_ok(height, width, th, tw), DD_ERR_UNSUPPORTED, "strip6_fwd: %d x %d views are not served (six equal tiles, W <= %d)", height, width, S6_MAXW);
@@ -357,6 +372,7 @@ int dd_strip6_fwd(const void* const* sample_ptrs, int32_t u8, const float* const
     S6Args a;
     if (int rc = s6_fill(a, sample_ptrs, b0, nb, weights, biases, height, width, th, tw, wpt)) return rc;
     a.mosaic = mosaic + (long)b0 * 3 * th * 2 * tw * 32;
+    a.bits = relu_bits ? relu_bits + (long)b0 * 3 * th * 2 * tw : nullptr;
     a.g = nullptr; a.part = nullptr;
     if (u8) hipLaunchKernelGGL(strip6_fwd_kernel<true>, dim3(S6_FWD_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(strip6_fwd_kernel<false>, dim3(S6_FWD_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
@@ -385,6 +401,7 @@ int dd_strip6_wgrad(const void* const* sample_ptrs, int32_t u8, const float* g, 
     S6Args a;
     if (int rc = s6_fill(a, sample_ptrs, b0, nb, nullptr, nullptr, height, width, th, tw, wpt)) return rc;
     a.mosaic = nullptr;
+    a.bits = nullptr;
     a.g = g + (long)b0 * 3 * th * 2 * tw * 32;
     a.part = (float*)workspace;
     if (u8) hipLaunchKernelGGL(strip6_wgrad_kernel<true>, dim3(S6_WG_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);

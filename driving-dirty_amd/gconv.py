@@ -498,16 +498,18 @@ def _ptr6(tensors, who, shapes=None):
 _STRIP_SHAPES = [(32, 3, 1, 50), (32, 3, 1, 50), (32, 3, 52, 1), (32, 3, 52, 1), (32, 3, 1, 50), (32, 3, 1, 50)]      # bl, fl, b, f, br, fr
 
 
-def strip6_fwd(views, weights, biases):
+def strip6_fwd(views, weights, biases, want_bits=False):
     """The six strip convs of SpatialMappingCNN (+ bias + ReLU) in one launch, written into their tiles of the 3 x 2 mosaic
-    (dd_strip6_fwd; spatial_bb/components.py:34-73).  ``weights`` / ``biases``: bl, fl, b, f, br, fr.  -> mosaic [B, 3 th, 2 tw, 32]."""
+    (dd_strip6_fwd; spatial_bb/components.py:34-73).  ``weights`` / ``biases``: bl, fl, b, f, br, fr.  -> mosaic [B, 3 th, 2 tw, 32];
+    with ``want_bits`` also its sign words, int32 [B, 3 th, 2 tw] (the ReLU mask of out_conv's data gradient on the Winograd kernels)."""
     table, b, h, w, dev, u8, _keep = _sample_table(views, "strip6_fwd")
     th, tw = (h - 1) // 3 + 1, (w - 50) // 2 + 1
     weights = [x.contiguous() for x in weights]
     mosaic = torch.empty((b, 3 * th, 2 * tw, 32), device=dev, dtype=torch.float32)
-    check(_lib.lib().dd_strip6_fwd(table, u8, _ptr6(weights, "weight", _STRIP_SHAPES), _ptr6(biases, "bias", [(32,)] * 6), _p(mosaic), b, h, w,
-                                   _stream()), "dd_strip6_fwd")
-    return mosaic
+    bits = torch.empty((b, 3 * th, 2 * tw), device=dev, dtype=torch.int32) if want_bits else None
+    check(_lib.lib().dd_strip6_fwd(table, u8, _ptr6(weights, "weight", _STRIP_SHAPES), _ptr6(biases, "bias", [(32,)] * 6), _p(mosaic),
+                                   _p(bits) if want_bits else None, b, h, w, _stream()), "dd_strip6_fwd")
+    return (mosaic, bits) if want_bits else mosaic
 
 
 def strip6_wgrad(views, g):

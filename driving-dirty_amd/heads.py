@@ -195,12 +195,14 @@ class SpatialMapFn(torch.autograd.Function):
             (views.shape[2:4] if views.dtype == torch.uint8 else views.shape[3:5])
         fused = gconv_mod.strip6_supported(h_in, w_in)
         th = tw = None
-        mosaic = None
+        mosaic = mosaic_bits = None
         laid = []                                           # generic path: the six NHWC4 layouts, kept for the weight gradients
         if fused:
             # all six strip convs in ONE launch reading the views where they lie: rot90 / flip / mosaic placement are index arithmetic
             # in the kernel (csrc/strip6.hip), no re-laid copies at all
-            mosaic = gconv_mod.strip6_fwd(views, [p[n][0] for n, *_ in _TILES], [p[n][1] for n, *_ in _TILES])
+            mosaic = gconv_mod.strip6_fwd(views, [p[n][0] for n, *_ in _TILES], [p[n][1] for n, *_ in _TILES], want_bits=WINO_OUT)
+            if WINO_OUT:      # the mosaic's sign words from the strip kernels' own epilogue: the ReLU mask of out_conv's data gradient below
+                mosaic, mosaic_bits = mosaic
             th, tw = mosaic.shape[1] // 3, mosaic.shape[2] // 2
         for name, vi, tf, tr, tc in (() if fused else _TILES):
             xv = view_to_nhwc4(views, vi, tf)
@@ -227,6 +229,9 @@ class SpatialMapFn(torch.autograd.Function):
             keep = out
         if TRACE is not None:
             TRACE.update(mosaic=mosaic, space_out=out, tile=(th, tw))
+        if ctx.wino and mosaic_bits is None:
+            mosaic_bits = ops.relu_sign_bits(mosaic)        # the generic strip path does not write them
+        ctx.mosaic_bits = mosaic_bits if ctx.wino else None  # no gradient flows to it: a plain reference
         if per_sample:
             ctx.samples = tuple(views)                      # inputs without gradients: plain references keep them alive
             ctx.save_for_backward(mosaic, keep, p["out_conv"][0])
@@ -249,9 +254,9 @@ class SpatialMapFn(torch.autograd.Function):
         grads = {}
         if ctx.wino:      # `out` holds the sign words of the padded output here
             d = cls._wino_desc(mosaic)
-            g = ops.relu_bwd_pad_bits(gout.contiguous(), out)      # dL/d(out_conv output) behind its ReLU, zero on the border ring the layer does not have
+            g = ops.relu_bwd_pad_bits(gout, out)      # dL/d(out_conv output) behind its ReLU, zero on the border ring the layer does not have (gout may be a channel slice of the merging head's concat gradient: read in place)
             grads["out_conv"] = ops.conv_wino2_wgrad(mosaic, g, d)
-            gm = ops.conv_wino2_dgrad_bits(g, ops.conv_wino2_pack(w_out, d, ops.PACK_DGRAD_S1), ops.relu_sign_bits(mosaic), d)
+            gm = ops.conv_wino2_dgrad_bits(g, ops.conv_wino2_pack(w_out, d, ops.PACK_DGRAD_S1), ctx.mosaic_bits, d)
         else:
             g = ops.relu_bwd(gout.contiguous(), out)
             grads["out_conv"] = cls.OUT.backward_weight(View(mosaic), View(g))
@@ -413,8 +418,11 @@ class MergeFn(torch.autograd.Function):
         gcat = g                                                                 # [B,256,256,64|96]; slices 0:32 / 64:96 ReLU-masked
         g_space = None
         if ctx.needs_input_grad[1]:                           # plain dL/d(spatial_map): no mask
-            g_space = _empty(gcat.shape[:3] + (32,), dev)
-            copy_channels(View(gcat, 32, 32), View(g_space))
+            if WINO_OUT:      # handed on as the slice of the concat gradient it is: SpatialMapFn's Winograd backward reads it where it lies
+                g_space = gcat[..., 32:64]
+            else:
+                g_space = _empty(gcat.shape[:3] + (32,), dev)
+                copy_channels(View(gcat, 32, 32), View(g_space))
         g_rm2 = g_rm1 = (None, None)
         if with_rm:
             g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))

@@ -524,14 +524,36 @@ def relu_sign_bits(x):
     return bits
 
 
+def channel_slice(v):
+    """``v`` [B,H,W,C]: (dense NHWC buffer [B,H,W,cs] it is a channel slice of, channel offset), or None (dense tensors: (v, 0))."""
+    if v.dim() != 4:
+        return None
+    if v.is_contiguous():
+        return v, 0
+    b, h, w, c = v.shape
+    sb, sh, sw, sc = v.stride()
+    if sc != 1 or sw < c or sh != w * sw or (b > 1 and sb != h * sh):
+        return None
+    coff = v.storage_offset() % sw
+    if coff + c > sw or v.storage_offset() != coff or v.untyped_storage().nbytes() // v.element_size() < b * h * w * sw:
+        return None
+    return v.as_strided((b, h, w, sw), (h * w * sw, w * sw, sw, 1), 0), coff
+
+
 def relu_bwd_pad_bits(dy, bits_pad):
-    """dy [B,H,W,32], sign words [B,H+2,W+2] -> [B,H+2,W+2,32]: dy behind the ReLU in the interior, zero on the border ring."""
-    _dev(dy, "dy")
+    """dy [B,H,W,32] (dense, or a channel slice of a dense NHWC buffer: read where it lies), sign words [B,H+2,W+2] ->
+    [B,H+2,W+2,32]: dy behind the ReLU in the interior, zero on the border ring."""
+    src = channel_slice(dy)
+    if src is None:
+        src = (dy.contiguous(), 0)
+    buf, coff = src
+    _dev(buf, "dy")
     b, h, w, c = dy.shape
-    if c != 32 or not (bits_pad.is_cuda and bits_pad.dtype == torch.int32 and bits_pad.is_contiguous() and tuple(bits_pad.shape) == (b, h + 2, w + 2)):
-        raise _lib.HotpathError(f"relu_bwd_pad_bits: dy {tuple(dy.shape)} needs 32 channels and contiguous int32 sign words [B,H+2,W+2], got {tuple(bits_pad.shape)}")
+    if c != 32 or coff % 4 or buf.shape[3] % 4 or not (bits_pad.is_cuda and bits_pad.dtype == torch.int32 and bits_pad.is_contiguous() and
+                                                        tuple(bits_pad.shape) == (b, h + 2, w + 2)):
+        raise _lib.HotpathError(f"relu_bwd_pad_bits: dy {tuple(dy.shape)} needs 32 channels (a 4-aligned slice) and contiguous int32 sign words [B,H+2,W+2], got {tuple(bits_pad.shape)}")
     out = torch.empty((b, h + 2, w + 2, 32), device=dy.device, dtype=torch.float32)
-    check(_lib.lib().dd_relu_bwd_pad_bits(_p(dy), _p(bits_pad), _p(out), b, h, w, _stream()), "dd_relu_bwd_pad_bits")
+    check(_lib.lib().dd_relu_bwd_pad_bits(_p(buf), _p(bits_pad), _p(out), b, h, w, buf.shape[3], coff, _stream()), "dd_relu_bwd_pad_bits")
     return out
 
 

@@ -203,9 +203,11 @@ int dd_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* st
  *   dd_relu_sign_bits: bits[p] bit c = x[p][c] > 0 for an NHWC activation of 32 channels -- the sign words dd_conv_*_fwd_relu_bits write
  *     beside their own output, for an activation some other kernel produced (the data gradient's ReLU mask);
  *   dd_relu_bwd_pad_bits: out_pad [B,h+2,w+2,32] = dy [B,h,w,32] where the sign word bits_pad [B,h+2,w+2] of that pixel has the channel's
- *     bit set, zero elsewhere and on the border ring (outputs that do not exist in the padding-0 layer carry no gradient). */
+ *     bit set, zero elsewhere and on the border ring (outputs that do not exist in the padding-0 layer carry no gradient); dy's 32 channels
+ *     may be a slice [dy_coff, +32) of dy_cstore stored ones (the concat buffer's gradient, read where it lies). */
 int dd_relu_sign_bits(const float* x, uint32_t* bits, int64_t npix, void* stream);
-int dd_relu_bwd_pad_bits(const float* dy, const uint32_t* bits_pad, float* out_pad, int32_t batch, int32_t h, int32_t w, void* stream);
+int dd_relu_bwd_pad_bits(const float* dy, const uint32_t* bits_pad, float* out_pad, int32_t batch, int32_t h, int32_t w, int32_t dy_cstore,
+                         int32_t dy_coff, void* stream);
 
 /* ---- NCHW-order max_pool1d(4) on an NHWC feature (K6) -----------------------------------
  * feat [B,H,W,C] NHWC.  The reference flattens the NCHW tensor and pools windows of 4 along
@@ -465,12 +467,13 @@ int dd_conv1x1_c32_c3_nchw(const float* x, const float* wt, const float* bias, f
  * `dweights` / `dbiases` (HOST arrays of 6 DEVICE pointers): bl_conv, fl_conv, b_conv, f_conv, br_conv, fr_conv; weights in the
  * modules' own layout [32][3][kh][kw].
  *   fwd    mosaic [batch][3 th][2 tw][32] NHWC fp32 = ReLU(conv + bias) of every tile (th = (H - 1) / 3 + 1, tw = (W - 50) / 2 + 1)
+ *          relu_bits (may be NULL): the mosaic's sign words [batch][3 th][2 tw], bit c = channel c > 0 (as dd_relu_sign_bits would give)
  *   wgrad  g = dL/d(mosaic) (already masked by the mosaic's ReLU) -> the six weight and bias gradients; per-wave partial sums in
  *          `workspace` (dd_strip6_wgrad_workspace_bytes()), added in a fixed order: deterministic
  * dd_strip6_supported: the six tiles must come out equal (H even, H % 3 != 0, W = H + 50; the reference's 256 x 306) and W <= 320. */
 int32_t dd_strip6_supported(int32_t height, int32_t width);
 int dd_strip6_fwd(const void* const* sample_ptrs, int32_t u8, const float* const* weights, const float* const* biases, float* mosaic,
-                  int32_t batch, int32_t height, int32_t width, void* stream);
+                  uint32_t* relu_bits, int32_t batch, int32_t height, int32_t width, void* stream);
 int64_t dd_strip6_wgrad_workspace_bytes(void);
 int dd_strip6_wgrad(const void* const* sample_ptrs, int32_t u8, const float* g, float* const* dweights, float* const* dbiases, int32_t batch,
                     int32_t height, int32_t width, void* workspace, int64_t workspace_bytes, void* stream);

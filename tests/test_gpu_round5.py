@@ -412,6 +412,9 @@ def test_sign_words_padded_relu_backward_and_window_copy(dev):
         want = torch.zeros_like(x)
         want[:, 1:-1, 1:-1] = dy * (x[:, 1:-1, 1:-1] > 0)
         assert torch.equal(got, want)
+        wide = torch.randn(b, h, w, 96, device=dev)           # the same from a channel slice of a wider buffer, read where it lies
+        wide[..., 32:64] = dy
+        assert ops.channel_slice(wide[..., 32:64])[1] == 32 and torch.equal(ops.relu_bwd_pad_bits(wide[..., 32:64], bits), want)
         dst = torch.full((b, h, w, 64), -1.0, device=dev)
         inner = x[:, 1:-1, 1:-1, :]
         base = heads.padded_nhwc(inner)
