@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float* __restric
       const int ox = ox0 + dd_acc_row(e, lane);
       float v = acc[e] + bv;
       if (relu) v = fmaxf(v, 0.f);
-      if (ox < ow) yr[ox * C1_CO + n] = v;
+      if (ox < ow) __builtin_nontemporal_store(v, yr + ox * C1_CO + n);
     }
   }
 }
@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restr
     __syncthreads();
     const float* gr = g + ((long)b * oh + oy) * ow * C1_CO;
     const char* pb = (const char*)&patch[0][0];
-    // pairs wave, wave + 4, ...: four at a time, loads first
-    for (int p0 = wave; p0 < npair; p0 += 16) {
-      float av[4], b0[4], b1[4];
+    // pairs wave, wave + 4, ...: eight at a time, loads first (four: 225 us at bs 32 -- 2 MB in flight on the chip, 1.25 TB/s of the 281 MB of g)
+    constexpr int NU = 8;
+    for (int p0 = wave; p0 < npair; p0 += 4 * NU) {
+      float av[NU], b0[NU], b1[NU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int p = p0 + 4 * u, px = 2 * p + h;
         av[u] = (p < npair && px < ow) ? gr[px * C1_CO + n] : 0.f;      // a pixel past the row end contributes nothing
         const int po = min(p, npair - 1) * 8;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restr
         b1[u] = *(const float*)(pb + boff[1] + po);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         acc[0] = DD_MFMA(av[u], b0[u], acc[0]);
         acc[1] = DD_MFMA(av[u], b1[u], acc[1]);
       }
