@@ -67,6 +67,10 @@ SIGNATURES = {
     "dd_conv1x1_c32_c3_nchw": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "dd_conv1ch_fwd": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dd_conv1ch_wgrad_workspace_bytes": (_i64, []),
+    "dd_conv1ch_fwd_phase3": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dd_conv1ch_wgrad_phase3": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
+    "dd_phase3_scatter": (_i32, [_p, _p] + [_i32] * 8 + [_p]),
+    "dd_phase3_gather": (_i32, [_p, _p] + [_i32] * 8 + [_p]),
     "dd_conv1ch_wgrad": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "dd_nhwc_to_nchw": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "dd_conv_packed_floats": (_i64, [_DP, _i32]),

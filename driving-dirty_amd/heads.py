@@ -162,6 +162,7 @@ _ORDER = ("f_conv", "fl_conv", "fr_conv", "b_conv", "bl_conv", "br_conv", "out_c
 
 WINO_OUT = True      # SpatialMapFn: out_conv on the Winograd kernels of the encoder's c2 layer (tests run both positions)
 WINO_DC2 = True      # DecoderConvStack: dc2 likewise
+WINO_RM2 = True      # MergeFn: rm_conv_2 (dilation 3) as nine plain 3x3 convolutions on phase images, on the same kernels
 
 
 class SpatialMapFn(torch.autograd.Function):
@@ -309,6 +310,27 @@ class MergeFn(torch.autograd.Function):
                  Layer(16, 8, 6, dil=6, transposed=True, output_padding=2))
 
     @staticmethod
+    def _rm2_wino_desc(b, rh, rw):
+        """The c2-layer descriptor of the 9 b phase images of rm_conv_2's rh x rw input, or None when the Winograd kernels do not take them."""
+        ph, pw = (rh + 2) // 3, (rw + 2) // 3
+        if ph < 4 or pw < 4:
+            return None
+        d = ops.conv_desc(9 * b, ph, pw, 32, 1)
+        return d if ops._lib.lib().dd_conv_wino2_packed_floats(ops.C.byref(d)) > 0 else None
+
+    @staticmethod
+    def _dense_from_phase3(p, oh, ow):
+        """[9B, ph, pw, 32] phase-major -> [B, oh, ow, 32] (tests / TRACE only)."""
+        b = p.shape[0] // 9
+        out = torch.empty((b, oh, ow, 32), device=p.device, dtype=p.dtype)
+        pv = p.view(b, 3, 3, p.shape[1], p.shape[2], 32)
+        for a in range(3):
+            for c in range(3):
+                na, nc = (oh - a + 2) // 3, (ow - c + 2) // 3
+                out[:, a::3, c::3] = pv[:, a, c, :na, :nc]
+        return out
+
+    @staticmethod
     def forward(ctx, ssr, space, rm4, with_rm, *params):
         cls = MergeFn
         ups = cls.UPS_RM if with_rm else cls.UPS_PLAIN
@@ -334,12 +356,24 @@ class MergeFn(torch.autograd.Function):
             copy_channels(View(space.contiguous()), View(cat, 32, 32))
         else:      # the interior of a padded activation (SpatialMapFn's Winograd out_conv): copied out of its window, no dense copy first
             copy_channels(View(base[0], 0, 32, base[1], base[2], space.shape[1], space.shape[2]), View(cat, 32, 32))
-        r1 = None
+        r1 = r1_bits = None
+        ctx.wino_rm2 = False
         if with_rm:
-            r1 = ops.conv1ch_fwd(rm4, p_rm1[0], p_rm1[1], relu=True)      # rm_conv_1: taps as the K dimension (csrc/conv1ch.hip)
-            rh, rw = r1.shape[1:3]
+            rh, rw = rm4.shape[1] - 6, rm4.shape[2] - 6
             assert cls.RM2.out_hw(rh, rw) == (ch, cw)
-            cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
+            d9 = cls._rm2_wino_desc(b, rh, rw) if WINO_RM2 else None
+            if d9 is not None:
+                # rm_conv_2 (32 -> 32, k3, dilation 3) is nine plain 3x3 convolutions on the residue classes of its input: rm_conv_1 writes
+                # them as nine images per scene (phase-major, csrc/conv1ch.hip), the c2 layer's Winograd kernels run the padding-1
+                # convolution of all 9 B of them, and the interiors are scattered into the concat slice (1.36 -> ~0.95 ms at bs 32)
+                ctx.wino_rm2 = True
+                r1, r1_bits = ops.conv1ch_fwd_phase3(rm4, p_rm1[0], p_rm1[1], relu=True)
+                y9, _ = ops.conv_wino2_fwd_bits(r1, ops.conv_wino2_pack(p_rm2[0], d9, ops.PACK_FWD), p_rm2[1], d9)
+                ops.phase3_scatter(y9, cat, 64, 1)
+                del y9
+            else:
+                r1 = ops.conv1ch_fwd(rm4, p_rm1[0], p_rm1[1], relu=True)      # rm_conv_1: taps as the K dimension (csrc/conv1ch.hip)
+                cls.RM2.forward(p_rm2[0], p_rm2[1], View(r1), View(cat, 64, 32), EPI_BIAS_RELU)
         acts = [cat]
         split_x = []                                 # split-product experiment (gconv.SPLIT_BF16): each layer input's bf16 planes, kept for its weight gradient
         planes = None                                # ... and the planes of the previous layer's OUTPUT, written by its epilogue (no split pass)
@@ -361,11 +395,12 @@ class MergeFn(torch.autograd.Function):
         check(_lib.lib().dd_deconv2x2_c1_fwd(_p(u), _p(p_last[0]), _p(p_last[1]), _p(probs), b, u.shape[1], u.shape[2], 8,
                                              _stream()), "dd_deconv2x2_c1_fwd")
         if TRACE is not None:
-            TRACE.update(s1=s1, cat=cat, r1=r1, acts=acts)
+            TRACE.update(s1=s1, cat=cat, r1=cls._dense_from_phase3(r1, rh, rw) if ctx.wino_rm2 else r1, acts=acts)
         ctx.with_rm = with_rm
         ctx.save_for_backward(ssr, s1, rm4 if with_rm else None, r1, probs, p_ssc[0], p_ssd[0],
                               p_rm2[0] if with_rm else None, p_last[0], *[w for w, _ in p_up], *acts)
         ctx.nup = len(ups)
+        ctx.r1_bits = r1_bits      # sign words of the phase-major r1 (no gradient flows to them: a plain reference)
         return probs
 
     @staticmethod
@@ -425,10 +460,17 @@ class MergeFn(torch.autograd.Function):
                 copy_channels(View(gcat, 32, 32), View(g_space))
         g_rm2 = g_rm1 = (None, None)
         if with_rm:
-            g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))
-            gr1 = _empty(r1.shape, dev)
-            cls.RM2.backward_data(w_rm2, View(gcat, 64, 32), View(gr1), relu_src=r1)
-            g_rm1 = ops.conv1ch_wgrad(rm4, gr1)
+            if ctx.wino_rm2:
+                d9 = cls._rm2_wino_desc(gcat.shape[0], rm4.shape[1] - 6, rm4.shape[2] - 6)
+                g9 = ops.phase3_gather(gcat, 64, r1.shape[1], r1.shape[2], 1)      # zero border ring and padding cells included
+                g_rm2 = ops.conv_wino2_wgrad(r1, g9, d9)
+                gr1 = ops.conv_wino2_dgrad_bits(g9, ops.conv_wino2_pack(w_rm2, d9, ops.PACK_DGRAD_S1), ctx.r1_bits, d9)
+                g_rm1 = ops.conv1ch_wgrad_phase3(rm4, gr1)
+            else:
+                g_rm2 = cls.RM2.backward_weight(View(r1), View(gcat, 64, 32))
+                gr1 = _empty(r1.shape, dev)
+                cls.RM2.backward_data(w_rm2, View(gcat, 64, 32), View(gr1), relu_src=r1)
+                g_rm1 = ops.conv1ch_wgrad(rm4, gr1)
         g_ssd = cls.SS_DECONV.backward_weight(View(s1), View(gcat, 0, 32))
         gs1 = _empty(s1.shape, dev)
         cls.SS_DECONV.backward_data(w_ssd, View(gcat, 0, 32), View(gs1), relu_src=s1)

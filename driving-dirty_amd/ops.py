@@ -290,6 +290,49 @@ def conv1ch_wgrad(taps4, g):
     return dw, db
 
 
+def conv1ch_fwd_phase3(taps4, w, bias, relu=True):
+    """conv1ch_fwd with the output in the phase-major layout of a dilation-3 consumer: -> (y [9B, ph, pw, 32], its sign words int32
+    [9B, ph, pw]), ph = ceil((sh-6) / 3), pw likewise; image b * 9 + (i % 3) * 3 + j % 3 holds the pixels (i, j) of that residue class."""
+    b, sh, sw, _ = taps4.shape
+    assert tuple(w.shape) == (32, 1, 7, 7) and w.is_contiguous()
+    ph, pw = (sh - 6 + 2) // 3, (sw - 6 + 2) // 3
+    y = torch.empty((9 * b, ph, pw, 32), device=taps4.device, dtype=torch.float32)
+    bits = torch.empty((9 * b, ph, pw), device=taps4.device, dtype=torch.int32)
+    check(_lib.lib().dd_conv1ch_fwd_phase3(_p(taps4), _p(w), _p(bias), _p(y), _p(bits), b, sh, sw, int(relu), _stream()), "dd_conv1ch_fwd_phase3")
+    return y, bits
+
+
+def conv1ch_wgrad_phase3(taps4, g_phase):
+    """conv1ch_wgrad from dL/dy in the phase-major layout [9B, ph, pw, 32]."""
+    b, sh, sw, _ = taps4.shape
+    ph, pw = (sh - 6 + 2) // 3, (sw - 6 + 2) // 3
+    assert tuple(g_phase.shape) == (9 * b, ph, pw, 32) and g_phase.is_contiguous()
+    dw = torch.empty((32, 1, 7, 7), device=g_phase.device, dtype=torch.float32)
+    db = torch.empty(32, device=g_phase.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().dd_conv1ch_wgrad_workspace_bytes(), device=g_phase.device, dtype=torch.uint8)
+    check(_lib.lib().dd_conv1ch_wgrad_phase3(_p(taps4), _p(g_phase), _p(dw), _p(db), b, sh, sw, _p(ws), _stream()), "dd_conv1ch_wgrad_phase3")
+    return dw, db
+
+
+def phase3_scatter(src_phase, dst, coff, off):
+    """dst [B,oh,ow,cs] channels [coff, +32) <- the phase images src_phase [9B, ph, pw, 32], read ``off`` cells in from their corner."""
+    _dev(src_phase, "src_phase")
+    _dev(dst, "dst")
+    b, oh, ow, cs = dst.shape
+    assert src_phase.shape[0] == 9 * b and src_phase.shape[3] == 32
+    check(_lib.lib().dd_phase3_scatter(_p(src_phase), _p(dst), b, oh, ow, src_phase.shape[1], src_phase.shape[2], off, cs, coff, _stream()),
+          "dd_phase3_scatter")
+
+
+def phase3_gather(src, coff, ph, pw, off):
+    """-> [9B, ph, pw, 32]: the 32-channel slice [coff, +32) of the dense NHWC buffer src in phase images, ``off`` cells in; zero elsewhere."""
+    _dev(src, "src")
+    b, oh, ow, cs = src.shape
+    out = torch.empty((9 * b, ph, pw, 32), device=src.device, dtype=torch.float32)
+    check(_lib.lib().dd_phase3_gather(_p(src), _p(out), b, oh, ow, ph, pw, off, cs, coff, _stream()), "dd_phase3_gather")
+    return out
+
+
 def nhwc_to_nchw(x, c):
     b, h, w, cs = x.shape
     _dev(x, "x")

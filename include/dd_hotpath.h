@@ -507,6 +507,21 @@ int dd_subsample_nhwc4_u8_ptrs(const unsigned char* const* mask_ptrs, float* dst
  * g = dL/dy [batch,sh-6,sw-6,32] (already masked by the ReLU); deterministic (fp64 fixed-order second stage). */
 int dd_conv1ch_fwd(const float* taps4, const float* w, const float* bias, float* y, int32_t batch, int32_t sh, int32_t sw,
                    int32_t relu, void* stream);
+/* The same two with rm_conv_1's OUTPUT (and its gradient) in the "phase-major" layout a dilation-3 consumer wants (rm_conv_2,
+ * spatial_bb/components.py:81,131): the nine residue classes (i mod 3, j mod 3) of [B][oh][ow][32] as nine images,
+ *   P[b * 9 + (i % 3) * 3 + j % 3][i / 3][j / 3][:] = T[b][i][j][:],   ph x pw = ceil(oh / 3) x ceil(ow / 3) pixels each, zero past a class's end.
+ * On P a 3x3 convolution with dilation 3 is nine plain 3x3 convolutions, which run on the c2 layer's Winograd kernels (batch 9 B).
+ * relu_bits (may be NULL): the sign words of y_phase in the same layout.  dd_phase3_scatter / dd_phase3_gather move a 32-channel slice of a
+ * dense NHWC buffer to / from such images, `off` cells in from the corner (1: the interior of a padding-1 convolution's output; gather
+ * writes every cell of dst_phase, zero where no pixel maps). */
+int dd_conv1ch_fwd_phase3(const float* taps4, const float* w, const float* bias, float* y_phase, uint32_t* relu_bits, int32_t batch,
+                          int32_t sh, int32_t sw, int32_t relu, void* stream);
+int dd_conv1ch_wgrad_phase3(const float* taps4, const float* g_phase, float* dw, float* dbias, int32_t batch, int32_t sh, int32_t sw,
+                            void* workspace, void* stream);
+int dd_phase3_scatter(const float* src_phase, float* dst, int32_t batch, int32_t oh, int32_t ow, int32_t src_ph, int32_t src_pw, int32_t off,
+                      int32_t dst_cstore, int32_t dst_coff, void* stream);
+int dd_phase3_gather(const float* src, float* dst_phase, int32_t batch, int32_t oh, int32_t ow, int32_t dst_ph, int32_t dst_pw, int32_t off,
+                     int32_t src_cstore, int32_t src_coff, void* stream);
 int64_t dd_conv1ch_wgrad_workspace_bytes(void);
 int dd_conv1ch_wgrad(const float* taps4, const float* g, float* dw, float* dbias, int32_t batch, int32_t sh, int32_t sw,
                      void* workspace, void* stream);

@@ -396,6 +396,76 @@ def test_joint_feature_gradient_in_one_pass_equals_the_three(dev, b, h, w):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("b,sh,sw", [(2, 40, 46), (1, 268, 268), (3, 19, 33)])
+def test_phase_major_rm_conv_1_and_the_scatter_gather_pair(dev, b, sh, sw):
+    """dd_conv1ch_fwd_phase3 / dd_conv1ch_wgrad_phase3: rm_conv_1's output and gradient in the nine-residue-class layout -- the dense
+    kernels' values bit for bit in their cells, zeros (and zero sign words) in the padding cells; dd_phase3_scatter / dd_phase3_gather are
+    inverse on the cells that map to pixels and write zeros elsewhere."""
+    from driving_dirty_amd import heads, ops
+    torch.manual_seed(sh)
+    rm4 = torch.zeros(b, sh, sw, 4, device=dev)
+    rm4[..., 0] = torch.rand(b, sh, sw, device=dev)
+    w = torch.randn(32, 1, 7, 7, device=dev) * 0.2
+    bias = torch.randn(32, device=dev) * 0.2
+    dense = ops.conv1ch_fwd(rm4, w, bias, relu=True)
+    oh, ow = dense.shape[1:3]
+    yp, bits = ops.conv1ch_fwd_phase3(rm4, w, bias, relu=True)
+    ph, pw = yp.shape[1:3]
+    assert (ph, pw) == ((oh + 2) // 3, (ow + 2) // 3)
+    assert torch.equal(heads.MergeFn._dense_from_phase3(yp, oh, ow), dense)
+    pv = yp.view(b, 3, 3, ph, pw, 32)
+    for a in range(3):
+        for c in range(3):
+            na, nc = (oh - a + 2) // 3, (ow - c + 2) // 3
+            assert float(pv[:, a, c, na:].abs().sum()) == 0.0 and float(pv[:, a, c, :, nc:].abs().sum()) == 0.0
+    assert torch.equal(bits, ops.relu_sign_bits(yp))
+    g = torch.randn_like(dense)
+    gp = ops.phase3_gather(g, 0, ph, pw, 0)
+    assert torch.equal(heads.MergeFn._dense_from_phase3(gp, oh, ow), g)
+    dw, db = ops.conv1ch_wgrad(rm4, g)
+    dwp, dbp = ops.conv1ch_wgrad_phase3(rm4, gp)
+    assert torch.equal(dwp, dw) and torch.equal(dbp, db)
+    # scatter with an offset into a channel slice, gather back
+    wide = torch.full((b, oh, ow, 96), -2.0, device=dev)
+    padded = torch.randn(9 * b, ph + 2, pw + 2, 32, device=dev)
+    ops.phase3_scatter(padded, wide, 64, 1)
+    assert torch.equal(wide[..., 64:], heads.MergeFn._dense_from_phase3(padded[:, 1:, 1:].contiguous(), oh, ow)) and float(wide[..., :64].max()) == -2.0
+    back = ops.phase3_gather(wide, 64, ph + 2, pw + 2, 1)
+    assert float(back[:, 0].abs().sum()) == 0.0 and float(back[:, :, 0].abs().sum()) == 0.0
+    assert torch.equal(heads.MergeFn._dense_from_phase3(back[:, 1:, 1:].contiguous(), oh, ow), wide[..., 64:])
+
+
+def test_rm_conv_2_on_the_winograd_kernels_equals_the_engine(dev):
+    """RoadMapBoxesMergingCNN forward + backward with rm_conv_2 as nine plain 3x3 convolutions on phase images (default) and on the
+    dilated-conv engine (heads.WINO_RM2 off): same probabilities, same gradients to summation order."""
+    from driving_dirty_amd import heads, synth
+    from driving_dirty_amd.spatial import RoadMapBoxesMergingCNN
+    m = RoadMapBoxesMergingCNN()
+    synth.fill_module(m, seed=29)
+    m = m.to(dev)
+    torch.manual_seed(4)
+    ssr = torch.rand(2, 32, 128, 918, device=dev)
+    space = torch.rand(2, 32, 256, 256, device=dev)
+    rm = (torch.rand(2, 1, 800, 800, device=dev) < 0.3).float()
+    res = {}
+    for wino in (True, False):
+        prev, heads.WINO_RM2 = heads.WINO_RM2, wino
+        try:
+            m.zero_grad(set_to_none=True)
+            y = m(ssr, space, rm)
+            # (positive weights: with a zero-mean weighting the last layer's bias gradient -- one number, the sum of 1.3 M terms -- cancels to
+            # 1e-4 of its terms and its RELATIVE difference between two fp32 paths says nothing)
+            (y * torch.linspace(0.5, 1.5, y.numel(), device=dev).view(y.shape)).sum().backward()
+            res[wino] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        finally:
+            heads.WINO_RM2 = prev
+    ya, ga = res[True]
+    yb, gb = res[False]
+    assert float((ya - yb).abs().max()) <= 5e-6 * float(yb.abs().max())
+    for k in gb:      # two fp32 paths: their difference may reach the sum of the two kernel-level bounds
+        assert float((ga[k] - gb[k]).abs().max()) <= 6e-5 * float(gb[k].abs().max()), k
+
+
 def test_sign_words_padded_relu_backward_and_window_copy(dev):
     """The three helpers behind it: dd_relu_sign_bits, dd_relu_bwd_pad_bits, dd_copy_channels_window against torch, ragged sizes."""
     from driving_dirty_amd import heads, ops
