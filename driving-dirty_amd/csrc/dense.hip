@@ -143,6 +143,115 @@ __global__ __launch_bounds__(256) void bn_relu_drop_bwd_kernel(
   }
 }
 
+// ---- the same two kernels for WIDE layers (the decoder's DenseBlock: 32 rows x 1.25 M features): V consecutive features per thread,
+// 16- / 8-byte accesses (a quarter / half of the memory instructions, 1 KB / 512 B per wave instruction), non-temporal: the 160 MB
+// activations stream through once.  Per feature the sums run over the rows in the same order as above: the same bits.
+template <int V>
+struct BnVec;
+template <>
+struct BnVec<4> { typedef f32x4 T; };
+template <>
+struct BnVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+
+__global__ __launch_bounds__(256) void bn_relu_drop_fwd_vec4(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, const float* __restrict__ keep, float* __restrict__ y,
+                                                             float* __restrict__ smean, float* __restrict__ sinv, int rows, int feat, float eps,
+                                                             float momentum, float scale, int training, long long* __restrict__ nbt) {
+  const int f = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (f >= feat) return;
+  if (nbt && f == 0) *nbt += 1;
+  f32x4 xv[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) xv[r] = (r < rows) ? __builtin_nontemporal_load((const f32x4*)(x + (long)r * feat + f)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 mean, invstd;
+  if (training) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += (r < rows) ? xv[r] : f32x4{0.f, 0.f, 0.f, 0.f};
+    mean = s / (float)rows;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const f32x4 dd = xv[r] - mean;
+      ss += (r < rows) ? dd * dd : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 var = ss / (float)rows;
+    const f32x4 unbiased = rows > 1 ? ss / (float)(rows - 1) : var;
+    const f32x4 rm = *(const f32x4*)(rmean + f), rv = *(const f32x4*)(rvar + f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) invstd[j] = 1.0f / sqrtf(var[j] + eps);
+    *(f32x4*)(smean + f) = mean;
+    *(f32x4*)(sinv + f) = invstd;
+    *(f32x4*)(rmean + f) = (1.f - momentum) * rm + momentum * mean;
+    *(f32x4*)(rvar + f) = (1.f - momentum) * rv + momentum * unbiased;
+  } else {
+    mean = *(const f32x4*)(rmean + f);
+    const f32x4 rv = *(const f32x4*)(rvar + f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) invstd[j] = 1.0f / sqrtf(rv[j] + eps);
+  }
+  const f32x4 g = *(const f32x4*)(gamma + f) * invstd, b = *(const f32x4*)(beta + f);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    if (r < rows) {
+      const long i = (long)r * feat + f;
+      f32x4 v = (xv[r] - mean) * g + b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      if (keep) v = v * __builtin_nontemporal_load((const f32x4*)(keep + i)) * scale;
+      __builtin_nontemporal_store(v, (f32x4*)(y + i));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_drop_bwd_vec2(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ keep,
+                                                             const float* __restrict__ smean, const float* __restrict__ sinv,
+                                                             const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int feat, float eps,
+                                                             float scale, int training) {
+  typedef BnVec<2>::T f2;
+  const int f = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (f >= feat) return;
+  f2 mean, invstd;
+  if (training) {
+    mean = *(const f2*)(smean + f);
+    invstd = *(const f2*)(sinv + f);
+  } else {
+    mean = *(const f2*)(rmean + f);
+    const f2 rv = *(const f2*)(rvar + f);
+    invstd = f2{1.0f / sqrtf(rv.x + eps), 1.0f / sqrtf(rv.y + eps)};
+  }
+  const float ks = keep ? scale : 1.f;
+  const f2 g = *(const f2*)(gamma + f) * invstd;
+  const float inv_rows = 1.f / rows;
+  f2 dzv[32], xh[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const long i = (long)r * feat + f;
+    const bool ok = r < rows;
+    const f2 yy = ok ? __builtin_nontemporal_load((const f2*)(y + i)) : f2{0.f, 0.f};
+    const f2 dd = ok ? __builtin_nontemporal_load((const f2*)(dy + i)) : f2{0.f, 0.f};
+    const f2 xx = ok ? __builtin_nontemporal_load((const f2*)(x + i)) : mean;
+    dzv[r] = f2{yy.x > 0.f ? dd.x * ks : 0.f, yy.y > 0.f ? dd.y * ks : 0.f};
+    xh[r] = (xx - mean) * invstd;
+  }
+  f2 sdz = {0.f, 0.f}, sdzx = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    sdz += dzv[r];
+    sdzx += dzv[r] * xh[r];
+  }
+  *(f2*)(dbeta + f) = sdz;
+  *(f2*)(dgamma + f) = sdzx;
+#pragma unroll
+  for (int r = 0; r < 32; ++r)
+    if (r < rows) {
+      const f2 o = training ? g * (dzv[r] - inv_rows * (sdz + xh[r] * sdzx)) : g * dzv[r];
+      __builtin_nontemporal_store(o, (f2*)(dx + (long)r * feat + f));
+    }
+}
+
 // ---- losses: grid-stride pass with per-thread fp32 partials, wave shuffle + LDS block reduce,
 // one fp64 partial per block, then a single-block fixed-order final sum (deterministic).
 __device__ __forceinline__ double block_sum(float v) {
@@ -429,6 +538,15 @@ int dd_bn_relu_drop_fwd(const float* x, const float* gamma, const float* beta, f
   DD_REQUIRE(rows > 0 && feat > 0, DD_ERR_BAD_ARG, "bn_fwd: non-positive size");
   DD_REQUIRE(!training || (save_mean && save_invstd), DD_ERR_BAD_ARG, "bn_fwd: training mode needs save buffers");
   DD_REQUIRE(!training || rows > 1, DD_ERR_UNSUPPORTED, "bn_fwd: batch statistics need more than 1 row (torch raises too)");
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  if (rows <= 32 && feat >= (1 << 16) && feat % 4 == 0 && al16(x) && al16(y) && al16(gamma) && al16(beta) && al16(running_mean) &&
+      al16(running_var) && (!keep || al16(keep)) && (!training || (al16(save_mean) && al16(save_invstd)))) {
+    hipLaunchKernelGGL(bn_relu_drop_fwd_vec4, dim3((feat / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean,
+                       running_var, keep, y, save_mean, save_invstd, rows, feat, eps, momentum, scale, training,
+                       (long long*)(training ? num_batches_tracked : nullptr));
+    DD_LAUNCH_CHECK("bn_relu_drop_fwd");
+    return 0;
+  }
   auto k = rows <= 32 ? bn_relu_drop_fwd_kernel<32> : rows <= 64 ? bn_relu_drop_fwd_kernel<64> : bn_relu_drop_fwd_kernel<0>;
   hipLaunchKernelGGL(k, dim3((feat + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var, keep, y,
                      save_mean, save_invstd, rows, feat, eps, momentum, scale, training, (long long*)(training ? num_batches_tracked : nullptr));
@@ -443,6 +561,14 @@ int dd_bn_relu_drop_bwd(const float* dy, const float* x, const float* y, const f
   DD_REQUIRE(dy && x && y && gamma && dx && dgamma && dbeta, DD_ERR_BAD_ARG, "bn_bwd: NULL pointer");
   DD_REQUIRE(training ? (save_mean && save_invstd) : (running_mean && running_var), DD_ERR_BAD_ARG, "bn_bwd: missing statistics");
   DD_REQUIRE(rows > 0 && feat > 0, DD_ERR_BAD_ARG, "bn_bwd: non-positive size");
+  auto al8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
+  if (rows <= 32 && feat >= (1 << 16) && feat % 2 == 0 && al8(dy) && al8(x) && al8(y) && al8(gamma) && al8(dx) && al8(dgamma) && al8(dbeta) &&
+      (training ? (al8(save_mean) && al8(save_invstd)) : (al8(running_mean) && al8(running_var)))) {
+    hipLaunchKernelGGL(bn_relu_drop_bwd_vec2, dim3((feat / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, x, y, gamma, keep, save_mean,
+                       save_invstd, running_mean, running_var, dx, dgamma, dbeta, rows, feat, eps, scale, training);
+    DD_LAUNCH_CHECK("bn_relu_drop_bwd");
+    return 0;
+  }
   auto k = rows <= 32 ? bn_relu_drop_bwd_kernel<32> : rows <= 64 ? bn_relu_drop_bwd_kernel<64> : bn_relu_drop_bwd_kernel<0>;
   hipLaunchKernelGGL(k, dim3((feat + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, x, y, gamma, keep, save_mean, save_invstd,
                      running_mean, running_var, dx, dgamma, dbeta, rows, feat, eps, scale, training);

@@ -293,7 +293,9 @@ def test_dense_block_counts_batches(dev):
     assert int(ref.num_batches_tracked) == 2
 
 
-@pytest.mark.parametrize("rows,feat,training,drop", [(3, 16, True, 0.0), (32, 128, True, 0.2), (5, 300, False, 0.2)])
+@pytest.mark.parametrize("rows,feat,training,drop", [(3, 16, True, 0.0), (32, 128, True, 0.2), (5, 300, False, 0.2),
+                                                     # wide layers (>= 65536 features): four / two features per thread (the decoder's DenseBlock)
+                                                     (32, 65540, True, 0.2), (7, 65536, False, 0.2), (32, 70002, True, 0.0)])
 def test_bn_relu_dropout(dev, rows, feat, training, drop):
     from driving_dirty_amd import ops
     from oracle.ae_parts import FcBlock
