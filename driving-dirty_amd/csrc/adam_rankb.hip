@@ -117,12 +117,13 @@ __device__ __forceinline__ void rankb_bias(const RankbArgs& a, const float* yl, 
 }
 
 // contraction over one 32-row chunk: A = dY (yp: this lane's column, swizzled), B = X (xp: this lane's 4 columns), both from LDS
+template <int XS = 64>      // XS: floats of a batch row of the X tile in LDS
 __device__ __forceinline__ void rankb_mfma_chunk(const float* yp, const float* xp, int rows_left, f32x4& acc0, f32x4& acc1, f32x4& acc2,
                                                  f32x4& acc3) {
   const int pairs = min(4, (rows_left + 7) / 8);          // two contraction steps per trip (rows past M are zeros in LDS): the second
   for (int s = 0; s < 2 * pairs; s += 2) {                // pair of LDS reads is issued under the first four MFMAs
     const float av0 = yp[s * 256], av1 = yp[s * 256 + 256];
-    const f32x4 bv0 = *(const f32x4*)(xp + s * 256), bv1 = *(const f32x4*)(xp + s * 256 + 256);
+    const f32x4 bv0 = *(const f32x4*)(xp + s * 4 * XS), bv1 = *(const f32x4*)(xp + (s + 1) * 4 * XS);
     mfma16(acc0, av0, bv0.x);
     mfma16(acc1, av0, bv0.y);
     mfma16(acc2, av0, bv0.z);
@@ -208,6 +209,74 @@ __global__ __launch_bounds__(256) void adam_rankb_lds_kernel(const RankbArgs a) 
     }
     gq += (kt + 1 == a.ntile_k);
     kt = (kt + 1 == a.ntile_k) ? 0 : kt + 1;
+  }
+}
+
+// The same pass when it runs BY ITSELF (bf16 models: after the backward, dd_set_adam_blocks_per_cu > 1; no register or LDS budget): a tile
+// of ONE n-tile (16 weight rows) x 256 columns, the four waves on four adjacent 64-column slabs of the same rows.  Above, a workgroup's
+// tile is 64 rows x 64 columns: 256 bytes of 64 different rows (16 MB apart for the 2x-resolution fc1) per tensor and visit -- 49 k DRAM
+// streams advancing 256 bytes at a time across the chip, which some boxes of the pool serve at 5.2 TB/s where a contiguous stream gets
+// 5.7-6.1.  Here a visit is 1 KB of 16 rows.  X tile 32 x 256 (32 KB), one tile ahead in 32 registers; dY tile as above (its first n-tile).
+__global__ __launch_bounds__(256) void adam_rankb_wide_kernel(const RankbArgs a) {
+  __shared__ __attribute__((aligned(16))) float xl[32 * 256];
+  __shared__ __attribute__((aligned(16))) float yl[32 * 64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t xs = dd_rsrc(a.x, a.M * a.K * 4), ys = dd_rsrc(a.dy, a.M * a.N * 4);
+  const int ntk = (a.K + 255) / 256;                       // 256-column tiles per n-tile; the list is (n-tile, tile), tile fastest
+  const int lo = min((int)blockIdx.x * a.per, a.total), hi = min(lo + a.per, a.total);
+  if (lo >= hi) return;
+  int nt = lo / ntk;
+  int kt = lo - nt * ntk;
+  int nt_in_lds = -1;
+  f32x4 xr[8];                                              // thread t: batch rows t / 16 and t / 16 + 16, columns 64 j + 4 (t % 16), j = 0 .. 3
+  auto fetch_x = [&](int tile) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = tile * 256 + 64 * j + 4 * (t & 15);
+      const bool ok = col < a.K;
+      const int off = ((t >> 4) * a.K + (ok ? col : 0)) * 4;
+      const f32x4 v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, off, 0, 0));
+      const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, off, 16 * a.K * 4, 0));
+      xr[2 * j] = ok ? v0 : f32x4{0.f, 0.f, 0.f, 0.f};
+      xr[2 * j + 1] = ok ? v1 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch_x(kt);
+  for (int it = lo; it < hi; ++it) {
+    __syncthreads();                                        // every wave is done with the previous tile's xl (and the previous n-tile's yl)
+    {
+      const int t = threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *(f32x4*)(xl + (t >> 4) * 256 + 64 * j + 4 * (t & 15)) = xr[2 * j];
+        *(f32x4*)(xl + ((t >> 4) + 16) * 256 + 64 * j + 4 * (t & 15)) = xr[2 * j + 1];
+      }
+      if (nt != nt_in_lds) {                                // dY columns 16 nt .. 16 nt + 63 (the first 16 are this n-tile's), swizzled as above
+        const int col = nt * 16 + 4 * (t & 15);
+        const bool ok = col < a.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = (t >> 4) + 16 * j;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ys, (row * a.N + (ok ? col : 0)) * 4, 0, 0));
+          *(f32x4*)(yl + row * 64 + ((4 * (t & 15)) ^ (16 * (row & 3)))) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        nt_in_lds = nt;
+      }
+    }
+    __syncthreads();
+    const bool last_of_row = kt + 1 == ntk;
+    if (it + 1 < hi) fetch_x(last_of_row ? 0 : kt + 1);     // the next tile's X: in flight through this tile's MFMAs and epilogue
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    {
+      const int lane = dd_fresh_lane();
+      const int r = lane & 15, q = lane >> 4;
+      rankb_mfma_chunk<256>(yl + q * 64 + (r ^ (16 * q)), xl + q * 256 + 64 * wave + 4 * r, a.M, acc0, acc1, acc2, acc3);
+    }
+    rankb_epilogue<2>(a, nt, 4 * kt + wave, acc0, acc1, acc2, acc3);      // (returns at once for a slab past K)
+    if (a.bp && kt == 0 && wave == 0) rankb_bias(a, yl, nt, 0);
+    nt += last_of_row;
+    kt = last_of_row ? 0 : kt + 1;
   }
 }
 
@@ -303,7 +372,9 @@ int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const floa
   a.inv_bc2 = 1.f / a.bc2_sqrt;
   a.gscale = grad_scale;
   const bool short_rows = rows <= 32 && a.ntile_k == 1;      // adam_rankb_short_kernel: its work list is of n-groups
-  const long total = (long)((a.ntile_n + 3) / 4) * (short_rows ? 1 : a.ntile_k);
+  // the pass by itself (more than one workgroup per CU: nothing to fit beside) on long rows: 16-row x 256-column tiles
+  const bool wide = rows <= 32 && !short_rows && a.ntile_k >= 64 && dd_adam_blocks_internal() > 1;
+  const long total = wide ? (long)a.ntile_n * ((k + 255) / 256) : (long)((a.ntile_n + 3) / 4) * (short_rows ? 1 : a.ntile_k);
   DD_REQUIRE(total < ((long)1 << 31), DD_ERR_UNSUPPORTED, "adam_rankb: too many tiles");
   a.total = (int)total;
   // one persistent workgroup per CU, as dd_adam_step (dense.hip): nothing of this launch is ever queued ahead of a conv kernel
@@ -313,7 +384,8 @@ int dd_adam_step_rankb(float* p, float* m, float* v, const float* dy, const floa
   hipStream_t st = (hipStream_t)stream;
   // (two k-tiles per group -- the decoder's fc2, K = 128 -- ran on a <2, RG = 1> build of the short form (its RG = 2 build needs 76 registers):
   // 2.98 ms beside the conv backward for 0.80 alone; the long-row form below keeps two rows of p / m / v in flight for it)
-  if (short_rows) hipLaunchKernelGGL((adam_rankb_short_kernel<1, 2>), dim3(grid), dim3(256), 0, st, a);
+  if (wide) hipLaunchKernelGGL(adam_rankb_wide_kernel, dim3(grid), dim3(256), 0, st, a);
+  else if (short_rows) hipLaunchKernelGGL((adam_rankb_short_kernel<1, 2>), dim3(grid), dim3(256), 0, st, a);
   else if (rows <= 32) hipLaunchKernelGGL((adam_rankb_lds_kernel<1, 2>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((adam_rankb_lds_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);
   DD_LAUNCH_CHECK("adam_rankb");

@@ -75,6 +75,33 @@ def test_adam_rankb_matches_fp64(dev, n, k, rows, with_bias, scale, signed):
         assert torch.equal(b.cpu(), b0) and float(bm.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows,with_bias", [(16, True), (32, False), (5, True)])
+def test_adam_rankb_wide_tiles_for_the_pass_by_itself_equal_the_budgeted_kernel(dev, rows, with_bias):
+    """With more than one workgroup per CU (dd_set_adam_blocks_per_cu: the pass runs by itself, bf16 models) long rows take the 16-row x
+    256-column tile form: every element gets the same contraction in the same order as in the 64 x 64 form, so p / m / v and the bias agree
+    bit for bit; K not a multiple of 256 (a ragged last tile) and N not a multiple of 16 included."""
+    from driving_dirty_amd import _lib, ops
+    lib = _lib.lib()
+    torch.manual_seed(rows)
+    n, k = 136, 64 * 70 + 12
+    p0 = torch.randn(n, k, device=dev) * 0.02
+    x, dy = torch.randn(rows, k, device=dev), torch.randn(rows, n, device=dev) * 1e-2
+    b0 = torch.randn(n, device=dev) * 0.02
+    outs = []
+    for blocks in (1, 4):
+        assert lib.dd_set_adam_blocks_per_cu(blocks) == 0
+        try:
+            p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+            b, bm, bv = (b0.clone(), torch.zeros_like(b0), torch.zeros_like(b0)) if with_bias else (None, None, None)
+            for step in (1, 2):
+                ops.adam_step_rankb(p, m, v, dy, x, b, bm, bv, 1e-3, 0.9, 0.999, 1e-8, step)
+            outs.append((p, m, v, b))
+        finally:
+            assert lib.dd_set_adam_blocks_per_cu(1) == 0
+    for a, c in zip(outs[0], outs[1]):
+        assert (a is None and c is None) or torch.equal(a, c)
+
+
 def test_adam_rankb_refuses_bad_arguments(dev):
     from driving_dirty_amd import _lib, ops
     p = torch.zeros(16, 6, device=dev)

@@ -38,7 +38,8 @@ def test_rankb_optimizer_kernels_fit_beside_the_c2_weight_gradient():
         import kernel_resources
     finally:
         sys.path.pop(0)
-    ks = [k for k in kernel_resources.kernels() if "adam_rankb" in k[".name"]]
+    # (adam_rankb_wide_kernel is the form for the pass that runs BY ITSELF -- more than one workgroup per CU -- and has no budget to keep)
+    ks = [k for k in kernel_resources.kernels() if "adam_rankb" in k[".name"] and "wide" not in k[".name"]]
     assert len(ks) == 3, [k[".name"] for k in ks]
     wgrad = [k for k in kernel_resources.kernels() if "conv_wino2_wgradILi4" in k[".name"]]
     assert wgrad and all(k[".vgpr_count"] <= 440 for k in wgrad)
