@@ -47,10 +47,19 @@ def _tiny_batch(dev, step, rank):
 
 
 # ------------------------------------------------------------------------------------------------ sharded optimizer, real kernel
-def _shard_worker(rank, world, port, out, shard, overlap):
+def _shard_worker(rank, world, port, out, shards, overlap):
+    """One process per rank runs the modes in ``shards`` one after the other (one spawn, one process group: the second spawn of a test was
+    3-4 s of interpreter, HIP and gloo start-up per parametrisation)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    for shard in shards:
+        _shard_body(rank, world, out, shard, overlap)
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def _shard_body(rank, world, out, shard, overlap):
     from driving_dirty_amd import ddp
     from driving_dirty_amd.train import TrainStep
     dev = torch.device("cuda:0")
@@ -76,8 +85,7 @@ def _shard_worker(rank, world, port, out, shard, overlap):
         assert "exp_avg" not in st and sum(m.numel() for m, _ in st["shards"].values()) * world == model.fc1.weight.numel()
     torch.cuda.synchronize()
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, f"{out}.{int(shard)}.{rank}")
-    dist.barrier()
-    dist.destroy_process_group()
+    ts.close()
 
 
 @pytest.mark.parametrize("world,overlap", [(2, True), (2, False), (4, True)])
@@ -86,8 +94,7 @@ def test_sharded_hipadam_is_bit_identical_to_the_all_reduce_path(tmp_path, dev, 
     unfrozen after step 0, Adam beside the backward or after it: every replica holds bit for bit the parameters the all-reduce path
     leaves (reduce-scatter over gloo adds in its all-reduce's order; the update is elementwise)."""
     out = str(tmp_path / "s.pt")
-    for shard in (False, True):
-        mp.spawn(_shard_worker, args=(world, free_port(), out, shard, overlap), nprocs=world, join=True)
+    mp.spawn(_shard_worker, args=(world, free_port(), out, (False, True), overlap), nprocs=world, join=True)
     ref = torch.load(f"{out}.0.0")
     start = {k: v.cpu() for k, v in _tiny_model(dev, 1).state_dict().items()}
     assert float((ref["ae.encoder.c2.weight"] - start["ae.encoder.c2.weight"]).abs().max()) > 0      # the unfrozen extractor trained
@@ -101,10 +108,18 @@ def test_sharded_hipadam_is_bit_identical_to_the_all_reduce_path(tmp_path, dev, 
                 assert torch.equal(plain[k], ref[k]), f"rank {rank}: parameter {k} differs from rank 0's"
 
 
-def _factor_worker(rank, world, port, out, factor, overlap, fuse=False):
+def _factor_worker(rank, world, port, out, modes, overlap):
+    """``modes``: (factor, fuse) pairs run one after the other in one process per rank (one spawn, one process group)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    for factor, fuse in modes:
+        _factor_body(rank, world, out, factor, overlap, fuse)
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def _factor_body(rank, world, out, factor, overlap, fuse):
     from driving_dirty_amd import ddp
     from driving_dirty_amd.train import TrainStep
     dev = torch.device("cuda:0")
@@ -128,8 +143,6 @@ def _factor_worker(rank, world, port, out, factor, overlap, fuse=False):
     torch.save({"state": {k: v.cpu() for k, v in model.state_dict().items()}, "grads": grads, "losses": losses}, f"{out}.{int(factor)}.{rank}")
     ts.close()
     assert not ddp.FACTOR_SYNC
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,overlap", [(2, True), (2, False)])
@@ -138,8 +151,7 @@ def test_factor_gather_with_the_rankb_pass_keeps_the_replicas_identical(tmp_path
     gradient tensor exists for the two big Linear layers (``.grad`` stays None, bias included).  Replicas bit-identical to each other;
     losses of three steps equal to the all-reduce path's to 1e-4."""
     out = str(tmp_path / "f.pt")
-    mp.spawn(_factor_worker, args=(world, free_port(), out, False, overlap, False), nprocs=world, join=True)
-    mp.spawn(_factor_worker, args=(world, free_port(), out, True, overlap, True), nprocs=world, join=True)
+    mp.spawn(_factor_worker, args=(world, free_port(), out, ((False, False), (True, True)), overlap), nprocs=world, join=True)
     plain = [torch.load(f"{out}.0.{r}") for r in range(world)]
     fact = [torch.load(f"{out}.1.{r}") for r in range(world)]
     assert len(plain[0]["grads"]) == 5 and not fact[0]["grads"]      # no .grad on the fused layers, ever
@@ -161,8 +173,7 @@ def test_factor_gather_forms_the_global_batch_gradient_on_every_rank(tmp_path, d
     all-reduce path's sum to rounding (one GEMM over the global batch against a sum of per-rank GEMMs), the replicas are bit-identical
     to each other, the losses of three steps agree."""
     out = str(tmp_path / "f.pt")
-    for factor in (False, True):
-        mp.spawn(_factor_worker, args=(world, free_port(), out, factor, overlap), nprocs=world, join=True)
+    mp.spawn(_factor_worker, args=(world, free_port(), out, ((False, False), (True, False)), overlap), nprocs=world, join=True)
     plain = [torch.load(f"{out}.0.{r}") for r in range(world)]
     fact = [torch.load(f"{out}.1.{r}") for r in range(world)]
     assert set(fact[0]["grads"]) == set(plain[0]["grads"]) and len(fact[0]["grads"]) == 5      # head: 3 steps, encoder fc1: after the unfreeze
